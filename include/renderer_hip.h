@@ -1,0 +1,211 @@
+/* renderer_hip.h -- C ABI of librenderer_hip.so, the MI355X (gfx950) implementation of the device layer that
+ * the `renderer` crate reaches through wgpu.  One export per wgpu call site of the reference; each declaration
+ * cites the reference call site(s) it replaces (paths relative to the reference tree).
+ *
+ * Conventions
+ *   - every call returns 0 on success, non-zero on failure; rh_last_error() gives a thread-local message.
+ *     The reference panics on these conditions (unwrap/panic!), so a host shim should panic on non-zero.
+ *   - handles are opaque and reference counted: *_create returns a handle with one reference,
+ *     *_retain / *_release adjust it (the reference clones Buffer/Texture/Program freely: src/buffer.rs:3-6,
+ *     src/texture.rs:3-6, src/program.rs:3-6, and un-submitted command buffers keep old resources alive).
+ *   - single-thread affinity per device, like the reference (RefCell/Rc everywhere), except
+ *     rh_buffer_mapped_ptr memory, which may be read from any thread until the buffer is released
+ *     (the reference reads mapped capture buffers on compressor worker threads: src/compressor.rs:118).
+ */
+#ifndef RENDERER_HIP_H
+#define RENDERER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rh_device rh_device;
+typedef struct rh_buffer rh_buffer;
+typedef struct rh_texture rh_texture;
+typedef struct rh_sampler rh_sampler;
+typedef struct rh_module rh_module;
+typedef struct rh_pipeline rh_pipeline;
+typedef struct rh_cmd rh_cmd;          /* command encoder */
+typedef struct rh_cmdbuf rh_cmdbuf;    /* finished command buffer */
+typedef struct rh_compressor rh_compressor;
+
+/* src/format.rs:3-9 (declaration order = bincode discriminant) */
+enum { RH_FORMAT_R_U8 = 0, RH_FORMAT_BGRA_U8 = 1, RH_FORMAT_RGBA_U8 = 2, RH_FORMAT_RGBA_F16 = 3, RH_FORMAT_RGBA_F32 = 4 };
+/* src/filter_mode.rs:2-5 */
+enum { RH_FILTER_LINEAR = 0, RH_FILTER_NEAREST = 1 };
+/* src/primitive.rs:2-5 */
+enum { RH_TOPOLOGY_TRIANGLE_LIST = 0, RH_TOPOLOGY_TRIANGLE_STRIP = 1 };
+/* wgpu::BlendFactor values the reference uses (src/blend_mode.rs:8-14) plus Zero/SrcAlpha */
+enum { RH_BLEND_ZERO = 0, RH_BLEND_ONE = 1, RH_BLEND_SRC_ALPHA = 2, RH_BLEND_ONE_MINUS_SRC_ALPHA = 3 };
+/* wgpu::LoadOp (src/render_pass.rs:72) */
+enum { RH_LOAD_OP_LOAD = 0, RH_LOAD_OP_CLEAR = 1 };
+/* kinds of flat binding slot, in the order src/pipeline.rs:95-113 emits them */
+enum { RH_SLOT_STORAGE = 0, RH_SLOT_UNIFORM = 1, RH_SLOT_TEXTURE = 2, RH_SLOT_SAMPLER = 3 };
+/* src/visibility.rs:2-15 */
+enum { RH_STAGE_VERTEX = 1, RH_STAGE_FRAGMENT = 2 };
+/* wgpu::BufferUsages bits the reference sets (src/attribute.rs:11, src/instanced.rs:10, src/uniform.rs:10,
+ * src/video_recorder.rs:88) */
+enum { RH_BUFFER_VERTEX = 1, RH_BUFFER_STORAGE = 2, RH_BUFFER_UNIFORM = 4, RH_BUFFER_COPY_DST = 8, RH_BUFFER_MAP_READ = 16 };
+/* wgpu::TextureUsages bits (src/texture.rs:111-114) */
+enum { RH_TEXTURE_BINDING = 1, RH_TEXTURE_COPY_DST = 2, RH_TEXTURE_RENDER_ATTACHMENT = 4, RH_TEXTURE_COPY_SRC = 8 };
+/* device options */
+enum {
+    RH_OPTION_CLIP_TO_VIEWPORT = 0,   /* 1 (default): fragments outside the viewport rectangle are clipped, as strict
+                                         clip-volume clipping gives; 0: only the attachment bounds restrict them */
+};
+
+#define RH_MAX_ATTRIBUTES 8
+#define RH_MAX_SLOTS 32               /* 8 bind groups x 4 bindings (src/pipeline.rs:25-27) */
+#define RH_BINDINGS_PER_GROUP 4
+#define RH_MAX_COLOR_TARGETS 4
+#define RH_COPY_BYTES_PER_ROW_ALIGNMENT 256   /* wgpu::COPY_BYTES_PER_ROW_ALIGNMENT (src/video_recorder.rs:75) */
+
+const char* rh_last_error(void);
+int rh_abi_version(void);
+
+/* ---- device: get_instance/get_adapter/get_device + surface configure (src/renderer.rs:301-354) ------------------- */
+/* Creates a device on HIP ordinal `hip_ordinal` with an offscreen BGRA8 "screen" of width x height (there is no
+ * display: Target::Screen becomes an offscreen texture, src/target.rs:10). */
+int rh_device_create(int hip_ordinal, uint32_t width, uint32_t height, rh_device** out);
+void rh_device_destroy(rh_device* dev);
+/* adapter.get_info() (src/renderer.rs:199-201): device name into `name` (NUL terminated, truncated to cap). */
+int rh_device_info(rh_device* dev, char* name, size_t cap);
+int rh_device_set_option(rh_device* dev, int option, int value);
+/* Blocks until all submitted work has finished (wgpu has no call site for this in the reference; tests and
+ * benchmarks need it). */
+int rh_device_synchronize(rh_device* dev);
+/* The HIP stream all submitted work runs on (a hipStream_t), for callers that time with HIP events. */
+void* rh_device_stream(rh_device* dev);
+
+/* surface.configure / get_current_texture / present (src/renderer.rs:301-319,96,115) */
+int rh_screen_texture(rh_device* dev, rh_texture** out);       /* borrowed: do not release */
+int rh_screen_resize(rh_device* dev, uint32_t width, uint32_t height);
+
+/* ---- buffers: device.create_buffer, queue.write_buffer, mapped-at-creation fill (src/buffer.rs:42,54,61-64;
+ *      src/video_recorder.rs:88-91) ------------------------------------------------------------------------------------ */
+int rh_buffer_create(rh_device* dev, size_t size, uint32_t usage, const void* init, size_t init_len, rh_buffer** out);
+int rh_buffer_write(rh_buffer* buf, size_t offset, const void* data, size_t len);
+size_t rh_buffer_size(rh_buffer* buf);
+/* Device address of the buffer (for callers that fill it with their own kernels / torch tensors). */
+void* rh_buffer_device_ptr(rh_buffer* buf);
+void rh_buffer_retain(rh_buffer* buf);
+void rh_buffer_release(rh_buffer* buf);
+/* buffer.slice(..).map_async(Read, cb) / get_mapped_range (src/video_recorder.rs:141; src/video_frame.rs:64;
+ * src/compressor.rs:118).  The callback fires from rh_poll or rh_submit once the copy into pinned host memory is done. */
+typedef void (*rh_map_callback)(void* user, int ok);
+int rh_buffer_map_async(rh_buffer* buf, rh_map_callback cb, void* user);
+int rh_buffer_mapped_ptr(rh_buffer* buf, const uint8_t** ptr, size_t* len);
+int rh_buffer_unmap(rh_buffer* buf);
+/* Drives map callbacks (wgpu fires them from later submits; the reference never calls device.poll). */
+int rh_poll(rh_device* dev, int wait);
+
+/* ---- textures: device.create_texture / create_view / create_sampler / queue.write_texture
+ *      (src/texture.rs:110-158,45-56) ---------------------------------------------------------------------------------- */
+int rh_texture_create(rh_device* dev, uint32_t width, uint32_t height, uint32_t layers, uint32_t format,
+                      uint32_t samples, uint32_t usage, rh_texture** out);
+int rh_texture_write(rh_texture* tex, uint32_t x, uint32_t y, uint32_t layer, uint32_t width, uint32_t height,
+                     const void* data, size_t data_len, uint32_t bytes_per_row);
+/* Synchronous read-back of one layer, tightly packed rows (test/inspection helper: the reference reads textures
+ * only through copy_texture_to_buffer + map). */
+int rh_texture_read(rh_texture* tex, uint32_t layer, void* out, size_t out_len);
+int rh_texture_size(rh_texture* tex, uint32_t* width, uint32_t* height, uint32_t* layers, uint32_t* format);
+void* rh_texture_device_ptr(rh_texture* tex);
+void rh_texture_retain(rh_texture* tex);
+void rh_texture_release(rh_texture* tex);
+/* ClampToEdge on all axes, mag = min = filter, mipmap nearest, lod 0..0 (src/texture.rs:141-158) */
+int rh_sampler_create(rh_device* dev, uint32_t filter, rh_sampler** out);
+void rh_sampler_release(rh_sampler* s);
+
+/* ---- shader modules: device.create_shader_module (src/program.rs:43-48) -------------------------------------------- */
+/* `code_object` is a gfx950 code object produced by the offline shader build (src/compiler.rs:22-33 replaced by
+ * hipcc --genco); loaded with hipModuleLoadData.  A vertex-stage object exports the binning kernels, a
+ * fragment-stage object exports the tile kernels; both carry an `rh_module_info` record. */
+int rh_module_load(rh_device* dev, const void* code_object, size_t size, rh_module** out);
+void rh_module_retain(rh_module* m);
+void rh_module_release(rh_module* m);
+
+/* ---- pipelines: create_bind_group_layout / create_bind_group / create_pipeline_layout / create_render_pipeline
+ *      (src/pipeline.rs:90-162,197-237) ------------------------------------------------------------------------------- */
+typedef struct rh_attribute_desc {
+    uint32_t location;      /* shader location (src/attribute.rs:28) */
+    uint32_t size;          /* 1..4 f32 per vertex, tightly packed, step mode Vertex (src/pipeline.rs:219-229) */
+} rh_attribute_desc;
+
+typedef struct rh_slot_desc {
+    uint32_t kind;          /* RH_SLOT_* */
+    uint32_t visibility;    /* RH_STAGE_* mask */
+    void* resource;         /* rh_buffer* (storage/uniform), rh_texture* or rh_sampler* */
+} rh_slot_desc;
+
+typedef struct rh_color_target_desc {
+    uint32_t format;        /* RH_FORMAT_* */
+    uint32_t src_factor;    /* same factors for colour and alpha, op Add, write mask ALL (src/blend_mode.rs:23-40) */
+    uint32_t dst_factor;
+} rh_color_target_desc;
+
+typedef struct rh_pipeline_desc {
+    rh_module* vertex_module;
+    rh_module* fragment_module;
+    uint32_t n_attributes;
+    const rh_attribute_desc* attributes;   /* vertex buffer slot i = attributes[i] (src/render_pass.rs:35-37) */
+    uint32_t n_slots;
+    const rh_slot_desc* slots;             /* flat slot i = (set i/4, binding i%4) (src/pipeline.rs:90-131) */
+    uint32_t topology;                     /* RH_TOPOLOGY_*; no culling, no depth/stencil (src/pipeline.rs:150-159,197-207) */
+    uint32_t samples;                      /* only 1 is implemented */
+    uint32_t n_targets;
+    const rh_color_target_desc* targets;   /* incl. the extra RGBA8 recording target (src/pipeline.rs:133-142) */
+} rh_pipeline_desc;
+
+int rh_pipeline_create(rh_device* dev, const rh_pipeline_desc* desc, rh_pipeline** out);
+void rh_pipeline_retain(rh_pipeline* p);
+void rh_pipeline_release(rh_pipeline* p);
+
+/* ---- command encoding: create_command_encoder / begin_render_pass / set_* / draw / copy_texture_to_buffer / finish
+ *      (src/render_pass.rs:25-53; src/video_recorder.rs:107-128) ------------------------------------------------------ */
+typedef struct rh_attachment_desc {
+    rh_texture* texture;
+    uint32_t load_op;       /* RH_LOAD_OP_* ; store op is always Store (src/render_pass.rs:73) */
+    double clear[4];        /* wgpu::Color (src/clear_color.rs:7-16) */
+} rh_attachment_desc;
+
+typedef struct rh_pass_desc {
+    rh_pipeline* pipeline;
+    uint32_t n_attachments;
+    const rh_attachment_desc* attachments;
+    uint32_t n_vertex_buffers;
+    rh_buffer* const* vertex_buffers;      /* slot order = pipeline attribute order */
+    int32_t has_viewport;                  /* src/render_pass.rs:39-41 */
+    float viewport[6];                     /* x, y, width, height, min_depth, max_depth */
+    uint32_t vertex_count;                 /* draw(0..vertex_count, 0..instance_count) (src/render_pass.rs:43) */
+    uint32_t instance_count;
+} rh_pass_desc;
+
+int rh_cmd_begin(rh_device* dev, rh_cmd** out);
+int rh_cmd_render_pass(rh_cmd* cmd, const rh_pass_desc* pass);
+/* encoder.copy_texture_to_buffer (src/video_recorder.rs:113-127): copies width x height texels starting at
+ * (origin_x, origin_y) of layer 0 into `buf` with `bytes_per_row` pitch (a multiple of 256). */
+int rh_cmd_copy_texture_to_buffer(rh_cmd* cmd, rh_texture* tex, uint32_t origin_x, uint32_t origin_y,
+                                  rh_buffer* buf, uint32_t bytes_per_row, uint32_t rows_per_image,
+                                  uint32_t width, uint32_t height);
+int rh_cmd_finish(rh_cmd* cmd, rh_cmdbuf** out);   /* consumes cmd */
+void rh_cmdbuf_release(rh_cmdbuf* cb);
+/* queue.submit (src/renderer.rs:119-122): executes the command buffers in order on the device's stream and
+ * releases them.  Also polls pending map callbacks. */
+int rh_submit(rh_device* dev, rh_cmdbuf* const* list, size_t n);
+
+/* ---- statistics of the most recent render pass executed (diagnostics for benchmarks) ------------------------------- */
+typedef struct rh_pass_stats {
+    uint64_t clusters;        /* binning units (pairs of consecutive triangles) */
+    uint64_t bin_entries;     /* (cluster, tile) pairs after binning */
+    uint32_t tiles_x, tiles_y;
+    uint32_t tile_size;
+} rh_pass_stats;
+int rh_device_last_pass_stats(rh_device* dev, rh_pass_stats* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RENDERER_HIP_H */

@@ -1,0 +1,410 @@
+// TEST INFRASTRUCTURE ONLY -- CPU restatement of the draw path, used as the parity checker.
+//
+// Nothing in the shipped product may include, link or call this file; only tests/,
+// __graft_entry__.smoke() and bench.py's cpu_baseline leg do.
+//
+// PARITY UNPINNED: the reference (/root/reference, a Rust crate over wgpu) contains no
+// rasterisation arithmetic of its own and no golden images; all per-vertex / per-triangle /
+// per-fragment arithmetic lives in wgpu -> Vulkan -> Mesa lavapipe, none of which is present
+// in /root/reference or buildable here.  This file restates:
+//   * the STATE the reference selects (what is bound where, formats, blend factors, sampler
+//     modes, topology, viewport, clear/load) -- each function cites the reference file:line;
+//   * the Vulkan 1.3 rasterisation rules that state selects (top-left fill rule on a
+//     1/256-pixel snapped grid, barycentric plane-equation varyings, clamp-to-edge
+//     bilinear/nearest unnormalised-coordinate sampling, fixed-function blend with
+//     round-to-nearest-even UNORM8 conversion after every fragment).
+// Every float operation below is written as an explicit single IEEE-754 binary32 operation
+// (fmaf = one fused rounding) so that another implementation can reproduce it bit for bit.
+// Build with -ffp-contract=off.
+//
+// C ABI (see orc_draw below) so that Python can drive it through ctypes.
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <thread>
+#include <vector>
+#include <algorithm>
+
+extern "C" {
+
+// Format discriminants follow the declaration order of reference src/format.rs:3-9.
+enum { ORC_FMT_R_U8 = 0, ORC_FMT_BGRA_U8 = 1, ORC_FMT_RGBA_U8 = 2, ORC_FMT_RGBA_F16 = 3, ORC_FMT_RGBA_F32 = 4 };
+// reference src/filter_mode.rs:2-5
+enum { ORC_FILTER_LINEAR = 0, ORC_FILTER_NEAREST = 1 };
+// reference src/primitive.rs:2-5
+enum { ORC_TOPO_TRIANGLE_LIST = 0, ORC_TOPO_TRIANGLE_STRIP = 1 };
+// blend factors used by reference src/blend_mode.rs:8-14 (+ Zero/SrcAlpha for completeness)
+enum { ORC_BF_ZERO = 0, ORC_BF_ONE = 1, ORC_BF_SRC_ALPHA = 2, ORC_BF_ONE_MINUS_SRC_ALPHA = 3 };
+// built-in shader programs (restatements of GLSL sources)
+enum {
+    ORC_SHADER_HELLO = 0,        // reference examples/quads/hello.vert:5-15 + hello.frag:7-17
+    ORC_SHADER_SIZED = 1,        // hello with a vec4 {x, y, half_w, half_h} instance record
+    ORC_SHADER_HELLO_NEAREST_LAYER = 2, // hello sampling layer `uniform[0]` of a 2D-array texture
+};
+
+struct orc_texture {
+    const uint8_t* data;   // tightly packed rows, layer-major (reference src/texture.rs:45-56)
+    uint32_t width, height, layers;
+    uint32_t format;       // ORC_FMT_*
+    uint32_t filter;       // ORC_FILTER_* (mag = min, mip nearest, lod 0; reference src/texture.rs:141-158)
+};
+
+struct orc_target {
+    uint8_t* data;         // width*height*4 bytes, row 0 = top
+    uint32_t width, height;
+    uint32_t format;       // ORC_FMT_RGBA_U8 or ORC_FMT_BGRA_U8 (reference src/target.rs:8-13)
+    int32_t  clear;        // 1 = LoadOp::Clear(clear_rgba), 0 = LoadOp::Load (reference src/render_pass.rs:71-74)
+    double   clear_rgba[4];// reference src/clear_color.rs:7-16 (f32 -> f64)
+};
+
+struct orc_draw {
+    int32_t  shader;                 // ORC_SHADER_*
+    int32_t  topology;               // ORC_TOPO_*
+    uint32_t vertex_count;           // draw(0..vertex_count, 0..instance_count): reference src/render_pass.rs:43
+    uint32_t instance_count;
+    const float* attr[8];            // one tightly packed f32 buffer per attribute location (reference src/attribute.rs:10-29)
+    uint32_t attr_size[8];           // 1..4 floats
+    const float* storage[4];         // read-only storage buffers, in slot order (reference src/instanced.rs:9-38)
+    const float* uniform[4];         // uniform buffers (reference src/uniform.rs:9-38)
+    orc_texture  tex[4];             // textures in slot order
+    int32_t  has_viewport;           // reference src/render_pass.rs:39-41
+    float    viewport[4];            // margin_x, margin_y, width, height
+    int32_t  clip_to_viewport;       // 1: fragments outside the viewport rectangle are clipped (strict clip volume)
+    uint32_t src_factor, dst_factor; // same factors for colour and alpha, op Add (reference src/blend_mode.rs:23-40)
+    uint32_t n_targets;              // colour attachments incl. the recording attachment (reference src/render_pass.rs:60-69)
+    orc_target targets[4];
+    int32_t  threads;                // <=0: hardware concurrency
+    uint64_t fragments_out;          // out: number of blended fragments per attachment
+};
+
+int orc_render(orc_draw* d);
+
+} // extern "C"
+
+namespace {
+
+constexpr int SUBPIXEL_BITS = 8;
+constexpr float SUBPIXEL_SCALE = 256.0f;
+constexpr float INV_SUBPIXEL = 1.0f / 256.0f;
+// Guard band: snapped coordinates are clamped to [-8192 px, 24576 px) so that every edge delta fits 24 signed bits.
+constexpr float GB_LO = -8192.0f * 256.0f;
+constexpr float GB_HI = 24576.0f * 256.0f - 1.0f;
+constexpr float INV_255 = 1.0f / 255.0f;
+constexpr int MAX_VARYINGS = 8;
+
+struct VsOut { float pos[4]; float var[MAX_VARYINGS]; };
+
+struct Shader {
+    int n_varyings;
+    int n_outputs;
+    void (*vs)(const orc_draw&, uint32_t vertex, uint32_t instance, VsOut&);
+    void (*fs)(const orc_draw&, const float* var, float out[][4]);
+};
+
+// ---- sampler: Vulkan unnormalised-coordinate rules for the sampler the reference creates --------------------
+// ClampToEdge on every axis, mag = min = filter, one mip level (reference src/texture.rs:141-158).
+inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+inline void fetch_texel(const orc_texture& t, int x, int y, uint32_t layer, float out[4]) {
+    size_t idx = ((size_t)layer * t.height + (size_t)y) * t.width + (size_t)x;
+    switch (t.format) {
+    case ORC_FMT_R_U8: out[0] = (float)t.data[idx]; out[1] = 0.0f; out[2] = 0.0f; out[3] = 255.0f; break;
+    case ORC_FMT_BGRA_U8: { const uint8_t* p = t.data + idx * 4; out[0] = p[2]; out[1] = p[1]; out[2] = p[0]; out[3] = p[3]; break; }
+    default: { const uint8_t* p = t.data + idx * 4; out[0] = p[0]; out[1] = p[1]; out[2] = p[2]; out[3] = p[3]; break; }
+    }
+}
+
+// Result in [0,1].  Texel values are kept on the 0..255 scale through the lerps and scaled once at the end.
+void sample_2d(const orc_texture& t, float s, float tc, uint32_t layer, float out[4]) {
+    const int W = (int)t.width, H = (int)t.height;
+    if (layer >= t.layers) layer = t.layers - 1;
+    if (t.filter == ORC_FILTER_NEAREST) {
+        float u = floorf(s * (float)W), v = floorf(tc * (float)H);
+        u = fminf(fmaxf(u, -1.0f), (float)W); v = fminf(fmaxf(v, -1.0f), (float)H);
+        int i = clampi((int)u, 0, W - 1), j = clampi((int)v, 0, H - 1);
+        float c[4]; fetch_texel(t, i, j, layer, c);
+        for (int k = 0; k < 4; k++) out[k] = c[k] * INV_255;
+        return;
+    }
+    float u = fmaf(s, (float)W, -0.5f), v = fmaf(tc, (float)H, -0.5f);
+    float fu = floorf(u), fv = floorf(v);
+    float a = u - fu, b = v - fv;
+    fu = fminf(fmaxf(fu, -1.0f), (float)W); fv = fminf(fmaxf(fv, -1.0f), (float)H);
+    int i0 = clampi((int)fu, 0, W - 1), i1 = clampi((int)fu + 1, 0, W - 1);
+    int j0 = clampi((int)fv, 0, H - 1), j1 = clampi((int)fv + 1, 0, H - 1);
+    float t00[4], t10[4], t01[4], t11[4];
+    fetch_texel(t, i0, j0, layer, t00); fetch_texel(t, i1, j0, layer, t10);
+    fetch_texel(t, i0, j1, layer, t01); fetch_texel(t, i1, j1, layer, t11);
+    for (int k = 0; k < 4; k++) {
+        float top = fmaf(a, t10[k] - t00[k], t00[k]);
+        float bot = fmaf(a, t11[k] - t01[k], t01[k]);
+        float c = fmaf(b, bot - top, top);
+        out[k] = c * INV_255;
+    }
+}
+
+// ---- shaders ---------------------------------------------------------------------------------------------------
+// hello.vert:12-15: v_tex_coord = a_tex_coord; gl_Position = vec4(a_position + i_offset[gl_InstanceIndex], 0, 1)
+void hello_vs(const orc_draw& d, uint32_t v, uint32_t inst, VsOut& o) {
+    const float* pos = d.attr[0] + (size_t)v * d.attr_size[0];
+    const float* uv = d.attr[1] + (size_t)v * d.attr_size[1];
+    const float* off = d.storage[0] + (size_t)inst * 2;   // ArrayStride 8 (std430 vec2[])
+    o.pos[0] = pos[0] + off[0]; o.pos[1] = pos[1] + off[1]; o.pos[2] = 0.0f; o.pos[3] = 1.0f;
+    o.var[0] = uv[0]; o.var[1] = uv[1];
+}
+// hello.frag:14-17: f_color = texture(sampler2D(t_texture, s_sampler), v_tex_coord); f_recording = f_color
+void hello_fs(const orc_draw& d, const float* var, float out[][4]) {
+    float c[4]; sample_2d(d.tex[0], var[0], var[1], 0, c);
+    for (uint32_t a = 0; a < 2; a++) for (int k = 0; k < 4; k++) out[a][k] = c[k];
+}
+// hello with per-instance size: storage record vec4 {x, y, half_w, half_h}; pos = a_position * half + xy
+void sized_vs(const orc_draw& d, uint32_t v, uint32_t inst, VsOut& o) {
+    const float* pos = d.attr[0] + (size_t)v * d.attr_size[0];
+    const float* uv = d.attr[1] + (size_t)v * d.attr_size[1];
+    const float* r = d.storage[0] + (size_t)inst * 4;
+    o.pos[0] = fmaf(pos[0], r[2], r[0]); o.pos[1] = fmaf(pos[1], r[3], r[1]); o.pos[2] = 0.0f; o.pos[3] = 1.0f;
+    o.var[0] = uv[0]; o.var[1] = uv[1];
+}
+// hello sampling layer uniform[0][0] (as float -> int) of a 2D array
+void layer_fs(const orc_draw& d, const float* var, float out[][4]) {
+    float lf = d.uniform[0] ? d.uniform[0][0] : 0.0f;
+    uint32_t layer = lf > 0.0f ? (uint32_t)lf : 0u;
+    float c[4]; sample_2d(d.tex[0], var[0], var[1], layer, c);
+    for (uint32_t a = 0; a < 2; a++) for (int k = 0; k < 4; k++) out[a][k] = c[k];
+}
+
+const Shader SHADERS[] = {
+    { 2, 2, hello_vs, hello_fs },
+    { 2, 2, sized_vs, hello_fs },
+    { 2, 2, hello_vs, layer_fs },
+};
+
+// ---- triangle setup ----------------------------------------------------------------------------------------------
+struct Vert { int32_t X, Y; float rw; bool ok; float var[MAX_VARYINGS]; };
+
+struct Tri {
+    int32_t A[3], B[3]; int64_t Cq[3];   // inside <=> A*i + B*j + Cq >= 0 for all three edges (i, j = pixel indices)
+    int32_t X0, Y0;
+    int x0, y0, x1, y1;                  // inclusive pixel bbox, already intersected with the scissor
+    float v0[MAX_VARYINGS], dvdx[MAX_VARYINGS], dvdy[MAX_VARYINGS];
+    float q0, dqdx, dqdy;                // 1/w plane
+    bool persp;
+};
+
+struct Scissor { int x0, y0, x1, y1; };  // [x0,x1) x [y0,y1)
+
+struct ViewXf { float hw, hh, ox, oy; };
+
+inline int32_t snap(float w) {
+    float t = (w - 0.5f) * SUBPIXEL_SCALE;        // pixel centres land on multiples of 256
+    t = fminf(fmaxf(t, GB_LO), GB_HI);
+    return (int32_t)rintf(t);                      // round half to even
+}
+
+Vert run_vertex(const orc_draw& d, const Shader& sh, const ViewXf& xf, uint32_t v, uint32_t inst) {
+    VsOut o; std::memset(&o, 0, sizeof o);
+    sh.vs(d, v, inst, o);
+    Vert r; r.ok = true;
+    float x = o.pos[0], y = o.pos[1], w = o.pos[3];
+    if (!(w > 0.0f) || std::isnan(x) || std::isnan(y)) { r.ok = false; r.X = r.Y = 0; r.rw = 1.0f; return r; }
+    float rw = 1.0f;
+    if (w != 1.0f) { rw = 1.0f / w; x = x * rw; y = y * rw; }
+    // Vulkan viewport transform with wgpu's y-up NDC: x_w = x*w/2 + (vx + w/2), y_w = -y*h/2 + (vy + h/2)
+    float xw = fmaf(x, xf.hw, xf.ox);
+    float yw = fmaf(y, -xf.hh, xf.oy);
+    r.X = snap(xw); r.Y = snap(yw); r.rw = rw;
+    for (int k = 0; k < sh.n_varyings; k++) r.var[k] = o.var[k];
+    return r;
+}
+
+inline int64_t asr8(int64_t v) { return v >> SUBPIXEL_BITS; }   // floor division by 256
+
+bool setup_tri(const Shader& sh, Vert a, Vert b, Vert c, const Scissor& sc, Tri& t) {
+    if (!a.ok || !b.ok || !c.ok) return false;
+    int64_t area2 = (int64_t)(b.X - a.X) * (c.Y - a.Y) - (int64_t)(c.X - a.X) * (b.Y - a.Y);
+    if (area2 == 0) return false;
+    if (area2 < 0) std::swap(b, c);     // no culling (reference src/pipeline.rs:197-207): both windings drawn
+    const Vert* v[3] = { &a, &b, &c };
+    for (int e = 0; e < 3; e++) {
+        const Vert& p = *v[e]; const Vert& q = *v[(e + 1) % 3];
+        int32_t A = p.Y - q.Y, B = q.X - p.X;
+        int64_t C = -((int64_t)A * p.X + (int64_t)B * p.Y);
+        bool top_left = (A > 0) || (A == 0 && B > 0);
+        t.A[e] = A; t.B[e] = B; t.Cq[e] = asr8(C + (top_left ? 0 : -1));
+    }
+    int32_t minX = std::min(a.X, std::min(b.X, c.X)), maxX = std::max(a.X, std::max(b.X, c.X));
+    int32_t minY = std::min(a.Y, std::min(b.Y, c.Y)), maxY = std::max(a.Y, std::max(b.Y, c.Y));
+    t.x0 = std::max(sc.x0, (int)((minX + 255) >> 8)); t.x1 = std::min(sc.x1 - 1, (int)(maxX >> 8));
+    t.y0 = std::max(sc.y0, (int)((minY + 255) >> 8)); t.y1 = std::min(sc.y1 - 1, (int)(maxY >> 8));
+    if (t.x0 > t.x1 || t.y0 > t.y1) return false;
+    t.X0 = a.X; t.Y0 = a.Y;
+    float e1x = (float)(b.X - a.X) * INV_SUBPIXEL, e1y = (float)(b.Y - a.Y) * INV_SUBPIXEL;
+    float e2x = (float)(c.X - a.X) * INV_SUBPIXEL, e2y = (float)(c.Y - a.Y) * INV_SUBPIXEL;
+    float area = fmaf(e1x, e2y, -(e2x * e1y));
+    float inv = 1.0f / area;
+    t.persp = !(a.rw == 1.0f && b.rw == 1.0f && c.rw == 1.0f);
+    auto plane = [&](float f0, float f1, float f2, float& o0, float& ox, float& oy) {
+        float d1 = f1 - f0, d2 = f2 - f0;
+        o0 = f0;
+        ox = fmaf(d1, e2y, -(d2 * e1y)) * inv;
+        oy = fmaf(d2, e1x, -(d1 * e2x)) * inv;
+    };
+    for (int k = 0; k < sh.n_varyings; k++) {
+        if (t.persp) plane(a.var[k] * a.rw, b.var[k] * b.rw, c.var[k] * c.rw, t.v0[k], t.dvdx[k], t.dvdy[k]);
+        else plane(a.var[k], b.var[k], c.var[k], t.v0[k], t.dvdx[k], t.dvdy[k]);
+    }
+    plane(a.rw, b.rw, c.rw, t.q0, t.dqdx, t.dqdy);
+    return true;
+}
+
+// ---- ROP ---------------------------------------------------------------------------------------------------------------
+inline float factor(uint32_t f, float src_alpha) {
+    switch (f) {
+    case ORC_BF_ZERO: return 0.0f;
+    case ORC_BF_ONE: return 1.0f;
+    case ORC_BF_SRC_ALPHA: return src_alpha;
+    default: return 1.0f - src_alpha;
+    }
+}
+
+inline uint8_t to_unorm8(float o) {
+    o = fminf(fmaxf(o, 0.0f), 1.0f);              // NaN -> 0
+    return (uint8_t)rintf(o * 255.0f);             // round half to even
+}
+
+// out = src*SF + dst*DF per channel, alpha included (reference src/blend_mode.rs:31-40), destination read back as
+// UNORM8 and the result re-quantised after every fragment.
+inline void blend_store(const orc_draw& d, const orc_target& tg, size_t pix, const float src[4]) {
+    uint8_t* p = tg.data + pix * 4;
+    const bool bgra = tg.format == ORC_FMT_BGRA_U8;
+    const float sf = factor(d.src_factor, src[3]), df = factor(d.dst_factor, src[3]);
+    uint8_t q[4];
+    for (int k = 0; k < 4; k++) {
+        int byte = bgra ? (k == 0 ? 2 : (k == 2 ? 0 : k)) : k;
+        float dst = (float)p[byte] * INV_255;
+        q[k] = to_unorm8(fmaf(dst, df, src[k] * sf));
+    }
+    if (bgra) { p[0] = q[2]; p[1] = q[1]; p[2] = q[0]; p[3] = q[3]; }
+    else { p[0] = q[0]; p[1] = q[1]; p[2] = q[2]; p[3] = q[3]; }
+}
+
+void clear_rows(const orc_target& tg, int y0, int y1) {
+    if (!tg.clear) return;
+    uint8_t q[4];
+    for (int k = 0; k < 4; k++) q[k] = to_unorm8((float)tg.clear_rgba[k]);
+    uint8_t px[4] = { q[0], q[1], q[2], q[3] };
+    if (tg.format == ORC_FMT_BGRA_U8) { px[0] = q[2]; px[2] = q[0]; }
+    for (int y = y0; y < y1; y++) {
+        uint8_t* row = tg.data + (size_t)y * tg.width * 4;
+        for (uint32_t x = 0; x < tg.width; x++) std::memcpy(row + (size_t)x * 4, px, 4);
+    }
+}
+
+// Triangles of instance `inst`, in primitive order.  Strip triangle i uses vertices (i, i+1, i+2) for even i and
+// (i, i+2, i+1) for odd i (Vulkan 1.3 section 21.1.7); list triangle i uses (3i, 3i+1, 3i+2).
+inline uint32_t tris_per_instance(const orc_draw& d) {
+    if (d.topology == ORC_TOPO_TRIANGLE_STRIP) return d.vertex_count >= 3 ? d.vertex_count - 2 : 0;
+    return d.vertex_count / 3;
+}
+inline void tri_vertices(const orc_draw& d, uint32_t i, uint32_t idx[3]) {
+    if (d.topology == ORC_TOPO_TRIANGLE_STRIP) {
+        idx[0] = i; idx[1] = (i & 1) ? i + 2 : i + 1; idx[2] = (i & 1) ? i + 1 : i + 2;
+    } else { idx[0] = 3 * i; idx[1] = 3 * i + 1; idx[2] = 3 * i + 2; }
+}
+
+void shade_tri(const orc_draw& d, const Shader& sh, const Tri& t, int band_y0, int band_y1, uint64_t& frags) {
+    int y0 = std::max(t.y0, band_y0), y1 = std::min(t.y1, band_y1 - 1);
+    for (int j = y0; j <= y1; j++) {
+        for (int i = t.x0; i <= t.x1; i++) {
+            bool in = true;
+            for (int e = 0; e < 3; e++)
+                in = in && ((int64_t)t.A[e] * i + (int64_t)t.B[e] * j + t.Cq[e] >= 0);
+            if (!in) continue;
+            float dx = (float)(i * 256 - t.X0) * INV_SUBPIXEL, dy = (float)(j * 256 - t.Y0) * INV_SUBPIXEL;
+            float var[MAX_VARYINGS];
+            for (int k = 0; k < sh.n_varyings; k++) var[k] = fmaf(t.dvdy[k], dy, fmaf(t.dvdx[k], dx, t.v0[k]));
+            if (t.persp) {
+                float q = fmaf(t.dqdy, dy, fmaf(t.dqdx, dx, t.q0));
+                for (int k = 0; k < sh.n_varyings; k++) var[k] = var[k] / q;
+            }
+            float out[4][4];
+            sh.fs(d, var, out);
+            for (uint32_t a = 0; a < d.n_targets; a++) {
+                const orc_target& tg = d.targets[a];
+                blend_store(d, tg, (size_t)j * tg.width + (size_t)i, out[a < (uint32_t)sh.n_outputs ? a : sh.n_outputs - 1]);
+            }
+            frags++;
+        }
+    }
+}
+
+} // namespace
+
+extern "C" int orc_render(orc_draw* d) {
+    if (d->shader < 0 || d->shader >= (int)(sizeof SHADERS / sizeof SHADERS[0])) return -1;
+    if (d->n_targets == 0) return 0;            // reference src/render_pass.rs:26: no targets, empty command buffer
+    if (d->n_targets > 4) return -2;
+    const Shader& sh = SHADERS[d->shader];
+    const int W = (int)d->targets[0].width, H = (int)d->targets[0].height;
+    for (uint32_t a = 1; a < d->n_targets; a++)
+        if ((int)d->targets[a].width != W || (int)d->targets[a].height != H) return -3;
+
+    float vp[4] = { 0.0f, 0.0f, (float)W, (float)H };
+    if (d->has_viewport) std::memcpy(vp, d->viewport, sizeof vp);
+    ViewXf xf; xf.hw = vp[2] * 0.5f; xf.hh = vp[3] * 0.5f; xf.ox = vp[0] + xf.hw; xf.oy = vp[1] + xf.hh;
+    Scissor sc = { 0, 0, W, H };
+    if (d->clip_to_viewport) {
+        // pixel centre (i + 0.5) inside [vx, vx + vw)
+        sc.x0 = std::max(0, (int)std::ceil((double)vp[0] - 0.5));
+        sc.y0 = std::max(0, (int)std::ceil((double)vp[1] - 0.5));
+        sc.x1 = std::min(W, (int)std::ceil((double)vp[0] + (double)vp[2] - 0.5));
+        sc.y1 = std::min(H, (int)std::ceil((double)vp[1] + (double)vp[3] - 0.5));
+    }
+
+    const uint32_t tpi = tris_per_instance(*d);
+    int nthreads = d->threads > 0 ? d->threads : (int)std::thread::hardware_concurrency();
+    if (nthreads < 1) nthreads = 1;
+    nthreads = std::min(nthreads, std::max(1, H / 8));
+
+    // Set up every triangle once (shared by all bands), in primitive order.
+    std::vector<Tri> tris;
+    const bool empty_scissor = sc.x0 >= sc.x1 || sc.y0 >= sc.y1;
+    if (!empty_scissor && tpi > 0) {
+        tris.reserve((size_t)d->instance_count * tpi);
+        std::vector<Vert> verts(d->vertex_count);
+        for (uint32_t inst = 0; inst < d->instance_count; inst++) {
+            for (uint32_t v = 0; v < d->vertex_count; v++) verts[v] = run_vertex(*d, sh, xf, v, inst);
+            for (uint32_t i = 0; i < tpi; i++) {
+                uint32_t idx[3]; tri_vertices(*d, i, idx);
+                Tri t;
+                if (setup_tri(sh, verts[idx[0]], verts[idx[1]], verts[idx[2]], sc, t)) tris.push_back(t);
+            }
+        }
+    }
+
+    // Row bands: each thread owns a band of rows and walks every triangle in order, so per-pixel blend order is
+    // primitive order regardless of the thread count.
+    std::vector<uint64_t> frags(nthreads, 0);
+    auto work = [&](int tid) {
+        int by0 = (int)((int64_t)H * tid / nthreads), by1 = (int)((int64_t)H * (tid + 1) / nthreads);
+        for (uint32_t a = 0; a < d->n_targets; a++) clear_rows(d->targets[a], by0, by1);
+        uint64_t n = 0;
+        for (const Tri& t : tris) {
+            if (t.y1 < by0 || t.y0 >= by1) continue;
+            shade_tri(*d, sh, t, by0, by1, n);
+        }
+        frags[tid] = n;
+    };
+    if (nthreads == 1) work(0);
+    else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nthreads; t++) pool.emplace_back(work, t);
+        for (auto& th : pool) th.join();
+    }
+    uint64_t total = 0; for (uint64_t n : frags) total += n;
+    d->fragments_out = total;
+    return 0;
+}
+
+extern "C" int orc_abi_version(void) { return 1; }

@@ -1,0 +1,137 @@
+"""ctypes binding of librenderer_hip.so (the C ABI in include/renderer_hip.h).
+
+The library is built in-tree by renderer_amd.build (hipcc, gfx950).  There is no CPU fallback: if the library is
+missing or a call fails, an exception is raised (the reference panics on the corresponding wgpu failures).
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "librenderer_hip.so")
+
+FORMAT_R_U8, FORMAT_BGRA_U8, FORMAT_RGBA_U8, FORMAT_RGBA_F16, FORMAT_RGBA_F32 = range(5)
+FILTER_LINEAR, FILTER_NEAREST = 0, 1
+TOPOLOGY_TRIANGLE_LIST, TOPOLOGY_TRIANGLE_STRIP = 0, 1
+BLEND_ZERO, BLEND_ONE, BLEND_SRC_ALPHA, BLEND_ONE_MINUS_SRC_ALPHA = range(4)
+LOAD_OP_LOAD, LOAD_OP_CLEAR = 0, 1
+SLOT_STORAGE, SLOT_UNIFORM, SLOT_TEXTURE, SLOT_SAMPLER = range(4)
+STAGE_VERTEX, STAGE_FRAGMENT = 1, 2
+BUFFER_VERTEX, BUFFER_STORAGE, BUFFER_UNIFORM, BUFFER_COPY_DST, BUFFER_MAP_READ = 1, 2, 4, 8, 16
+TEXTURE_BINDING, TEXTURE_COPY_DST, TEXTURE_RENDER_ATTACHMENT, TEXTURE_COPY_SRC = 1, 2, 4, 8
+OPTION_CLIP_TO_VIEWPORT = 0
+COPY_BYTES_PER_ROW_ALIGNMENT = 256
+MAX_COLOR_TARGETS = 4
+
+
+class RendererError(RuntimeError):
+    """Raised where the reference would panic."""
+
+
+class AttributeDesc(C.Structure):
+    _fields_ = [("location", C.c_uint32), ("size", C.c_uint32)]
+
+
+class SlotDesc(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("visibility", C.c_uint32), ("resource", C.c_void_p)]
+
+
+class ColorTargetDesc(C.Structure):
+    _fields_ = [("format", C.c_uint32), ("src_factor", C.c_uint32), ("dst_factor", C.c_uint32)]
+
+
+class PipelineDesc(C.Structure):
+    _fields_ = [("vertex_module", C.c_void_p), ("fragment_module", C.c_void_p),
+                ("n_attributes", C.c_uint32), ("attributes", C.POINTER(AttributeDesc)),
+                ("n_slots", C.c_uint32), ("slots", C.POINTER(SlotDesc)),
+                ("topology", C.c_uint32), ("samples", C.c_uint32),
+                ("n_targets", C.c_uint32), ("targets", C.POINTER(ColorTargetDesc))]
+
+
+class AttachmentDesc(C.Structure):
+    _fields_ = [("texture", C.c_void_p), ("load_op", C.c_uint32), ("clear", C.c_double * 4)]
+
+
+class PassDesc(C.Structure):
+    _fields_ = [("pipeline", C.c_void_p), ("n_attachments", C.c_uint32), ("attachments", C.POINTER(AttachmentDesc)),
+                ("n_vertex_buffers", C.c_uint32), ("vertex_buffers", C.POINTER(C.c_void_p)),
+                ("has_viewport", C.c_int32), ("viewport", C.c_float * 6),
+                ("vertex_count", C.c_uint32), ("instance_count", C.c_uint32)]
+
+
+class PassStats(C.Structure):
+    _fields_ = [("clusters", C.c_uint64), ("bin_entries", C.c_uint64), ("tiles_x", C.c_uint32), ("tiles_y", C.c_uint32),
+                ("tile_size", C.c_uint32)]
+
+
+MAP_CALLBACK = C.CFUNCTYPE(None, C.c_void_p, C.c_int)
+
+# name -> (restype, argtypes); every symbol declared in include/renderer_hip.h
+_P = C.c_void_p
+_PP = C.POINTER(C.c_void_p)
+SIGNATURES = {
+    "rh_last_error": (C.c_char_p, []),
+    "rh_abi_version": (C.c_int, []),
+    "rh_device_create": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32, _PP]),
+    "rh_device_destroy": (None, [_P]),
+    "rh_device_info": (C.c_int, [_P, C.c_char_p, C.c_size_t]),
+    "rh_device_set_option": (C.c_int, [_P, C.c_int, C.c_int]),
+    "rh_device_synchronize": (C.c_int, [_P]),
+    "rh_device_stream": (C.c_void_p, [_P]),
+    "rh_screen_texture": (C.c_int, [_P, _PP]),
+    "rh_screen_resize": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
+    "rh_buffer_create": (C.c_int, [_P, C.c_size_t, C.c_uint32, _P, C.c_size_t, _PP]),
+    "rh_buffer_write": (C.c_int, [_P, C.c_size_t, _P, C.c_size_t]),
+    "rh_buffer_size": (C.c_size_t, [_P]),
+    "rh_buffer_device_ptr": (C.c_void_p, [_P]),
+    "rh_buffer_retain": (None, [_P]),
+    "rh_buffer_release": (None, [_P]),
+    "rh_buffer_map_async": (C.c_int, [_P, MAP_CALLBACK, _P]),
+    "rh_buffer_mapped_ptr": (C.c_int, [_P, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]),
+    "rh_buffer_unmap": (C.c_int, [_P]),
+    "rh_poll": (C.c_int, [_P, C.c_int]),
+    "rh_texture_create": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _PP]),
+    "rh_texture_write": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _P, C.c_size_t, C.c_uint32]),
+    "rh_texture_read": (C.c_int, [_P, C.c_uint32, _P, C.c_size_t]),
+    "rh_texture_size": (C.c_int, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "rh_texture_device_ptr": (C.c_void_p, [_P]),
+    "rh_texture_retain": (None, [_P]),
+    "rh_texture_release": (None, [_P]),
+    "rh_sampler_create": (C.c_int, [_P, C.c_uint32, _PP]),
+    "rh_sampler_release": (None, [_P]),
+    "rh_module_load": (C.c_int, [_P, _P, C.c_size_t, _PP]),
+    "rh_module_retain": (None, [_P]),
+    "rh_module_release": (None, [_P]),
+    "rh_pipeline_create": (C.c_int, [_P, C.POINTER(PipelineDesc), _PP]),
+    "rh_pipeline_retain": (None, [_P]),
+    "rh_pipeline_release": (None, [_P]),
+    "rh_cmd_begin": (C.c_int, [_P, _PP]),
+    "rh_cmd_render_pass": (C.c_int, [_P, C.POINTER(PassDesc)]),
+    "rh_cmd_copy_texture_to_buffer": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "rh_cmd_finish": (C.c_int, [_P, _PP]),
+    "rh_cmdbuf_release": (None, [_P]),
+    "rh_submit": (C.c_int, [_P, _PP, C.c_size_t]),
+    "rh_device_last_pass_stats": (C.c_int, [_P, C.POINTER(PassStats)]),
+}
+
+_lib = None
+
+
+def lib():
+    """Loads librenderer_hip.so, failing loudly if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RendererError(f"{LIB_PATH} is missing: run `python -m renderer_amd.build` (needs hipcc) first; "
+                                "there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise RendererError(lib().rh_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,37 @@
+"""Builds librenderer_hip.so (host C ABI + shader-independent gfx950 kernels) and the bundled shader code objects.
+Run as `python -m renderer_amd.build`.  hipcc cross-compiles for gfx950 without a GPU present."""
+import os
+import subprocess
+import sys
+
+from .compiler import HIPCC, Compiler
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "librenderer_hip.so")
+SOURCES = ["rh_api.cpp", "rh_kernels.hip", "rh_codec.hip"]
+
+
+def build_library(force=False):
+    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + \
+        [os.path.join(HERE, "..", "include", "renderer_hip.h")]
+    if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in deps):
+        return LIB
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall",
+           "-Wno-unused-result"] + srcs + ["-o", LIB]
+    subprocess.check_call(cmd)
+    return LIB
+
+
+def build_all(force=False):
+    lib = build_library(force)
+    shaders = Compiler.compile_shaders(os.path.join(HERE, "shaders"), force=force)
+    return lib, shaders
+
+
+if __name__ == "__main__":
+    lib, shaders = build_all(force="--force" in sys.argv)
+    print(lib)
+    for s in shaders:
+        print(s)

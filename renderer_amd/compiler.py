@@ -1,0 +1,48 @@
+"""Offline shader build (reference src/compiler.rs:7-33): recursively compiles `<name>.vert.hip` / `<name>.frag.hip`
+pairs to gfx950 code objects `<name>.vert.co` / `<name>.frag.co` next to the sources, with hipcc instead of shaderc.
+
+A fragment object embeds the vertex function of the same stem, because triangle setup re-runs the vertex function
+inside the tile kernel rather than reading transformed vertices back from HBM."""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SHADER_INCLUDE = os.path.join(HERE, "csrc", "shader")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--genco", "--no-gpu-bundle-output", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+         "-I", SHADER_INCLUDE]
+
+
+class Compiler:
+    @staticmethod
+    def compile_shaders(directory, force=False):
+        built = []
+        for root, _dirs, files in os.walk(directory):
+            for name in sorted(files):
+                if name.endswith(".vert.hip") or name.endswith(".frag.hip"):
+                    out = Compiler.compile_shader(os.path.join(root, name), force=force)
+                    if out:
+                        built.append(out)
+        return built
+
+    @staticmethod
+    def compile_shader(path, force=False):
+        path = os.path.abspath(path)
+        stem, stage = path[:-len(".vert.hip")], path[-len(".vert.hip"):-len(".hip")]     # ".vert" | ".frag"
+        vert = stem + ".vert.hip"
+        out = path[:-len(".hip")] + ".co"
+        if not os.path.exists(vert):
+            raise FileNotFoundError(f"{path}: no vertex source {vert} with the same stem")
+        deps = [path, vert] + [os.path.join(SHADER_INCLUDE, f) for f in os.listdir(SHADER_INCLUDE)] + \
+               [os.path.join(HERE, "csrc", "rh_abi.h")]
+        if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
+            return out
+        tag = os.path.basename(stem)
+        defs = [f'-DRH_VERTEX_SOURCE="{vert}"', f'-DRH_VERTEX_TAG="{tag}"']
+        if stage == ".vert":
+            unit = os.path.join(SHADER_INCLUDE, "rh_stage_vertex.hip")
+        else:
+            unit = os.path.join(SHADER_INCLUDE, "rh_stage_fragment.hip")
+            defs.append(f'-DRH_FRAGMENT_SOURCE="{path}"')
+        subprocess.check_call([HIPCC] + FLAGS + defs + [unit, "-o", out])
+        return out

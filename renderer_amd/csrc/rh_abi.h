@@ -1,0 +1,82 @@
+// Plain-data structures shared between the host library (librenderer_hip.so) and the shader code objects it
+// launches.  Everything here is passed by value as kernel arguments; keep it POD and keep the layout stable:
+// a code object records RH_DEVICE_ABI_VERSION in its rh_module_info and the host refuses a mismatch.
+#pragma once
+#include <stdint.h>
+
+#define RH_DEVICE_ABI_VERSION 3u
+#define RH_MODULE_MAGIC 0x52484d4fu   // "RHMO"
+
+#define RH_DEV_MAX_ATTRIBUTES 8
+#define RH_DEV_MAX_SLOTS 16
+#define RH_DEV_MAX_TARGETS 4
+
+// Rasteriser geometry
+#define RH_SUBPIXEL_BITS 8
+#define RH_TILE 32                 // screen tile edge in pixels (one workgroup per tile)
+#define RH_BLOCK 8                 // one wavefront shades an 8x8 pixel block at a time
+#define RH_BATCH_TRIS 128          // triangles set up per batch inside a tile workgroup
+#define RH_TILE_THREADS 256
+
+enum { RH_MODULE_STAGE_VERTEX = 1, RH_MODULE_STAGE_FRAGMENT = 2 };
+
+// Exported by every shader code object as the global `rh_module_info`.
+struct rh_module_info_t {
+    uint32_t magic;
+    uint32_t abi_version;
+    uint32_t stage;          // RH_MODULE_STAGE_*
+    uint32_t n_varyings;     // floats interpolated per fragment
+    uint32_t n_outputs;      // colour outputs the fragment function writes
+    uint32_t vertex_tag;     // hash of the vertex function's source name: ties a fragment object to its vertex object
+    uint32_t reserved[2];
+};
+
+struct rh_slot_dev {
+    const void* ptr;         // buffer base / texture base (layer 0)
+    uint32_t width, height, layers;
+    uint32_t format;         // RH_FORMAT_*
+    uint32_t filter;         // RH_FILTER_* (for texture slots: the filter of the sampler that follows)
+    uint32_t size_bytes;     // buffers: capacity in bytes (whole buffer is bound, reference src/instanced.rs:18)
+};
+
+struct rh_draw_params {
+    const float* attr[RH_DEV_MAX_ATTRIBUTES];        // indexed by shader location
+    uint32_t attr_size[RH_DEV_MAX_ATTRIBUTES];
+    rh_slot_dev slots[RH_DEV_MAX_SLOTS];             // flat slot index = set * 4 + binding
+    float vp_hw, vp_hh, vp_ox, vp_oy;                // viewport transform: x_w = x*hw + ox ; y_w = y*(-hh) + oy
+    int32_t sc_x0, sc_y0, sc_x1, sc_y1;              // scissor rectangle in pixels [x0,x1) x [y0,y1)
+    uint32_t width, height;                          // attachment size in pixels
+    uint32_t tiles_x, tiles_y;
+    uint32_t topology;
+    uint32_t vertex_count, instance_count;
+    uint32_t tpi;                                    // triangles per instance
+    uint32_t cpi;                                    // clusters (pairs of consecutive triangles) per instance
+    uint32_t n_clusters;                             // instance_count * cpi
+};
+
+// Packed tile rectangle of a cluster: x0 | y0 << 16, x1 | y1 << 16 (inclusive); x0 > x1 marks "touches nothing".
+struct rh_tile_range { uint32_t lo, hi; };
+
+struct rh_bin_count_args {
+    rh_draw_params p;
+    rh_tile_range* ranges;      // [n_clusters]
+    uint32_t* block_sums;       // [ceil(n_clusters / 256)]
+};
+
+struct rh_attach_dev {
+    uint8_t* ptr;               // texel (0,0)
+    uint32_t pitch_px;          // row pitch in pixels
+    uint32_t format;            // RH_FORMAT_RGBA_U8 or RH_FORMAT_BGRA_U8
+    uint32_t load_op;           // RH_LOAD_OP_*
+    uint32_t clear_rgba8;       // clear colour already converted to UNORM8, r in byte 0
+};
+
+struct rh_tile_args {
+    rh_draw_params p;
+    const uint32_t* list;       // cluster ids sorted by (tile, cluster)
+    const uint32_t* tile_start; // [tiles]
+    const uint32_t* tile_end;   // [tiles]
+    rh_attach_dev att[RH_DEV_MAX_TARGETS];
+    uint32_t n_att;
+    uint32_t src_factor, dst_factor;
+};

@@ -1,0 +1,749 @@
+// librenderer_hip.so -- host side of the C ABI declared in include/renderer_hip.h.
+//
+// Objects are reference counted PODs around HIP allocations.  Command buffers record passes and copies and are
+// executed, in order, on the device's single HIP stream by rh_submit (the reference defers all GPU work to
+// queue.submit: src/renderer.rs:119-122).
+#include <hip/hip_runtime.h>
+#include <atomic>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/renderer_hip.h"
+#include "rh_abi.h"
+#include "rh_kernels.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    g_last_error = buf;
+    return 1;
+}
+
+#define RH_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+
+uint32_t bytes_per_texel(uint32_t format) {
+    switch (format) {
+    case RH_FORMAT_R_U8: return 1;
+    case RH_FORMAT_BGRA_U8: case RH_FORMAT_RGBA_U8: return 4;
+    case RH_FORMAT_RGBA_F16: return 8;
+    case RH_FORMAT_RGBA_F32: return 16;
+    default: return 0;
+    }
+}
+
+// Growable device scratch area.
+struct Scratch {
+    void* ptr = nullptr; size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr; cap = 0;
+        size_t want = bytes + bytes / 2 + 4096;
+        RH_HIP(hipMalloc(&ptr, want));
+        cap = want;
+        return 0;
+    }
+    void release() { if (ptr) (void)hipFree(ptr); ptr = nullptr; cap = 0; }
+    template <typename T> T* as() { return reinterpret_cast<T*>(ptr); }
+};
+
+} // namespace
+
+struct rh_device {
+    int ordinal = 0;
+    hipStream_t stream = nullptr;
+    uint32_t width = 0, height = 0;
+    rh_texture* screen = nullptr;
+    int clip_to_viewport = 1;
+    std::string name;
+    // scratch for binning
+    Scratch ranges, block_sums, chunk_tmp, keys_a, vals_a, keys_b, vals_b, hist, tile_start, tile_end;
+    unsigned long long* d_total = nullptr;
+    unsigned long long* h_total = nullptr;      // pinned
+    // allocation caches (exact-size reuse; capture buffers come and go every frame)
+    std::multimap<size_t, void*> free_device, free_pinned;
+    std::vector<rh_buffer*> pending_maps;
+    rh_pass_stats stats{};
+};
+
+struct rh_buffer {
+    std::atomic<int> refs{1};
+    rh_device* dev = nullptr;
+    size_t size = 0; uint32_t usage = 0;
+    void* dptr = nullptr;
+    // mapping state
+    void* hptr = nullptr;          // pinned host copy
+    hipEvent_t map_event = nullptr;
+    int map_state = 0;             // 0 unmapped, 1 pending, 2 mapped
+    rh_map_callback cb = nullptr; void* cb_user = nullptr;
+};
+
+struct rh_texture {
+    std::atomic<int> refs{1};
+    rh_device* dev = nullptr;
+    uint32_t width = 0, height = 0, layers = 0, format = 0, samples = 1, usage = 0;
+    uint32_t bpt = 0;
+    void* dptr = nullptr;          // layer-major, tightly packed rows
+    size_t bytes = 0;
+};
+
+struct rh_sampler { rh_device* dev; uint32_t filter; };
+
+struct rh_module {
+    std::atomic<int> refs{1};
+    rh_device* dev = nullptr;
+    hipModule_t module = nullptr;
+    rh_module_info_t info{};
+    hipFunction_t bin_count = nullptr;
+    hipFunction_t tile[RH_MAX_COLOR_TARGETS] = {nullptr, nullptr, nullptr, nullptr};
+};
+
+struct SlotRef { uint32_t kind = 0, visibility = 0; rh_buffer* buf = nullptr; rh_texture* tex = nullptr; uint32_t filter = 0; };
+
+struct rh_pipeline {
+    std::atomic<int> refs{1};
+    rh_device* dev = nullptr;
+    rh_module* vs = nullptr; rh_module* fs = nullptr;
+    std::vector<rh_attribute_desc> attributes;
+    std::vector<SlotRef> slots;
+    uint32_t topology = 0, samples = 1;
+    std::vector<rh_color_target_desc> targets;
+};
+
+namespace {
+
+struct PassCmd {
+    rh_pipeline* pipeline = nullptr;
+    std::vector<rh_attachment_desc> attachments;     // textures retained
+    std::vector<rh_buffer*> vertex_buffers;          // retained
+    bool has_viewport = false; float viewport[6] = {0, 0, 0, 0, 0, 1};
+    uint32_t vertex_count = 0, instance_count = 0;
+};
+
+struct CopyCmd {
+    rh_texture* tex = nullptr; rh_buffer* buf = nullptr;
+    uint32_t ox = 0, oy = 0, bytes_per_row = 0, rows_per_image = 0, width = 0, height = 0;
+};
+
+struct Cmd { int kind = 0; PassCmd pass; CopyCmd copy; };   // kind 0 = pass, 1 = copy
+
+} // namespace
+
+struct rh_cmd { rh_device* dev = nullptr; std::vector<Cmd> cmds; };
+struct rh_cmdbuf { rh_device* dev = nullptr; std::vector<Cmd> cmds; };
+
+// ---- allocation caches ------------------------------------------------------------------------------------------------
+namespace {
+
+int device_alloc(rh_device* dev, size_t size, void** out) {
+    auto it = dev->free_device.find(size);
+    if (it != dev->free_device.end()) { *out = it->second; dev->free_device.erase(it); return 0; }
+    RH_HIP(hipMalloc(out, size ? size : 1));
+    return 0;
+}
+void device_free(rh_device* dev, size_t size, void* p) {
+    if (!p) return;
+    if (dev->free_device.size() < 64) dev->free_device.emplace(size, p); else (void)hipFree(p);
+}
+int pinned_alloc(rh_device* dev, size_t size, void** out) {
+    auto it = dev->free_pinned.find(size);
+    if (it != dev->free_pinned.end()) { *out = it->second; dev->free_pinned.erase(it); return 0; }
+    RH_HIP(hipHostMalloc(out, size ? size : 1, hipHostMallocDefault));
+    return 0;
+}
+void pinned_free(rh_device* dev, size_t size, void* p) {
+    if (!p) return;
+    if (dev->free_pinned.size() < 64) dev->free_pinned.emplace(size, p); else (void)hipHostFree(p);
+}
+
+int set_device(rh_device* dev) { RH_HIP(hipSetDevice(dev->ordinal)); return 0; }
+
+uint32_t unorm8(double c) {
+    float o = (float)c;
+    o = fminf(fmaxf(o, 0.0f), 1.0f);
+    return (uint32_t)rintf(o * 255.0f);
+}
+
+uint32_t bits_for(uint32_t n) { uint32_t b = 1; while (b < 32 && (1ull << b) < n) b++; return b; }
+
+} // namespace
+
+extern "C" {
+
+const char* rh_last_error(void) { return g_last_error.c_str(); }
+int rh_abi_version(void) { return (int)RH_DEVICE_ABI_VERSION; }
+
+// ---- device -----------------------------------------------------------------------------------------------------------
+int rh_device_create(int hip_ordinal, uint32_t width, uint32_t height, rh_device** out) {
+    if (!out) return fail("rh_device_create: out is null");
+    if (width == 0 || height == 0) return fail("rh_device_create: zero-sized screen");
+    int count = 0;
+    RH_HIP(hipGetDeviceCount(&count));
+    if (hip_ordinal < 0 || hip_ordinal >= count) return fail("rh_device_create: HIP ordinal %d out of range (%d devices)", hip_ordinal, count);
+    RH_HIP(hipSetDevice(hip_ordinal));
+    hipDeviceProp_t prop;
+    RH_HIP(hipGetDeviceProperties(&prop, hip_ordinal));
+    rh_device* dev = new rh_device();
+    dev->ordinal = hip_ordinal; dev->width = width; dev->height = height;
+    dev->name = std::string(prop.name) + " (" + prop.gcnArchName + ")";
+    hipError_t e = hipStreamCreateWithFlags(&dev->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete dev; return fail("hipStreamCreate failed: %s", hipGetErrorString(e)); }
+    if (hipMalloc((void**)&dev->d_total, 8) != hipSuccess || hipHostMalloc((void**)&dev->h_total, 8, hipHostMallocDefault) != hipSuccess) {
+        delete dev; return fail("rh_device_create: allocation failed");
+    }
+    if (rh_texture_create(dev, width, height, 1, RH_FORMAT_BGRA_U8, 1,
+                          RH_TEXTURE_RENDER_ATTACHMENT | RH_TEXTURE_COPY_SRC | RH_TEXTURE_BINDING, &dev->screen)) { delete dev; return 1; }
+    *out = dev;
+    return 0;
+}
+
+void rh_device_destroy(rh_device* dev) {
+    if (!dev) return;
+    (void)hipSetDevice(dev->ordinal);
+    (void)hipStreamSynchronize(dev->stream);
+    for (rh_buffer* b : dev->pending_maps) rh_buffer_release(b);
+    dev->pending_maps.clear();
+    if (dev->screen) rh_texture_release(dev->screen);
+    Scratch* all[] = { &dev->ranges, &dev->block_sums, &dev->chunk_tmp, &dev->keys_a, &dev->vals_a, &dev->keys_b, &dev->vals_b,
+                       &dev->hist, &dev->tile_start, &dev->tile_end };
+    for (Scratch* s : all) s->release();
+    for (auto& kv : dev->free_device) (void)hipFree(kv.second);
+    for (auto& kv : dev->free_pinned) (void)hipHostFree(kv.second);
+    if (dev->d_total) (void)hipFree(dev->d_total);
+    if (dev->h_total) (void)hipHostFree(dev->h_total);
+    (void)hipStreamDestroy(dev->stream);
+    delete dev;
+}
+
+int rh_device_info(rh_device* dev, char* name, size_t cap) {
+    if (!dev || !name || cap == 0) return fail("rh_device_info: bad argument");
+    snprintf(name, cap, "%s", dev->name.c_str());
+    return 0;
+}
+
+int rh_device_set_option(rh_device* dev, int option, int value) {
+    if (!dev) return fail("rh_device_set_option: null device");
+    if (option == RH_OPTION_CLIP_TO_VIEWPORT) { dev->clip_to_viewport = value ? 1 : 0; return 0; }
+    return fail("rh_device_set_option: unknown option %d", option);
+}
+
+int rh_device_synchronize(rh_device* dev) {
+    if (!dev) return fail("rh_device_synchronize: null device");
+    if (set_device(dev)) return 1;
+    RH_HIP(hipStreamSynchronize(dev->stream));
+    return 0;
+}
+
+void* rh_device_stream(rh_device* dev) { return dev ? (void*)dev->stream : nullptr; }
+
+int rh_screen_texture(rh_device* dev, rh_texture** out) {
+    if (!dev || !out) return fail("rh_screen_texture: bad argument");
+    *out = dev->screen;
+    return 0;
+}
+
+int rh_screen_resize(rh_device* dev, uint32_t width, uint32_t height) {
+    if (!dev) return fail("rh_screen_resize: null device");
+    if (width == 0 || height == 0) return 0;           // reference src/renderer.rs:57 ignores zero sizes
+    if (width == dev->width && height == dev->height) return 0;
+    rh_texture* t = nullptr;
+    if (rh_texture_create(dev, width, height, 1, RH_FORMAT_BGRA_U8, 1,
+                          RH_TEXTURE_RENDER_ATTACHMENT | RH_TEXTURE_COPY_SRC | RH_TEXTURE_BINDING, &t)) return 1;
+    rh_texture_release(dev->screen);
+    dev->screen = t; dev->width = width; dev->height = height;
+    return 0;
+}
+
+// ---- buffers ------------------------------------------------------------------------------------------------------------
+int rh_buffer_create(rh_device* dev, size_t size, uint32_t usage, const void* init, size_t init_len, rh_buffer** out) {
+    if (!dev || !out) return fail("rh_buffer_create: bad argument");
+    if (init_len > size) return fail("rh_buffer_create: initial data (%zu bytes) larger than the buffer (%zu bytes)", init_len, size);
+    if (set_device(dev)) return 1;
+    rh_buffer* b = new rh_buffer();
+    b->dev = dev; b->size = size; b->usage = usage;
+    if (device_alloc(dev, size, &b->dptr)) { delete b; return 1; }
+    if (init && init_len) {
+        hipError_t e = hipMemcpyAsync(b->dptr, init, init_len, hipMemcpyHostToDevice, dev->stream);
+        if (e != hipSuccess) { device_free(dev, size, b->dptr); delete b; return fail("rh_buffer_create: upload failed: %s", hipGetErrorString(e)); }
+    }
+    *out = b;
+    return 0;
+}
+
+int rh_buffer_write(rh_buffer* buf, size_t offset, const void* data, size_t len) {
+    if (!buf || (!data && len)) return fail("rh_buffer_write: bad argument");
+    if (offset > buf->size || len > buf->size - offset) return fail("rh_buffer_write: range %zu+%zu exceeds buffer size %zu", offset, len, buf->size);
+    if (len == 0) return 0;
+    if (set_device(buf->dev)) return 1;
+    RH_HIP(hipMemcpyAsync((uint8_t*)buf->dptr + offset, data, len, hipMemcpyHostToDevice, buf->dev->stream));
+    return 0;
+}
+
+size_t rh_buffer_size(rh_buffer* buf) { return buf ? buf->size : 0; }
+void* rh_buffer_device_ptr(rh_buffer* buf) { return buf ? buf->dptr : nullptr; }
+void rh_buffer_retain(rh_buffer* buf) { if (buf) buf->refs.fetch_add(1); }
+
+void rh_buffer_release(rh_buffer* buf) {
+    if (!buf) return;
+    if (buf->refs.fetch_sub(1) != 1) return;
+    rh_device* dev = buf->dev;
+    (void)hipSetDevice(dev->ordinal);
+    // stream-ordered reuse: everything that used this memory was submitted on dev->stream before this point
+    device_free(dev, buf->size, buf->dptr);
+    if (buf->hptr) pinned_free(dev, buf->size, buf->hptr);
+    if (buf->map_event) (void)hipEventDestroy(buf->map_event);
+    delete buf;
+}
+
+int rh_buffer_map_async(rh_buffer* buf, rh_map_callback cb, void* user) {
+    if (!buf) return fail("rh_buffer_map_async: null buffer");
+    if (!(buf->usage & RH_BUFFER_MAP_READ)) return fail("rh_buffer_map_async: buffer was not created with MAP_READ");
+    if (buf->map_state != 0) return fail("rh_buffer_map_async: buffer is already mapped or mapping");
+    rh_device* dev = buf->dev;
+    if (set_device(dev)) return 1;
+    if (!buf->hptr && pinned_alloc(dev, buf->size, &buf->hptr)) return 1;
+    if (!buf->map_event) RH_HIP(hipEventCreateWithFlags(&buf->map_event, hipEventDisableTiming));
+    RH_HIP(hipMemcpyAsync(buf->hptr, buf->dptr, buf->size, hipMemcpyDeviceToHost, dev->stream));
+    RH_HIP(hipEventRecord(buf->map_event, dev->stream));
+    buf->map_state = 1; buf->cb = cb; buf->cb_user = user;
+    rh_buffer_retain(buf);
+    dev->pending_maps.push_back(buf);
+    return 0;
+}
+
+int rh_buffer_mapped_ptr(rh_buffer* buf, const uint8_t** ptr, size_t* len) {
+    if (!buf || !ptr || !len) return fail("rh_buffer_mapped_ptr: bad argument");
+    if (buf->map_state != 2) return fail("rh_buffer_mapped_ptr: buffer is not mapped");
+    *ptr = (const uint8_t*)buf->hptr; *len = buf->size;
+    return 0;
+}
+
+int rh_buffer_unmap(rh_buffer* buf) {
+    if (!buf) return fail("rh_buffer_unmap: null buffer");
+    if (buf->map_state == 1) return fail("rh_buffer_unmap: mapping still pending");
+    buf->map_state = 0;
+    return 0;
+}
+
+int rh_poll(rh_device* dev, int wait) {
+    if (!dev) return fail("rh_poll: null device");
+    if (set_device(dev)) return 1;
+    size_t done = 0;
+    for (; done < dev->pending_maps.size(); done++) {
+        rh_buffer* b = dev->pending_maps[done];
+        hipError_t e = wait ? hipEventSynchronize(b->map_event) : hipEventQuery(b->map_event);
+        if (e == hipErrorNotReady) break;
+        b->map_state = (e == hipSuccess) ? 2 : 0;
+        if (b->cb) b->cb(b->cb_user, e == hipSuccess ? 1 : 0);
+        b->cb = nullptr;
+        rh_buffer_release(b);
+    }
+    dev->pending_maps.erase(dev->pending_maps.begin(), dev->pending_maps.begin() + done);
+    return 0;
+}
+
+// ---- textures -----------------------------------------------------------------------------------------------------------
+int rh_texture_create(rh_device* dev, uint32_t width, uint32_t height, uint32_t layers, uint32_t format,
+                      uint32_t samples, uint32_t usage, rh_texture** out) {
+    if (!dev || !out) return fail("rh_texture_create: bad argument");
+    if (width == 0 || height == 0 || layers == 0) return fail("rh_texture_create: zero-sized texture");
+    const uint32_t bpt = bytes_per_texel(format);
+    if (bpt == 0) return fail("rh_texture_create: unknown format %u", format);
+    if (samples != 1) return fail("rh_texture_create: %u samples requested; multisampling is not implemented", samples);
+    if (set_device(dev)) return 1;
+    rh_texture* t = new rh_texture();
+    t->dev = dev; t->width = width; t->height = height; t->layers = layers; t->format = format; t->samples = samples; t->usage = usage;
+    t->bpt = bpt; t->bytes = (size_t)width * height * layers * bpt;
+    if (device_alloc(dev, t->bytes, &t->dptr)) { delete t; return 1; }
+    // wgpu textures start zero-initialised
+    hipError_t e = hipMemsetAsync(t->dptr, 0, t->bytes, dev->stream);
+    if (e != hipSuccess) { device_free(dev, t->bytes, t->dptr); delete t; return fail("rh_texture_create: clear failed: %s", hipGetErrorString(e)); }
+    *out = t;
+    return 0;
+}
+
+int rh_texture_write(rh_texture* tex, uint32_t x, uint32_t y, uint32_t layer, uint32_t width, uint32_t height,
+                     const void* data, size_t data_len, uint32_t bytes_per_row) {
+    if (!tex || !data) return fail("rh_texture_write: bad argument");
+    if (layer >= tex->layers || x > tex->width || y > tex->height || width > tex->width - x || height > tex->height - y)
+        return fail("rh_texture_write: region (%u,%u,%u)+(%u,%u) outside the %ux%ux%u texture", x, y, layer, width, height, tex->width, tex->height, tex->layers);
+    if (width == 0 || height == 0) return 0;
+    const size_t row_bytes = (size_t)width * tex->bpt;
+    if (bytes_per_row < row_bytes) return fail("rh_texture_write: bytes_per_row %u smaller than a row (%zu bytes)", bytes_per_row, row_bytes);
+    if (data_len < (size_t)bytes_per_row * (height - 1) + row_bytes) return fail("rh_texture_write: %zu bytes of data are too few for %u rows", data_len, height);
+    if (set_device(tex->dev)) return 1;
+    uint8_t* dst = (uint8_t*)tex->dptr + (((size_t)layer * tex->height + y) * tex->width + x) * tex->bpt;
+    RH_HIP(hipMemcpy2DAsync(dst, (size_t)tex->width * tex->bpt, data, bytes_per_row, row_bytes, height, hipMemcpyHostToDevice, tex->dev->stream));
+    return 0;
+}
+
+int rh_texture_read(rh_texture* tex, uint32_t layer, void* out, size_t out_len) {
+    if (!tex || !out) return fail("rh_texture_read: bad argument");
+    if (layer >= tex->layers) return fail("rh_texture_read: layer %u out of range", layer);
+    const size_t layer_bytes = (size_t)tex->width * tex->height * tex->bpt;
+    if (out_len < layer_bytes) return fail("rh_texture_read: output too small (%zu < %zu)", out_len, layer_bytes);
+    if (set_device(tex->dev)) return 1;
+    RH_HIP(hipMemcpyAsync(out, (uint8_t*)tex->dptr + layer * layer_bytes, layer_bytes, hipMemcpyDeviceToHost, tex->dev->stream));
+    RH_HIP(hipStreamSynchronize(tex->dev->stream));
+    return 0;
+}
+
+int rh_texture_size(rh_texture* tex, uint32_t* width, uint32_t* height, uint32_t* layers, uint32_t* format) {
+    if (!tex) return fail("rh_texture_size: null texture");
+    if (width) *width = tex->width;
+    if (height) *height = tex->height;
+    if (layers) *layers = tex->layers;
+    if (format) *format = tex->format;
+    return 0;
+}
+
+void* rh_texture_device_ptr(rh_texture* tex) { return tex ? tex->dptr : nullptr; }
+void rh_texture_retain(rh_texture* tex) { if (tex) tex->refs.fetch_add(1); }
+void rh_texture_release(rh_texture* tex) {
+    if (!tex) return;
+    if (tex->refs.fetch_sub(1) != 1) return;
+    (void)hipSetDevice(tex->dev->ordinal);
+    device_free(tex->dev, tex->bytes, tex->dptr);
+    delete tex;
+}
+
+int rh_sampler_create(rh_device* dev, uint32_t filter, rh_sampler** out) {
+    if (!dev || !out) return fail("rh_sampler_create: bad argument");
+    if (filter != RH_FILTER_LINEAR && filter != RH_FILTER_NEAREST) return fail("rh_sampler_create: unknown filter %u", filter);
+    *out = new rh_sampler{dev, filter};
+    return 0;
+}
+void rh_sampler_release(rh_sampler* s) { delete s; }
+
+// ---- modules ------------------------------------------------------------------------------------------------------------
+int rh_module_load(rh_device* dev, const void* code_object, size_t size, rh_module** out) {
+    if (!dev || !code_object || size < 64 || !out) return fail("rh_module_load: bad argument");
+    if (set_device(dev)) return 1;
+    rh_module* m = new rh_module();
+    m->dev = dev;
+    hipError_t e = hipModuleLoadData(&m->module, code_object);
+    if (e != hipSuccess) { delete m; return fail("rh_module_load: hipModuleLoadData failed: %s (is this a gfx950 code object?)", hipGetErrorString(e)); }
+    hipDeviceptr_t info_ptr = nullptr; size_t info_bytes = 0;
+    e = hipModuleGetGlobal(&info_ptr, &info_bytes, m->module, "rh_module_info");
+    if (e != hipSuccess || info_bytes != sizeof(rh_module_info_t)) { (void)hipModuleUnload(m->module); delete m; return fail("rh_module_load: code object has no rh_module_info record"); }
+    e = hipMemcpy(&m->info, info_ptr, sizeof m->info, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { (void)hipModuleUnload(m->module); delete m; return fail("rh_module_load: reading rh_module_info failed: %s", hipGetErrorString(e)); }
+    if (m->info.magic != RH_MODULE_MAGIC || m->info.abi_version != RH_DEVICE_ABI_VERSION) {
+        uint32_t v = m->info.abi_version;
+        (void)hipModuleUnload(m->module); delete m;
+        return fail("rh_module_load: code object built for device ABI %u, library expects %u; re-run the shader build", v, RH_DEVICE_ABI_VERSION);
+    }
+    if (m->info.stage == RH_MODULE_STAGE_VERTEX) {
+        if (hipModuleGetFunction(&m->bin_count, m->module, "rh_bin_count") != hipSuccess) { (void)hipModuleUnload(m->module); delete m; return fail("rh_module_load: vertex code object lacks rh_bin_count"); }
+    } else if (m->info.stage == RH_MODULE_STAGE_FRAGMENT) {
+        const char* names[RH_MAX_COLOR_TARGETS] = { "rh_tile_1", "rh_tile_2", "rh_tile_3", "rh_tile_4" };
+        for (int i = 0; i < RH_MAX_COLOR_TARGETS; i++)
+            if (hipModuleGetFunction(&m->tile[i], m->module, names[i]) != hipSuccess) { (void)hipModuleUnload(m->module); delete m; return fail("rh_module_load: fragment code object lacks %s", names[i]); }
+    } else { (void)hipModuleUnload(m->module); delete m; return fail("rh_module_load: unknown stage"); }
+    *out = m;
+    return 0;
+}
+void rh_module_retain(rh_module* m) { if (m) m->refs.fetch_add(1); }
+void rh_module_release(rh_module* m) {
+    if (!m) return;
+    if (m->refs.fetch_sub(1) != 1) return;
+    (void)hipSetDevice(m->dev->ordinal);
+    (void)hipModuleUnload(m->module);
+    delete m;
+}
+
+// ---- pipelines -----------------------------------------------------------------------------------------------------------
+int rh_pipeline_create(rh_device* dev, const rh_pipeline_desc* d, rh_pipeline** out) {
+    if (!dev || !d || !out) return fail("rh_pipeline_create: bad argument");
+    if (!d->vertex_module || d->vertex_module->info.stage != RH_MODULE_STAGE_VERTEX) return fail("rh_pipeline_create: vertex_module is not a vertex-stage code object");
+    if (!d->fragment_module || d->fragment_module->info.stage != RH_MODULE_STAGE_FRAGMENT) return fail("rh_pipeline_create: fragment_module is not a fragment-stage code object");
+    if (d->vertex_module->info.vertex_tag != d->fragment_module->info.vertex_tag || d->vertex_module->info.n_varyings != d->fragment_module->info.n_varyings)
+        return fail("rh_pipeline_create: the fragment code object was not built against this vertex code object");
+    if (d->n_attributes > RH_MAX_ATTRIBUTES) return fail("rh_pipeline_create: %u attributes (max %d)", d->n_attributes, RH_MAX_ATTRIBUTES);
+    if (d->n_slots > RH_DEV_MAX_SLOTS) return fail("rh_pipeline_create: %u binding slots (max %d implemented)", d->n_slots, RH_DEV_MAX_SLOTS);
+    if (d->n_targets > RH_MAX_COLOR_TARGETS) return fail("rh_pipeline_create: %u colour targets (max %d)", d->n_targets, RH_MAX_COLOR_TARGETS);
+    if (d->samples != 1) return fail("rh_pipeline_create: %u samples requested; multisampling is not implemented", d->samples);
+    if (d->topology != RH_TOPOLOGY_TRIANGLE_LIST && d->topology != RH_TOPOLOGY_TRIANGLE_STRIP) return fail("rh_pipeline_create: unknown topology %u", d->topology);
+    rh_pipeline* p = new rh_pipeline();
+    p->dev = dev; p->topology = d->topology; p->samples = d->samples;
+    for (uint32_t i = 0; i < d->n_attributes; i++) {
+        const rh_attribute_desc& a = d->attributes[i];
+        if (a.location >= RH_MAX_ATTRIBUTES || a.size < 1 || a.size > 4) { delete p; return fail("rh_pipeline_create: unsupported attribute (location %u, size %u)", a.location, a.size); }
+        p->attributes.push_back(a);
+    }
+    for (uint32_t i = 0; i < d->n_targets; i++) {
+        const rh_color_target_desc& t = d->targets[i];
+        if (t.format != RH_FORMAT_RGBA_U8 && t.format != RH_FORMAT_BGRA_U8) { delete p; return fail("rh_pipeline_create: colour target format %u is not implemented (RGBA8/BGRA8 only)", t.format); }
+        if (t.src_factor > RH_BLEND_ONE_MINUS_SRC_ALPHA || t.dst_factor > RH_BLEND_ONE_MINUS_SRC_ALPHA) { delete p; return fail("rh_pipeline_create: unknown blend factor"); }
+        if (t.src_factor != d->targets[0].src_factor || t.dst_factor != d->targets[0].dst_factor) { delete p; return fail("rh_pipeline_create: all colour targets must share one blend state"); }
+        p->targets.push_back(t);
+    }
+    for (uint32_t i = 0; i < d->n_slots; i++) {
+        const rh_slot_desc& s = d->slots[i];
+        SlotRef r; r.kind = s.kind; r.visibility = s.visibility;
+        if (!s.resource) { delete p; return fail("rh_pipeline_create: slot %u has no resource", i); }
+        switch (s.kind) {
+        case RH_SLOT_STORAGE: case RH_SLOT_UNIFORM: r.buf = (rh_buffer*)s.resource; break;
+        case RH_SLOT_TEXTURE: {
+            r.tex = (rh_texture*)s.resource;
+            if (r.tex->format != RH_FORMAT_RGBA_U8 && r.tex->format != RH_FORMAT_BGRA_U8 && r.tex->format != RH_FORMAT_R_U8) { delete p; return fail("rh_pipeline_create: sampling format %u is not implemented", r.tex->format); }
+            break;
+        }
+        case RH_SLOT_SAMPLER: r.filter = ((rh_sampler*)s.resource)->filter; break;
+        default: delete p; return fail("rh_pipeline_create: unknown slot kind %u", s.kind);
+        }
+        p->slots.push_back(r);
+    }
+    for (SlotRef& r : p->slots) { if (r.buf) rh_buffer_retain(r.buf); if (r.tex) rh_texture_retain(r.tex); }
+    p->vs = d->vertex_module; p->fs = d->fragment_module;
+    rh_module_retain(p->vs); rh_module_retain(p->fs);
+    *out = p;
+    return 0;
+}
+void rh_pipeline_retain(rh_pipeline* p) { if (p) p->refs.fetch_add(1); }
+void rh_pipeline_release(rh_pipeline* p) {
+    if (!p) return;
+    if (p->refs.fetch_sub(1) != 1) return;
+    for (SlotRef& r : p->slots) { if (r.buf) rh_buffer_release(r.buf); if (r.tex) rh_texture_release(r.tex); }
+    rh_module_release(p->vs); rh_module_release(p->fs);
+    delete p;
+}
+
+// ---- command encoding ------------------------------------------------------------------------------------------------------
+int rh_cmd_begin(rh_device* dev, rh_cmd** out) {
+    if (!dev || !out) return fail("rh_cmd_begin: bad argument");
+    rh_cmd* c = new rh_cmd(); c->dev = dev; *out = c;
+    return 0;
+}
+
+static void release_cmds(std::vector<Cmd>& cmds) {
+    for (Cmd& c : cmds) {
+        if (c.kind == 0) {
+            rh_pipeline_release(c.pass.pipeline);
+            for (auto& a : c.pass.attachments) rh_texture_release(a.texture);
+            for (rh_buffer* b : c.pass.vertex_buffers) rh_buffer_release(b);
+        } else { rh_texture_release(c.copy.tex); rh_buffer_release(c.copy.buf); }
+    }
+    cmds.clear();
+}
+
+int rh_cmd_render_pass(rh_cmd* cmd, const rh_pass_desc* d) {
+    if (!cmd || !d || !d->pipeline) return fail("rh_cmd_render_pass: bad argument");
+    rh_pipeline* p = d->pipeline;
+    if (d->n_attachments == 0) return 0;                        // reference src/render_pass.rs:26
+    if (d->n_attachments != p->targets.size()) return fail("rh_cmd_render_pass: %u attachments for a pipeline with %zu colour targets", d->n_attachments, p->targets.size());
+    if (d->n_vertex_buffers != p->attributes.size()) return fail("rh_cmd_render_pass: %u vertex buffers for a pipeline with %zu attributes", d->n_vertex_buffers, p->attributes.size());
+    const rh_texture* t0 = d->attachments[0].texture;
+    for (uint32_t i = 0; i < d->n_attachments; i++) {
+        const rh_texture* t = d->attachments[i].texture;
+        if (!t) return fail("rh_cmd_render_pass: attachment %u has no texture", i);
+        if (t->format != p->targets[i].format) return fail("rh_cmd_render_pass: attachment %u has format %u but the pipeline expects %u", i, t->format, p->targets[i].format);
+        if (t->width != t0->width || t->height != t0->height) return fail("rh_cmd_render_pass: attachment %u is %ux%u, attachment 0 is %ux%u", i, t->width, t->height, t0->width, t0->height);
+        if (!(t->usage & RH_TEXTURE_RENDER_ATTACHMENT)) return fail("rh_cmd_render_pass: attachment %u was not created renderable", i);
+    }
+    for (uint32_t i = 0; i < d->n_vertex_buffers; i++) {
+        rh_buffer* b = d->vertex_buffers[i];
+        if (!b) return fail("rh_cmd_render_pass: vertex buffer %u is null", i);
+        const size_t need = (size_t)d->vertex_count * p->attributes[i].size * sizeof(float);
+        if (b->size < need) return fail("rh_cmd_render_pass: vertex buffer %u holds %zu bytes, %u vertices need %zu", i, b->size, d->vertex_count, need);
+    }
+    Cmd c; c.kind = 0;
+    c.pass.pipeline = p; rh_pipeline_retain(p);
+    for (uint32_t i = 0; i < d->n_attachments; i++) { c.pass.attachments.push_back(d->attachments[i]); rh_texture_retain(d->attachments[i].texture); }
+    for (uint32_t i = 0; i < d->n_vertex_buffers; i++) { c.pass.vertex_buffers.push_back(d->vertex_buffers[i]); rh_buffer_retain(d->vertex_buffers[i]); }
+    c.pass.has_viewport = d->has_viewport != 0;
+    if (c.pass.has_viewport) memcpy(c.pass.viewport, d->viewport, sizeof c.pass.viewport);
+    c.pass.vertex_count = d->vertex_count; c.pass.instance_count = d->instance_count;
+    cmd->cmds.push_back(std::move(c));
+    return 0;
+}
+
+int rh_cmd_copy_texture_to_buffer(rh_cmd* cmd, rh_texture* tex, uint32_t origin_x, uint32_t origin_y,
+                                  rh_buffer* buf, uint32_t bytes_per_row, uint32_t rows_per_image, uint32_t width, uint32_t height) {
+    if (!cmd || !tex || !buf) return fail("rh_cmd_copy_texture_to_buffer: bad argument");
+    if (!(tex->usage & RH_TEXTURE_COPY_SRC)) return fail("rh_cmd_copy_texture_to_buffer: texture was not created copyable");
+    if (bytes_per_row % RH_COPY_BYTES_PER_ROW_ALIGNMENT) return fail("rh_cmd_copy_texture_to_buffer: bytes_per_row %u is not a multiple of %d", bytes_per_row, RH_COPY_BYTES_PER_ROW_ALIGNMENT);
+    if (origin_x > tex->width || origin_y > tex->height || width > tex->width - origin_x || height > tex->height - origin_y)
+        return fail("rh_cmd_copy_texture_to_buffer: region (%u,%u)+(%u,%u) outside the %ux%u texture", origin_x, origin_y, width, height, tex->width, tex->height);
+    if ((size_t)width * tex->bpt > bytes_per_row) return fail("rh_cmd_copy_texture_to_buffer: bytes_per_row %u smaller than a row", bytes_per_row);
+    if (height > 0 && (size_t)bytes_per_row * height > buf->size) return fail("rh_cmd_copy_texture_to_buffer: buffer of %zu bytes too small for %u rows of %u bytes", buf->size, height, bytes_per_row);
+    Cmd c; c.kind = 1;
+    c.copy.tex = tex; c.copy.buf = buf; rh_texture_retain(tex); rh_buffer_retain(buf);
+    c.copy.ox = origin_x; c.copy.oy = origin_y; c.copy.bytes_per_row = bytes_per_row; c.copy.rows_per_image = rows_per_image;
+    c.copy.width = width; c.copy.height = height;
+    cmd->cmds.push_back(std::move(c));
+    return 0;
+}
+
+int rh_cmd_finish(rh_cmd* cmd, rh_cmdbuf** out) {
+    if (!cmd || !out) return fail("rh_cmd_finish: bad argument");
+    rh_cmdbuf* cb = new rh_cmdbuf(); cb->dev = cmd->dev; cb->cmds = std::move(cmd->cmds);
+    delete cmd;
+    *out = cb;
+    return 0;
+}
+
+void rh_cmdbuf_release(rh_cmdbuf* cb) { if (!cb) return; release_cmds(cb->cmds); delete cb; }
+
+} // extern "C"
+
+// ---- execution ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+int launch_module_kernel(hipFunction_t fn, uint32_t grid, void* args, size_t args_size, hipStream_t s) {
+    void* config[] = { HIP_LAUNCH_PARAM_BUFFER_POINTER, args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &args_size, HIP_LAUNCH_PARAM_END };
+    RH_HIP(hipModuleLaunchKernel(fn, grid, 1, 1, 256, 1, 1, 0, s, nullptr, config));
+    return 0;
+}
+
+int execute_pass(rh_device* dev, const PassCmd& c) {
+    rh_pipeline* pl = c.pipeline;
+    const rh_texture* t0 = c.attachments[0].texture;
+    const uint32_t W = t0->width, H = t0->height;
+
+    rh_draw_params p;
+    memset(&p, 0, sizeof p);
+    for (size_t i = 0; i < pl->attributes.size(); i++) {
+        p.attr[pl->attributes[i].location] = (const float*)c.vertex_buffers[i]->dptr;
+        p.attr_size[pl->attributes[i].location] = pl->attributes[i].size;
+    }
+    for (size_t i = 0; i < pl->slots.size(); i++) {
+        const SlotRef& s = pl->slots[i];
+        rh_slot_dev& d = p.slots[i];
+        if (s.buf) { d.ptr = s.buf->dptr; d.size_bytes = (uint32_t)std::min<size_t>(s.buf->size, 0xffffffffu); }
+        if (s.tex) {
+            d.ptr = s.tex->dptr; d.width = s.tex->width; d.height = s.tex->height; d.layers = s.tex->layers; d.format = s.tex->format;
+            // a texture's sampler, when it has one, occupies the next slot (reference src/pipeline.rs:105-112)
+            d.filter = (i + 1 < pl->slots.size() && pl->slots[i + 1].kind == RH_SLOT_SAMPLER) ? pl->slots[i + 1].filter : RH_FILTER_NEAREST;
+        }
+        if (s.kind == RH_SLOT_SAMPLER) d.filter = s.filter;
+    }
+    float vx = 0.0f, vy = 0.0f, vw = (float)W, vh = (float)H;
+    if (c.has_viewport) { vx = c.viewport[0]; vy = c.viewport[1]; vw = c.viewport[2]; vh = c.viewport[3]; }
+    p.vp_hw = vw * 0.5f; p.vp_hh = vh * 0.5f; p.vp_ox = vx + p.vp_hw; p.vp_oy = vy + p.vp_hh;
+    p.sc_x0 = 0; p.sc_y0 = 0; p.sc_x1 = (int32_t)W; p.sc_y1 = (int32_t)H;
+    if (dev->clip_to_viewport) {
+        // pixel centre (i + 0.5) inside [vx, vx + vw)
+        p.sc_x0 = std::max(0, (int)std::ceil((double)vx - 0.5));
+        p.sc_y0 = std::max(0, (int)std::ceil((double)vy - 0.5));
+        p.sc_x1 = std::min((int)W, (int)std::ceil((double)vx + (double)vw - 0.5));
+        p.sc_y1 = std::min((int)H, (int)std::ceil((double)vy + (double)vh - 0.5));
+    }
+    p.width = W; p.height = H;
+    p.tiles_x = (W + RH_TILE - 1) / RH_TILE; p.tiles_y = (H + RH_TILE - 1) / RH_TILE;
+    const uint32_t n_tiles = p.tiles_x * p.tiles_y;
+    p.topology = pl->topology;
+    p.vertex_count = c.vertex_count; p.instance_count = c.instance_count;
+    p.tpi = pl->topology == RH_TOPOLOGY_TRIANGLE_STRIP ? (c.vertex_count >= 3 ? c.vertex_count - 2 : 0) : c.vertex_count / 3;
+    p.cpi = (p.tpi + 1) / 2;
+    const uint64_t n_clusters64 = (uint64_t)p.cpi * c.instance_count;
+    if (n_clusters64 >= 0xffffff00ull) return fail("render pass: %llu triangle pairs exceed the 32-bit cluster index", (unsigned long long)n_clusters64);
+    p.n_clusters = (uint32_t)n_clusters64;
+    const bool empty_scissor = p.sc_x0 >= p.sc_x1 || p.sc_y0 >= p.sc_y1;
+    const uint32_t n_clusters = empty_scissor ? 0u : p.n_clusters;
+
+    hipStream_t s = dev->stream;
+    if (dev->tile_start.ensure((size_t)n_tiles * 4) || dev->tile_end.ensure((size_t)n_tiles * 4)) return 1;
+    uint64_t total = 0;
+    uint32_t* sorted_vals = nullptr;
+    if (n_clusters > 0) {
+        const uint32_t n_blocks = (n_clusters + 255) / 256;
+        if (dev->ranges.ensure((size_t)n_clusters * sizeof(rh_tile_range)) || dev->block_sums.ensure((size_t)n_blocks * 4) ||
+            dev->chunk_tmp.ensure((size_t)rhk::scan_chunks_for(n_blocks) * 4)) return 1;
+        rh_bin_count_args ba;
+        ba.p = p; ba.p.n_clusters = n_clusters;
+        ba.ranges = dev->ranges.as<rh_tile_range>(); ba.block_sums = dev->block_sums.as<uint32_t>();
+        if (launch_module_kernel(pl->vs->bin_count, n_blocks, &ba, sizeof ba, s)) return 1;
+        rhk::exclusive_scan(dev->block_sums.as<uint32_t>(), n_blocks, dev->chunk_tmp.as<uint32_t>(), dev->d_total, s);
+        RH_HIP(hipMemcpyAsync(dev->h_total, dev->d_total, 8, hipMemcpyDeviceToHost, s));
+        RH_HIP(hipStreamSynchronize(s));
+        total = *dev->h_total;
+        if (total >= 0x7fffffffull) return fail("render pass: %llu (tile, cluster) pairs exceed the 31-bit pair index", (unsigned long long)total);
+        if (total > 0) {
+            const uint32_t n = (uint32_t)total;
+            const uint32_t sort_blocks = rhk::sort_blocks_for(n);
+            if (dev->keys_a.ensure((size_t)n * 4) || dev->vals_a.ensure((size_t)n * 4) || dev->keys_b.ensure((size_t)n * 4) || dev->vals_b.ensure((size_t)n * 4) ||
+                dev->hist.ensure((size_t)sort_blocks * 256 * 4) || dev->chunk_tmp.ensure((size_t)rhk::scan_chunks_for(sort_blocks * 256) * 4)) return 1;
+            rhk::bin_emit(dev->ranges.as<rh_tile_range>(), n_clusters, p.tiles_x, dev->block_sums.as<uint32_t>(),
+                          dev->keys_a.as<uint32_t>(), dev->vals_a.as<uint32_t>(), s);
+            int where = rhk::radix_sort_pairs(dev->keys_a.as<uint32_t>(), dev->vals_a.as<uint32_t>(), dev->keys_b.as<uint32_t>(), dev->vals_b.as<uint32_t>(),
+                                              n, bits_for(n_tiles), dev->hist.as<uint32_t>(), dev->chunk_tmp.as<uint32_t>(), s);
+            uint32_t* sorted_keys = where ? dev->keys_b.as<uint32_t>() : dev->keys_a.as<uint32_t>();
+            sorted_vals = where ? dev->vals_b.as<uint32_t>() : dev->vals_a.as<uint32_t>();
+            rhk::tile_ranges(sorted_keys, n, dev->tile_start.as<uint32_t>(), dev->tile_end.as<uint32_t>(), n_tiles, s);
+        }
+    }
+    if (total == 0) {
+        RH_HIP(hipMemsetAsync(dev->tile_start.ptr, 0, (size_t)n_tiles * 4, s));
+        RH_HIP(hipMemsetAsync(dev->tile_end.ptr, 0, (size_t)n_tiles * 4, s));
+    }
+
+    rh_tile_args ta;
+    memset(&ta, 0, sizeof ta);
+    ta.p = p; ta.p.n_clusters = n_clusters;
+    ta.list = sorted_vals; ta.tile_start = dev->tile_start.as<uint32_t>(); ta.tile_end = dev->tile_end.as<uint32_t>();
+    ta.n_att = (uint32_t)c.attachments.size();
+    bool any_clear = false;
+    for (size_t i = 0; i < c.attachments.size(); i++) {
+        const rh_attachment_desc& a = c.attachments[i];
+        rh_attach_dev& d = ta.att[i];
+        d.ptr = (uint8_t*)a.texture->dptr; d.pitch_px = a.texture->width; d.format = a.texture->format; d.load_op = a.load_op;
+        d.clear_rgba8 = unorm8(a.clear[0]) | (unorm8(a.clear[1]) << 8) | (unorm8(a.clear[2]) << 16) | (unorm8(a.clear[3]) << 24);
+        any_clear = any_clear || a.load_op == RH_LOAD_OP_CLEAR;
+    }
+    ta.src_factor = pl->targets[0].src_factor; ta.dst_factor = pl->targets[0].dst_factor;
+    if (total > 0 || any_clear)
+        if (launch_module_kernel(pl->fs->tile[c.attachments.size() - 1], n_tiles, &ta, sizeof ta, s)) return 1;
+
+    dev->stats.clusters = n_clusters; dev->stats.bin_entries = total;
+    dev->stats.tiles_x = p.tiles_x; dev->stats.tiles_y = p.tiles_y; dev->stats.tile_size = RH_TILE;
+    return 0;
+}
+
+int execute_copy(rh_device* dev, const CopyCmd& c) {
+    rhk::copy_texture_to_buffer((const uint8_t*)c.tex->dptr, c.tex->width * c.tex->bpt, c.ox, c.oy, c.tex->bpt, c.width, c.height,
+                                (uint8_t*)c.buf->dptr, c.bytes_per_row, dev->stream);
+    RH_HIP(hipGetLastError());
+    return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+int rh_submit(rh_device* dev, rh_cmdbuf* const* list, size_t n) {
+    if (!dev || (!list && n)) return fail("rh_submit: bad argument");
+    if (set_device(dev)) return 1;
+    int rc = 0;
+    for (size_t i = 0; i < n; i++) {
+        rh_cmdbuf* cb = list[i];
+        if (!cb) continue;
+        if (!rc) {
+            for (const Cmd& c : cb->cmds) {
+                rc = c.kind == 0 ? execute_pass(dev, c.pass) : execute_copy(dev, c.copy);
+                if (rc) break;
+            }
+        }
+        rh_cmdbuf_release(cb);
+    }
+    if (!rc) rc = rh_poll(dev, 0);
+    return rc;
+}
+
+int rh_device_last_pass_stats(rh_device* dev, rh_pass_stats* out) {
+    if (!dev || !out) return fail("rh_device_last_pass_stats: bad argument");
+    *out = dev->stats;
+    return 0;
+}
+
+} // extern "C"

@@ -1,0 +1,273 @@
+// Shader-independent device kernels of librenderer_hip.so: prefix sums, (tile, cluster) pair emission, the stable
+// LSD radix sort that turns the pair array into per-tile cluster lists in primitive order, tile range extraction,
+// and the texture -> buffer copy of the capture path.
+#include <hip/hip_runtime.h>
+#include "rh_abi.h"
+#include "rh_kernels.h"
+
+namespace {
+
+constexpr int WG = 256;
+constexpr int SCAN_ITEMS = 16;                 // items per thread in the chunked scan
+constexpr int SCAN_CHUNK = WG * SCAN_ITEMS;    // 4096
+constexpr int SORT_ITEMS = 16;
+constexpr int SORT_CHUNK = WG * SORT_ITEMS;    // 4096 pairs per workgroup, 1024 per wave
+
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t n = __shfl_up(v, off);
+        if (lane >= off) v += n;
+    }
+    return v;
+}
+
+// Exclusive scan of one value per thread across a 256-thread workgroup; returns the exclusive prefix and the total.
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* lds4, uint32_t& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = wave_inclusive_scan(v, lane);
+    if (lane == 63) lds4[wave] = inc;
+    __syncthreads();
+    uint32_t w0 = lds4[0], w1 = lds4[1], w2 = lds4[2], w3 = lds4[3];
+    uint32_t base = wave == 0 ? 0u : (wave == 1 ? w0 : (wave == 2 ? w0 + w1 : w0 + w1 + w2));
+    total = w0 + w1 + w2 + w3;
+    __syncthreads();
+    return base + inc - v;
+}
+
+} // namespace
+
+// ---- chunked exclusive scan (in place), three launches for any n -------------------------------------------------------
+// phase 1: per-chunk sums
+extern "C" __global__ __launch_bounds__(256) void rh_scan_reduce(const uint32_t* data, uint32_t n, uint32_t* chunk_sums) {
+    __shared__ uint32_t lds4[4];
+    const size_t base = (size_t)blockIdx.x * SCAN_CHUNK;
+    uint32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        size_t idx = base + (size_t)i * WG + threadIdx.x;
+        if (idx < n) s += data[idx];
+    }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+    if ((threadIdx.x & 63) == 0) lds4[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) chunk_sums[blockIdx.x] = lds4[0] + lds4[1] + lds4[2] + lds4[3];
+}
+
+// phase 2: single workgroup, exclusive scan of the chunk sums in place; writes the grand total (64-bit)
+extern "C" __global__ __launch_bounds__(256) void rh_scan_chunks(uint32_t* chunk_sums, uint32_t n_chunks, unsigned long long* total_out) {
+    __shared__ uint32_t lds4[4];
+    unsigned long long running = 0;
+    for (uint32_t base = 0; base < n_chunks; base += WG) {
+        uint32_t idx = base + threadIdx.x;
+        uint32_t v = idx < n_chunks ? chunk_sums[idx] : 0u;
+        uint32_t total;
+        uint32_t ex = block_exclusive_scan(v, lds4, total);
+        if (idx < n_chunks) chunk_sums[idx] = (uint32_t)running + ex;
+        running += total;
+    }
+    if (threadIdx.x == 0 && total_out) *total_out = running;
+}
+
+// phase 3: per-chunk exclusive scan plus the chunk's base
+extern "C" __global__ __launch_bounds__(256) void rh_scan_apply(uint32_t* data, uint32_t n, const uint32_t* chunk_bases) {
+    __shared__ uint32_t lds4[4];
+    const size_t base = (size_t)blockIdx.x * SCAN_CHUNK + (size_t)threadIdx.x * SCAN_ITEMS;
+    uint32_t v[SCAN_ITEMS];
+    uint32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) { v[i] = (base + i < n) ? data[base + i] : 0u; s += v[i]; }
+    uint32_t total;
+    uint32_t ex = block_exclusive_scan(s, lds4, total) + chunk_bases[blockIdx.x];
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) { if (base + i < n) data[base + i] = ex; ex += v[i]; }
+}
+
+// ---- pair emission ------------------------------------------------------------------------------------------------------
+// One thread per cluster (same 256-cluster partition as rh_bin_count).  Cluster c writes its (tile, c) pairs at
+// block_base + exclusive prefix within the block, tiles in row-major order, so the pair array is ordered by cluster.
+// Clusters that touch more than 32 tiles are written cooperatively by the whole workgroup.
+extern "C" __global__ __launch_bounds__(256) void rh_bin_emit(const rh_tile_range* ranges, uint32_t n_clusters, uint32_t tiles_x,
+                                                             const uint32_t* block_bases, uint32_t* keys, uint32_t* vals) {
+    __shared__ uint32_t lds4[4];
+    __shared__ uint32_t big_n;
+    __shared__ uint32_t big_cluster[WG], big_off[WG];
+    if (threadIdx.x == 0) big_n = 0;
+    const uint32_t c = blockIdx.x * WG + threadIdx.x;
+    uint32_t tx0 = 1, ty0 = 0, tx1 = 0, ty1 = 0, count = 0;
+    if (c < n_clusters) {
+        rh_tile_range r = ranges[c];
+        tx0 = r.lo & 0xffffu; ty0 = r.lo >> 16; tx1 = r.hi & 0xffffu; ty1 = r.hi >> 16;
+        if (tx0 <= tx1) count = (tx1 - tx0 + 1) * (ty1 - ty0 + 1);
+    }
+    uint32_t total;
+    uint32_t off = block_exclusive_scan(count, lds4, total) + block_bases[blockIdx.x];
+    if (count > 32) {
+        uint32_t slot = atomicAdd(&big_n, 1u);
+        big_cluster[slot] = threadIdx.x; big_off[slot] = off;
+    } else if (count > 0) {
+        for (uint32_t ty = ty0; ty <= ty1; ty++)
+            for (uint32_t tx = tx0; tx <= tx1; tx++) { keys[off] = ty * tiles_x + tx; vals[off] = c; off++; }
+    }
+    __syncthreads();
+    const uint32_t nb = big_n;
+    for (uint32_t b = 0; b < nb; b++) {
+        const uint32_t cc = blockIdx.x * WG + big_cluster[b];
+        rh_tile_range r = ranges[cc];
+        const uint32_t x0 = r.lo & 0xffffu, y0 = r.lo >> 16, x1 = r.hi & 0xffffu, y1 = r.hi >> 16;
+        const uint32_t w = x1 - x0 + 1, cnt = w * (y1 - y0 + 1), o = big_off[b];
+        for (uint32_t i = threadIdx.x; i < cnt; i += WG) {
+            keys[o + i] = (y0 + i / w) * tiles_x + (x0 + i % w); vals[o + i] = cc;
+        }
+    }
+}
+
+// ---- stable LSD radix sort, 8 bits per pass ------------------------------------------------------------------------------
+// histogram: hist[digit * n_blocks + block]
+extern "C" __global__ __launch_bounds__(256) void rh_sort_hist(const uint32_t* keys, uint32_t n, uint32_t shift, uint32_t* hist, uint32_t n_blocks) {
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const size_t base = (size_t)blockIdx.x * SORT_CHUNK;
+#pragma unroll
+    for (int i = 0; i < SORT_ITEMS; i++) {
+        size_t idx = base + (size_t)i * WG + threadIdx.x;
+        if (idx < n) atomicAdd(&h[(keys[idx] >> shift) & 0xffu], 1u);
+    }
+    __syncthreads();
+    hist[(size_t)threadIdx.x * n_blocks + blockIdx.x] = h[threadIdx.x];
+}
+
+// scatter: `offsets` is the exclusive scan of hist.  Each wave owns 1024 consecutive pairs and walks them in order,
+// 64 at a time; a lane's rank among the lanes with the same digit comes from eight ballots, so equal keys keep their
+// input order (stability is what preserves primitive order inside a tile).
+extern "C" __global__ __launch_bounds__(256) void rh_sort_scatter(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
+                                                                 uint32_t n, uint32_t shift, const uint32_t* offsets, uint32_t n_blocks) {
+    __shared__ uint32_t cnt[4][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 4 * 256; i += WG) (&cnt[0][0])[i] = 0;
+    __syncthreads();
+    const size_t wave_base = (size_t)blockIdx.x * SORT_CHUNK + (size_t)wave * (SORT_CHUNK / 4);
+    // per-wave digit counts
+    for (int step = 0; step < SORT_CHUNK / 4 / 64; step++) {
+        size_t idx = wave_base + (size_t)step * 64 + lane;
+        if (idx < n) atomicAdd(&cnt[wave][(keys_in[idx] >> shift) & 0xffu], 1u);
+    }
+    __syncthreads();
+    // turn counts into running bases: global offset of (digit, block) + counts of the earlier waves
+    {
+        const int d = threadIdx.x;
+        uint32_t base = offsets[(size_t)d * n_blocks + blockIdx.x];
+        uint32_t c0 = cnt[0][d], c1 = cnt[1][d], c2 = cnt[2][d];
+        cnt[0][d] = base; cnt[1][d] = base + c0; cnt[2][d] = base + c0 + c1; cnt[3][d] = base + c0 + c1 + c2;
+    }
+    __syncthreads();
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    for (int step = 0; step < SORT_CHUNK / 4 / 64; step++) {
+        size_t idx = wave_base + (size_t)step * 64 + lane;
+        const bool valid = idx < n;
+        uint32_t key = 0, val = 0;
+        if (valid) { key = keys_in[idx]; val = vals_in[idx]; }
+        const uint32_t d = (key >> shift) & 0xffu;
+        unsigned long long peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            unsigned long long bal = __ballot((d >> b) & 1u);
+            peers &= ((d >> b) & 1u) ? bal : ~bal;
+        }
+        if (valid) {
+            const uint32_t rank = (uint32_t)__popcll(peers & lt_mask);
+            const uint32_t dst = cnt[wave][d] + rank;
+            keys_out[dst] = key; vals_out[dst] = val;
+        }
+        // the highest lane of every digit group advances that digit's base (reads above finish before the update:
+        // same wave, program order, LDS operations complete in order)
+        if (valid && (peers >> lane) == 1ull) cnt[wave][d] += (uint32_t)__popcll(peers);
+    }
+}
+
+// ---- tile ranges from the sorted key array --------------------------------------------------------------------------------
+extern "C" __global__ __launch_bounds__(256) void rh_tile_ranges(const uint32_t* keys, uint32_t n, uint32_t* tile_start, uint32_t* tile_end) {
+    const size_t i = (size_t)blockIdx.x * WG + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t k = keys[i];
+    if (i == 0 || keys[i - 1] != k) tile_start[k] = (uint32_t)i;
+    if (i == n - 1 || keys[i + 1] != k) tile_end[k] = (uint32_t)i + 1;
+}
+
+// ---- capture: texture region -> buffer with a 256-byte-aligned row pitch --------------------------------------------------
+// One thread per 4 bytes; rows are contiguous in both source and destination so accesses coalesce.  Padding bytes
+// at the end of each destination row are written as zero.
+extern "C" __global__ __launch_bounds__(256) void rh_copy_texture_to_buffer(const uint8_t* tex, uint32_t tex_pitch_bytes, uint32_t origin_x, uint32_t origin_y,
+                                                                           uint32_t bytes_per_texel, uint32_t width, uint32_t height,
+                                                                           uint8_t* dst, uint32_t dst_pitch_bytes) {
+    const uint32_t row = blockIdx.y;
+    if (row >= height) return;
+    const uint32_t row_bytes = width * bytes_per_texel;
+    const uint8_t* src_row = tex + (size_t)(origin_y + row) * tex_pitch_bytes + (size_t)origin_x * bytes_per_texel;
+    uint8_t* dst_row = dst + (size_t)row * dst_pitch_bytes;
+    for (uint32_t b = (blockIdx.x * WG + threadIdx.x) * 4u; b < dst_pitch_bytes; b += gridDim.x * WG * 4u) {
+        uint32_t v = 0;
+        if (b + 4 <= row_bytes && ((bytes_per_texel & 3u) == 0)) v = *reinterpret_cast<const uint32_t*>(src_row + b);
+        else { for (uint32_t k = 0; k < 4; k++) if (b + k < row_bytes) v |= (uint32_t)src_row[b + k] << (8 * k); }
+        *reinterpret_cast<uint32_t*>(dst_row + b) = v;
+    }
+}
+
+// ---- host-callable launchers ----------------------------------------------------------------------------------------------
+namespace rhk {
+
+static inline uint32_t div_up(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+
+uint32_t scan_chunks_for(uint32_t n) { return div_up(n, SCAN_CHUNK); }
+uint32_t sort_blocks_for(uint32_t n) { return div_up(n, SORT_CHUNK); }
+
+// In-place exclusive scan of data[0..n); chunk_tmp needs scan_chunks_for(n) words.
+void exclusive_scan(uint32_t* data, uint32_t n, uint32_t* chunk_tmp, unsigned long long* total_out, hipStream_t s) {
+    if (n == 0) { if (total_out) (void)hipMemsetAsync(total_out, 0, sizeof(unsigned long long), s); return; }
+    const uint32_t chunks = scan_chunks_for(n);
+    hipLaunchKernelGGL(rh_scan_reduce, dim3(chunks), dim3(WG), 0, s, data, n, chunk_tmp);
+    hipLaunchKernelGGL(rh_scan_chunks, dim3(1), dim3(WG), 0, s, chunk_tmp, chunks, total_out);
+    hipLaunchKernelGGL(rh_scan_apply, dim3(chunks), dim3(WG), 0, s, data, n, chunk_tmp);
+}
+
+void bin_emit(const rh_tile_range* ranges, uint32_t n_clusters, uint32_t tiles_x, const uint32_t* block_bases,
+              uint32_t* keys, uint32_t* vals, hipStream_t s) {
+    if (n_clusters == 0) return;
+    hipLaunchKernelGGL(rh_bin_emit, dim3(div_up(n_clusters, WG)), dim3(WG), 0, s, ranges, n_clusters, tiles_x, block_bases, keys, vals);
+}
+
+// Sorts n pairs by the low `key_bits` bits of the key.  Buffers ping-pong; returns 0 when the result is in
+// (keys_a, vals_a) and 1 when it is in (keys_b, vals_b).  hist needs 256 * sort_blocks_for(n) words, chunk_tmp
+// scan_chunks_for(256 * sort_blocks_for(n)) words.
+int radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, uint32_t n, uint32_t key_bits,
+                     uint32_t* hist, uint32_t* chunk_tmp, hipStream_t s) {
+    if (n == 0) return 0;
+    const uint32_t blocks = sort_blocks_for(n);
+    int cur = 0;
+    for (uint32_t shift = 0; shift < key_bits; shift += 8) {
+        uint32_t* ki = cur ? keys_b : keys_a; uint32_t* vi = cur ? vals_b : vals_a;
+        uint32_t* ko = cur ? keys_a : keys_b; uint32_t* vo = cur ? vals_a : vals_b;
+        hipLaunchKernelGGL(rh_sort_hist, dim3(blocks), dim3(WG), 0, s, ki, n, shift, hist, blocks);
+        exclusive_scan(hist, 256u * blocks, chunk_tmp, nullptr, s);
+        hipLaunchKernelGGL(rh_sort_scatter, dim3(blocks), dim3(WG), 0, s, ki, vi, ko, vo, n, shift, hist, blocks);
+        cur ^= 1;
+    }
+    return cur;
+}
+
+void tile_ranges(const uint32_t* keys, uint32_t n, uint32_t* tile_start, uint32_t* tile_end, uint32_t n_tiles, hipStream_t s) {
+    (void)hipMemsetAsync(tile_start, 0, (size_t)n_tiles * 4, s);
+    (void)hipMemsetAsync(tile_end, 0, (size_t)n_tiles * 4, s);
+    if (n == 0) return;
+    hipLaunchKernelGGL(rh_tile_ranges, dim3(div_up(n, WG)), dim3(WG), 0, s, keys, n, tile_start, tile_end);
+}
+
+void copy_texture_to_buffer(const uint8_t* tex, uint32_t tex_pitch_bytes, uint32_t ox, uint32_t oy, uint32_t bpt, uint32_t w, uint32_t h,
+                            uint8_t* dst, uint32_t dst_pitch, hipStream_t s) {
+    if (w == 0 || h == 0) return;
+    uint32_t gx = div_up(dst_pitch / 4, WG); if (gx > 16) gx = 16;
+    hipLaunchKernelGGL(rh_copy_texture_to_buffer, dim3(gx, h), dim3(WG), 0, s, tex, tex_pitch_bytes, ox, oy, bpt, w, h, dst, dst_pitch);
+}
+
+} // namespace rhk

@@ -1,0 +1,217 @@
+"""Scene descriptions shared by the parity tests, smoke() and bench.py: each scene is a plain dict that can be drawn
+both by the HIP renderer (through renderer_amd, i.e. the C ABI) and by the CPU oracle.
+
+Scene keys
+  shader        'hello' | 'sized'
+  width,height  window / target size
+  target        'screen' (BGRA8 offscreen screen) | 'texture' (RGBA8 texture target)
+  position,uv   per-vertex attributes (location 0 and 1), float32 [V, 2]
+  instances     float32 [N, 2] ('hello') or [N, 4] ('sized')
+  texture       uint8 [H, W, 4] (or [H, W] for r_u8), texture_format, filter ('linear' | 'nearest')
+  blend         'premultiplied' | 'additive'
+  topology      'strip' | 'list'
+  clear         None | (r, g, b, a)
+  viewport      None | (aspect_x, aspect_y)
+  record        False | True  (adds the RGBA8 recording attachment)
+"""
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+f32 = np.float32
+
+
+def load_letter_f():
+    """The reference example's texture (examples/quads/letter_f.png, committed as tests/golden/letter_f.png),
+    premultiplied the way examples/quads_main_thread.rs:181-189 does: c * (a / 255) in f32, rounded half away from
+    zero (Rust f32::round)."""
+    from PIL import Image
+    img = np.array(Image.open(os.path.join(HERE, "golden", "letter_f.png")).convert("RGBA"), dtype=np.uint8)
+    out = img.copy()
+    alpha = img[..., 3].astype(f32) / f32(255.0)
+    for c in range(3):
+        v = img[..., c].astype(f32) * alpha
+        out[..., c] = np.floor(v + f32(0.5)).astype(np.uint8)      # values are >= 0, so this is round-half-away
+    return out
+
+
+def example_positions(frame):
+    """Instance offsets of the quads example at frame `frame` (1-based): the f32 bounce recurrence of
+    examples/quads_main_thread.rs:122-141."""
+    state = [[f32(0.3), f32(0.015)], [f32(-0.3), f32(0.01)], [f32(-0.5), f32(0.005)], [f32(-0.1), f32(0.02)]]
+    for _ in range(frame):
+        for s in state:
+            s[0] = f32(s[0] + s[1])
+            if s[0] > f32(0.9) or s[0] < f32(-0.9):
+                s[1] = f32(s[1] * f32(-1.0))
+    return np.array([state[0][0], state[1][0], state[2][0], state[3][0]], dtype=f32).reshape(2, 2)
+
+
+QUAD_POSITION = np.array([[-0.1, -0.1], [-0.1, 0.1], [0.1, -0.1], [0.1, 0.1]], dtype=f32)   # quads_main_thread.rs:86
+QUAD_UV = np.array([[0., 1.], [0., 0.], [1., 1.], [1., 0.]], dtype=f32)                      # quads_main_thread.rs:87
+UNIT_POSITION = np.array([[-1., -1.], [-1., 1.], [1., -1.], [1., 1.]], dtype=f32)
+
+
+def example_scene(frame, width=1920, height=1080, record=False):
+    """BASELINE config[0]: the quads example at 1920x1080 with a 1:1 letterboxed viewport."""
+    return dict(shader="hello", width=width, height=height, target="screen", position=QUAD_POSITION, uv=QUAD_UV,
+                instances=example_positions(frame), texture=load_letter_f(), texture_format="rgba_u8",
+                filter="linear", blend="premultiplied", topology="strip", clear=(0., 0., 0., 1.),
+                viewport=(1., 1.), record=record)
+
+
+def random_quads_scene(n, side_px, width, height, seed, blend="premultiplied", filter="linear", target="texture",
+                       clear=(0., 0., 0., 1.), texture=None):
+    """BASELINE config[1] family: n quads of side_px x side_px pixels, positions uniform with random sub-pixel
+    offsets, fully inside the target."""
+    rng = np.random.default_rng(seed)
+    hx, hy = f32(side_px / width), f32(side_px / height)         # half extents in NDC: (side/2) / (size/2)
+    position = np.array([[-hx, -hy], [-hx, hy], [hx, -hy], [hx, hy]], dtype=f32)
+    cx = rng.uniform(-1.0 + float(hx), 1.0 - float(hx), n).astype(f32)
+    cy = rng.uniform(-1.0 + float(hy), 1.0 - float(hy), n).astype(f32)
+    return dict(shader="hello", width=width, height=height, target=target, position=position, uv=QUAD_UV,
+                instances=np.stack([cx, cy], axis=1).astype(f32),
+                texture=load_letter_f() if texture is None else texture, texture_format="rgba_u8",
+                filter=filter, blend=blend, topology="strip", clear=clear, viewport=None, record=False)
+
+
+def tiny_quads_scene(n, width, height, seed, lo=2, hi=8):
+    """BASELINE config[2]: n quads with integer side in [lo, hi] px, additive blending, vec4 instance records."""
+    rng = np.random.default_rng(seed)
+    side = rng.integers(lo, hi + 1, n)
+    hw = (side / width).astype(f32); hh = (side / height).astype(f32)
+    cx = rng.uniform(-0.98, 0.98, n).astype(f32); cy = rng.uniform(-0.98, 0.98, n).astype(f32)
+    return dict(shader="sized", width=width, height=height, target="texture", position=UNIT_POSITION, uv=QUAD_UV,
+                instances=np.stack([cx, cy, hw, hh], axis=1).astype(f32), texture=load_letter_f(),
+                texture_format="rgba_u8", filter="linear", blend="additive", topology="strip",
+                clear=(0., 0., 0., 1.), viewport=None, record=False)
+
+
+# ---- drawing with the oracle -------------------------------------------------------------------------------------------------
+def draw_oracle(scene, threads=0, clip_to_viewport=True, initial=None):
+    """Returns {'color': uint8 [H, W, 4] in the target's byte order, 'recording': ... (if record), 'fragments': n}."""
+    from oracle import loader as O
+    W, H = scene["width"], scene["height"]
+    fmt = O.FMT_BGRA_U8 if scene["target"] == "screen" else O.FMT_RGBA_U8
+    color = np.zeros((H, W, 4), dtype=np.uint8) if initial is None else initial.copy()
+    targets = [dict(data=color, format=fmt, clear=scene["clear"])]
+    rec = None
+    if scene.get("record"):
+        rec = np.zeros((H, W, 4), dtype=np.uint8)
+        targets.append(dict(data=rec, format=O.FMT_RGBA_U8, clear=scene.get("record_clear", scene["clear"])))
+    viewport = None
+    if scene["viewport"] is not None:
+        from renderer_amd.viewport import Viewport
+        v = Viewport(scene["viewport"][0], scene["viewport"][1], float(W), float(H))
+        viewport = (v.margin_x, v.margin_y, v.width, v.height)
+    tex = scene["texture"]
+    tfmt = {"rgba_u8": O.FMT_RGBA_U8, "bgra_u8": O.FMT_BGRA_U8, "r_u8": O.FMT_R_U8}[scene["texture_format"]]
+    layers = scene.get("texture_layers", 1)
+    th, tw = (tex.shape[0] // layers, tex.shape[1])
+    blend = {"premultiplied": (O.BF_ONE, O.BF_ONE_MINUS_SRC_ALPHA), "additive": (O.BF_ONE, O.BF_ONE)}[scene["blend"]]
+    n = O.render(shader={"hello": O.SHADER_HELLO, "sized": O.SHADER_SIZED}[scene["shader"]],
+                 topology=O.TOPO_TRIANGLE_STRIP if scene["topology"] == "strip" else O.TOPO_TRIANGLE_LIST,
+                 vertex_count=len(scene["position"]), instance_count=len(scene["instances"]),
+                 attrs=[(scene["position"], 2), (scene["uv"], 2)], storage=[scene["instances"]],
+                 textures=[(tex, tw, th, layers, tfmt, O.FILTER_LINEAR if scene["filter"] == "linear" else O.FILTER_NEAREST)],
+                 targets=targets, blend=blend, viewport=viewport, clip_to_viewport=clip_to_viewport, threads=threads)
+    out = {"color": color, "fragments": n}
+    if rec is not None:
+        out["recording"] = rec
+    return out
+
+
+# ---- drawing with the HIP renderer ----------------------------------------------------------------------------------------------
+def shader_code(name):
+    import renderer_amd
+    d = os.path.join(os.path.dirname(renderer_amd.__file__), "shaders")
+    with open(os.path.join(d, f"{name}.vert.co"), "rb") as f:
+        vert = f.read()
+    with open(os.path.join(d, f"{name}.frag.co"), "rb") as f:
+        frag = f.read()
+    return vert, frag
+
+
+class HipScene:
+    """Builds the renderer objects for a scene the way examples/quads_main_thread.rs:37-88 does."""
+
+    def __init__(self, scene, renderer=None, clip_to_viewport=True):
+        from renderer_amd import Renderer
+        self.scene = scene
+        W, H = scene["width"], scene["height"]
+        self.renderer = r = renderer or Renderer(W, H)
+        self.owns = renderer is None
+        r.set_clip_to_viewport(clip_to_viewport)
+        vert, frag = shader_code(scene["shader"])
+        tex = scene["texture"]
+        layers = scene.get("texture_layers", 1)
+        th, tw = tex.shape[0] // layers, tex.shape[1]
+        fmt = {"rgba_u8": Renderer.rgba_u8(), "bgra_u8": Renderer.bgra_u8(), "r_u8": Renderer.red_u8()}[scene["texture_format"]]
+        flt = Renderer.linear_filtering() if scene["filter"] == "linear" else Renderer.nearest_filtering()
+        a_position = r.attribute(0, 2)
+        a_tex_coord = r.attribute(1, 2)
+        i_offset = r.instanced()
+        t_texture = r.texture(tw, th, layers, flt, fmt, False, False, True)
+        program = r.program(vert, frag, [a_position, a_tex_coord], [i_offset], [],
+                            [(t_texture, Renderer.visible_to_fragment_shader())])
+        blend = Renderer.pre_multiplied_blend() if scene["blend"] == "premultiplied" else Renderer.additive_blend()
+        primitive = Renderer.triangle_strip_primitive() if scene["topology"] == "strip" else Renderer.triangle_primitive()
+        if scene["target"] == "screen":
+            self.target_texture = None
+            target = Renderer.screen_target()
+        else:
+            self.target_texture = r.texture(W, H, 1, Renderer.nearest_filtering(), Renderer.rgba_u8(), True, True, False)
+            target = Renderer.texture_target(self.target_texture)
+        self.pipeline = r.pipeline(program, blend, primitive, 1, [target])
+        r.set_attribute(self.pipeline, 0, scene["position"])
+        r.set_attribute(self.pipeline, 1, scene["uv"])
+        layer_px = tex.reshape(layers, -1)
+        r.set_texture(self.pipeline, (0, 1), [layer_px[i] for i in range(layers)])
+        r.set_instanced(self.pipeline, (0, 0), scene["instances"])
+        self.clear = Renderer.clear_color(*scene["clear"]) if scene["clear"] is not None else None
+        self.viewport = r.viewport(*scene["viewport"]) if scene["viewport"] is not None else None
+        self.count = (len(scene["instances"]), len(scene["position"]))
+        self.frames = []
+        if scene.get("record"):
+            rc = scene.get("record_clear", scene["clear"])
+            r.start_recording([self.pipeline], Renderer.clear_color(*rc) if rc is not None else None, 500.,
+                              lambda frame: self.frames.append(frame))
+
+    def set_initial(self, image):
+        """Pre-fills the colour target (for LoadOp::Load scenes)."""
+        from renderer_amd import _ffi
+        h = self.target_texture.handle if self.target_texture is not None else self.renderer.screen_handle()
+        image = np.ascontiguousarray(image)
+        _ffi.check(_ffi.lib().rh_texture_write(h, 0, 0, 0, image.shape[1], image.shape[0], image.ctypes.data,
+                                               image.nbytes, image.shape[1] * 4))
+
+    def draw(self):
+        self.renderer.render(self.pipeline, self.clear, self.viewport, self.count)
+        self.renderer.finish_frame()
+
+    def read_color(self):
+        if self.target_texture is not None:
+            return self.target_texture.read()
+        return self.renderer.read_screen()
+
+    def read_recording(self):
+        return self.renderer.recorder.recording_texture.read()
+
+    def close(self):
+        if self.owns:
+            self.renderer.close()
+
+
+def draw_hip(scene, clip_to_viewport=True, initial=None):
+    hs = HipScene(scene, clip_to_viewport=clip_to_viewport)
+    try:
+        if initial is not None:
+            hs.set_initial(initial)
+        hs.draw()
+        out = {"color": hs.read_color(), "stats": hs.renderer.last_pass_stats()}
+        if scene.get("record"):
+            out["recording"] = hs.read_recording()
+        return out
+    finally:
+        hs.close()

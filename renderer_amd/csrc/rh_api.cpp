@@ -60,6 +60,7 @@ struct Scratch {
 } // namespace
 
 struct rh_device {
+    std::atomic<int> refs{1};        // the creator's reference plus one per live object created on the device
     int ordinal = 0;
     hipStream_t stream = nullptr;
     uint32_t width = 0, height = 0;
@@ -145,6 +146,9 @@ struct rh_cmdbuf { rh_device* dev = nullptr; std::vector<Cmd> cmds; };
 // ---- allocation caches ------------------------------------------------------------------------------------------------
 namespace {
 
+void device_retain(rh_device* dev) { dev->refs.fetch_add(1); }
+void device_release(rh_device* dev);
+
 int device_alloc(rh_device* dev, size_t size, void** out) {
     auto it = dev->free_device.find(size);
     if (it != dev->free_device.end()) { *out = it->second; dev->free_device.erase(it); return 0; }
@@ -207,13 +211,26 @@ int rh_device_create(int hip_ordinal, uint32_t width, uint32_t height, rh_device
     return 0;
 }
 
+// Objects created on a device keep it alive: the device is torn down when the creator has called
+// rh_device_destroy AND every buffer/texture/module/pipeline/sampler has been released.
 void rh_device_destroy(rh_device* dev) {
     if (!dev) return;
     (void)hipSetDevice(dev->ordinal);
     (void)hipStreamSynchronize(dev->stream);
-    for (rh_buffer* b : dev->pending_maps) rh_buffer_release(b);
-    dev->pending_maps.clear();
-    if (dev->screen) rh_texture_release(dev->screen);
+    std::vector<rh_buffer*> pending; pending.swap(dev->pending_maps);
+    for (rh_buffer* b : pending) rh_buffer_release(b);
+    rh_texture* screen = dev->screen; dev->screen = nullptr;
+    if (screen) rh_texture_release(screen);
+    device_release(dev);
+}
+
+} // extern "C"
+
+namespace {
+void device_release(rh_device* dev) {
+    if (dev->refs.fetch_sub(1) != 1) return;
+    (void)hipSetDevice(dev->ordinal);
+    (void)hipStreamSynchronize(dev->stream);
     Scratch* all[] = { &dev->ranges, &dev->block_sums, &dev->chunk_tmp, &dev->keys_a, &dev->vals_a, &dev->keys_b, &dev->vals_b,
                        &dev->hist, &dev->tile_start, &dev->tile_end };
     for (Scratch* s : all) s->release();
@@ -224,6 +241,9 @@ void rh_device_destroy(rh_device* dev) {
     (void)hipStreamDestroy(dev->stream);
     delete dev;
 }
+} // namespace
+
+extern "C" {
 
 int rh_device_info(rh_device* dev, char* name, size_t cap) {
     if (!dev || !name || cap == 0) return fail("rh_device_info: bad argument");
@@ -272,9 +292,10 @@ int rh_buffer_create(rh_device* dev, size_t size, uint32_t usage, const void* in
     rh_buffer* b = new rh_buffer();
     b->dev = dev; b->size = size; b->usage = usage;
     if (device_alloc(dev, size, &b->dptr)) { delete b; return 1; }
+    device_retain(dev);
     if (init && init_len) {
         hipError_t e = hipMemcpyAsync(b->dptr, init, init_len, hipMemcpyHostToDevice, dev->stream);
-        if (e != hipSuccess) { device_free(dev, size, b->dptr); delete b; return fail("rh_buffer_create: upload failed: %s", hipGetErrorString(e)); }
+        if (e != hipSuccess) { device_free(dev, size, b->dptr); delete b; device_release(dev); return fail("rh_buffer_create: upload failed: %s", hipGetErrorString(e)); }
     }
     *out = b;
     return 0;
@@ -303,6 +324,7 @@ void rh_buffer_release(rh_buffer* buf) {
     if (buf->hptr) pinned_free(dev, buf->size, buf->hptr);
     if (buf->map_event) (void)hipEventDestroy(buf->map_event);
     delete buf;
+    device_release(dev);
 }
 
 int rh_buffer_map_async(rh_buffer* buf, rh_map_callback cb, void* user) {
@@ -365,9 +387,10 @@ int rh_texture_create(rh_device* dev, uint32_t width, uint32_t height, uint32_t 
     t->dev = dev; t->width = width; t->height = height; t->layers = layers; t->format = format; t->samples = samples; t->usage = usage;
     t->bpt = bpt; t->bytes = (size_t)width * height * layers * bpt;
     if (device_alloc(dev, t->bytes, &t->dptr)) { delete t; return 1; }
+    device_retain(dev);
     // wgpu textures start zero-initialised
     hipError_t e = hipMemsetAsync(t->dptr, 0, t->bytes, dev->stream);
-    if (e != hipSuccess) { device_free(dev, t->bytes, t->dptr); delete t; return fail("rh_texture_create: clear failed: %s", hipGetErrorString(e)); }
+    if (e != hipSuccess) { device_free(dev, t->bytes, t->dptr); delete t; device_release(dev); return fail("rh_texture_create: clear failed: %s", hipGetErrorString(e)); }
     *out = t;
     return 0;
 }
@@ -412,18 +435,21 @@ void rh_texture_retain(rh_texture* tex) { if (tex) tex->refs.fetch_add(1); }
 void rh_texture_release(rh_texture* tex) {
     if (!tex) return;
     if (tex->refs.fetch_sub(1) != 1) return;
-    (void)hipSetDevice(tex->dev->ordinal);
-    device_free(tex->dev, tex->bytes, tex->dptr);
+    rh_device* dev = tex->dev;
+    (void)hipSetDevice(dev->ordinal);
+    device_free(dev, tex->bytes, tex->dptr);
     delete tex;
+    device_release(dev);
 }
 
 int rh_sampler_create(rh_device* dev, uint32_t filter, rh_sampler** out) {
     if (!dev || !out) return fail("rh_sampler_create: bad argument");
     if (filter != RH_FILTER_LINEAR && filter != RH_FILTER_NEAREST) return fail("rh_sampler_create: unknown filter %u", filter);
     *out = new rh_sampler{dev, filter};
+    device_retain(dev);
     return 0;
 }
-void rh_sampler_release(rh_sampler* s) { delete s; }
+void rh_sampler_release(rh_sampler* s) { if (!s) return; rh_device* dev = s->dev; delete s; device_release(dev); }
 
 // ---- modules ------------------------------------------------------------------------------------------------------------
 int rh_module_load(rh_device* dev, const void* code_object, size_t size, rh_module** out) {
@@ -450,6 +476,7 @@ int rh_module_load(rh_device* dev, const void* code_object, size_t size, rh_modu
         for (int i = 0; i < RH_MAX_COLOR_TARGETS; i++)
             if (hipModuleGetFunction(&m->tile[i], m->module, names[i]) != hipSuccess) { (void)hipModuleUnload(m->module); delete m; return fail("rh_module_load: fragment code object lacks %s", names[i]); }
     } else { (void)hipModuleUnload(m->module); delete m; return fail("rh_module_load: unknown stage"); }
+    device_retain(dev);
     *out = m;
     return 0;
 }
@@ -457,9 +484,11 @@ void rh_module_retain(rh_module* m) { if (m) m->refs.fetch_add(1); }
 void rh_module_release(rh_module* m) {
     if (!m) return;
     if (m->refs.fetch_sub(1) != 1) return;
-    (void)hipSetDevice(m->dev->ordinal);
+    rh_device* dev = m->dev;
+    (void)hipSetDevice(dev->ordinal);
     (void)hipModuleUnload(m->module);
     delete m;
+    device_release(dev);
 }
 
 // ---- pipelines -----------------------------------------------------------------------------------------------------------
@@ -507,6 +536,7 @@ int rh_pipeline_create(rh_device* dev, const rh_pipeline_desc* d, rh_pipeline** 
     for (SlotRef& r : p->slots) { if (r.buf) rh_buffer_retain(r.buf); if (r.tex) rh_texture_retain(r.tex); }
     p->vs = d->vertex_module; p->fs = d->fragment_module;
     rh_module_retain(p->vs); rh_module_retain(p->fs);
+    device_retain(dev);
     *out = p;
     return 0;
 }
@@ -516,7 +546,9 @@ void rh_pipeline_release(rh_pipeline* p) {
     if (p->refs.fetch_sub(1) != 1) return;
     for (SlotRef& r : p->slots) { if (r.buf) rh_buffer_release(r.buf); if (r.tex) rh_texture_release(r.tex); }
     rh_module_release(p->vs); rh_module_release(p->fs);
+    rh_device* dev = p->dev;
     delete p;
+    device_release(dev);
 }
 
 // ---- command encoding ------------------------------------------------------------------------------------------------------

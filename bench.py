@@ -1,0 +1,138 @@
+#!/usr/bin/env python3
+"""Headline benchmark: instanced quads/s at 4K with alpha blending (BASELINE.json configs[1]).
+
+A "step" is one frame: one render pass of 1,000,000 instanced 16x16 px textured quads (pre-multiplied alpha blend,
+linear filtering) into a 3840x2160 RGBA8 texture target, cleared each frame, through the C ABI of
+librenderer_hip.so.  Inputs (instance buffer, attributes, texture) are resident in HBM before the timed region.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): the path shards by frame -- every rank renders its own
+frames with no data-path collective -- so the job value is the sum over ranks ("weak" scaling).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--quads", type=int, default=1_000_000)
+    ap.add_argument("--side", type=int, default=16, help="quad edge in pixels (headline: 16)")
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    n_gpus = max(args.gpus, world)
+
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import numpy as np
+    import scenes
+    from renderer_amd import Renderer
+
+    # every rank renders a different frame of the same distribution
+    scene = scenes.random_quads_scene(args.quads, args.side, args.width, args.height, seed=1 + rank)
+    renderer = Renderer(args.width, args.height, hip_ordinal=local_rank)
+    hs = scenes.HipScene(scene, renderer=renderer)
+
+    def step():
+        renderer.render(hs.pipeline, hs.clear, hs.viewport, hs.count)
+        renderer.finish_frame()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier(device_ids=[local_rank])
+        renderer.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    renderer.synchronize()
+    renderer.set_timing(True)
+    renderer.drain_timings()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    renderer.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    timings = renderer.drain_timings()
+    renderer.set_timing(False)
+    stats = renderer.last_pass_stats()
+
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        total_quads = args.quads * args.steps * n_gpus
+        value = total_quads / elapsed
+        ms_per_step = elapsed / args.steps * 1e3
+        # Algorithmic bytes of one tile-kernel launch (one frame): every instance record read once, every blended
+        # fragment a read-modify-write of its 4-byte target texel, plus the distinct texels of the texture.
+        n_frag = args.quads * args.side * args.side
+        tex_bytes = scene["texture"].nbytes
+        b_alg = args.quads * scene["instances"].shape[1] * 4 + n_frag * 2 * 4 * 1 + tex_bytes
+        b_min = args.quads * scene["instances"].shape[1] * 4 + args.width * args.height * 4 + tex_bytes
+        tile_ms = timings["tile_ms"] / max(1, timings["passes"])
+        bin_ms = timings["bin_ms"] / max(1, timings["passes"])
+        achieved = b_alg / (tile_ms * 1e-3) / 1e9 if tile_ms > 0 else 0.0
+        out = {
+            "metric": "instanced quads/s at 4K alpha-blend", "value": value, "unit": "quads/s",
+            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32->unorm8",
+            "data": "synthetic",
+            "config": {"workload": f"{args.quads} instanced textured quads {args.side}x{args.side} px, pre-multiplied alpha blend, "
+                                   f"linear filter, {args.width}x{args.height} RGBA8 texture target, clear each frame "
+                                   "(BASELINE.json configs[1])",
+                       "parallelism": f"frame-parallel x{n_gpus}" if n_gpus > 1 else "single GPU",
+                       "bin_entries": int(stats["bin_entries"]), "tile_px": int(stats["tile_size"])},
+            "roofline": {"bound": "hbm", "kernel": "rh_tile_1", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": b_alg, "compulsory_bytes_per_launch": b_min,
+                         "kernel_ms": tile_ms, "binning_ms": bin_ms,
+                         "fragments_per_s": n_frag / (tile_ms * 1e-3) if tile_ms > 0 else 0.0},
+        }
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            # CPU restatement (the parity oracle) timed on the host cores, same scene, one full frame.
+            cores = min(16, os.cpu_count() or 1)
+            t1 = time.perf_counter()
+            orc = scenes.draw_oracle(scene, threads=cores)
+            cpu_s = time.perf_counter() - t1
+            out["cpu_baseline"] = {"value": args.quads / cpu_s, "unit": "quads/s", "cores": cores, "kind": "port",
+                                   "sample": f"one full frame of the same scene ({args.quads} quads, {orc['fragments']} fragments) "
+                                             f"on {cores} threads, {cpu_s:.2f} s wall; CPU restatement, not lavapipe"}
+        print(json.dumps(out), flush=True)
+
+    hs.close()
+    renderer.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -55,6 +55,8 @@ enum { RH_TEXTURE_BINDING = 1, RH_TEXTURE_COPY_DST = 2, RH_TEXTURE_RENDER_ATTACH
 enum {
     RH_OPTION_CLIP_TO_VIEWPORT = 0,   /* 1 (default): fragments outside the viewport rectangle are clipped, as strict
                                          clip-volume clipping gives; 0: only the attachment bounds restrict them */
+    RH_OPTION_TIMING = 1,             /* 1: record HIP events around the binning phase and the tile kernel of every
+                                         render pass (read with rh_device_drain_timings); default 0 */
 };
 
 #define RH_MAX_ATTRIBUTES 8
@@ -204,6 +206,15 @@ typedef struct rh_pass_stats {
     uint32_t tile_size;
 } rh_pass_stats;
 int rh_device_last_pass_stats(rh_device* dev, rh_pass_stats* out);
+
+/* Sums of the HIP-event timings recorded since the previous drain (RH_OPTION_TIMING).  Waits for the recorded
+ * passes to finish. */
+typedef struct rh_timings {
+    uint32_t passes;          /* render passes covered */
+    double bin_ms;            /* vertex/binning phase: count, scan, emit, sort, tile ranges (incl. the host round trip) */
+    double tile_ms;           /* tile kernel (setup + coverage + shading + blend + store) */
+} rh_timings;
+int rh_device_drain_timings(rh_device* dev, rh_timings* out);
 
 #ifdef __cplusplus
 }

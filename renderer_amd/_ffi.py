@@ -19,6 +19,7 @@ STAGE_VERTEX, STAGE_FRAGMENT = 1, 2
 BUFFER_VERTEX, BUFFER_STORAGE, BUFFER_UNIFORM, BUFFER_COPY_DST, BUFFER_MAP_READ = 1, 2, 4, 8, 16
 TEXTURE_BINDING, TEXTURE_COPY_DST, TEXTURE_RENDER_ATTACHMENT, TEXTURE_COPY_SRC = 1, 2, 4, 8
 OPTION_CLIP_TO_VIEWPORT = 0
+OPTION_TIMING = 1
 COPY_BYTES_PER_ROW_ALIGNMENT = 256
 MAX_COLOR_TARGETS = 4
 
@@ -61,6 +62,10 @@ class PassDesc(C.Structure):
 class PassStats(C.Structure):
     _fields_ = [("clusters", C.c_uint64), ("bin_entries", C.c_uint64), ("tiles_x", C.c_uint32), ("tiles_y", C.c_uint32),
                 ("tile_size", C.c_uint32)]
+
+
+class Timings(C.Structure):
+    _fields_ = [("passes", C.c_uint32), ("bin_ms", C.c_double), ("tile_ms", C.c_double)]
 
 
 MAP_CALLBACK = C.CFUNCTYPE(None, C.c_void_p, C.c_int)
@@ -111,6 +116,7 @@ SIGNATURES = {
     "rh_cmdbuf_release": (None, [_P]),
     "rh_submit": (C.c_int, [_P, _PP, C.c_size_t]),
     "rh_device_last_pass_stats": (C.c_int, [_P, C.POINTER(PassStats)]),
+    "rh_device_drain_timings": (C.c_int, [_P, C.POINTER(Timings)]),
 }
 
 _lib = None

@@ -75,6 +75,10 @@ struct rh_device {
     std::multimap<size_t, void*> free_device, free_pinned;
     std::vector<rh_buffer*> pending_maps;
     rh_pass_stats stats{};
+    // optional per-pass HIP-event timing
+    int timing = 0;
+    std::vector<hipEvent_t> event_pool;            // unused events
+    std::vector<hipEvent_t> timing_events;         // 3 per recorded pass: start, before tile kernel, end
 };
 
 struct rh_buffer {
@@ -234,6 +238,8 @@ void device_release(rh_device* dev) {
     Scratch* all[] = { &dev->ranges, &dev->block_sums, &dev->chunk_tmp, &dev->keys_a, &dev->vals_a, &dev->keys_b, &dev->vals_b,
                        &dev->hist, &dev->tile_start, &dev->tile_end };
     for (Scratch* s : all) s->release();
+    for (hipEvent_t e : dev->event_pool) (void)hipEventDestroy(e);
+    for (hipEvent_t e : dev->timing_events) (void)hipEventDestroy(e);
     for (auto& kv : dev->free_device) (void)hipFree(kv.second);
     for (auto& kv : dev->free_pinned) (void)hipHostFree(kv.second);
     if (dev->d_total) (void)hipFree(dev->d_total);
@@ -254,6 +260,7 @@ int rh_device_info(rh_device* dev, char* name, size_t cap) {
 int rh_device_set_option(rh_device* dev, int option, int value) {
     if (!dev) return fail("rh_device_set_option: null device");
     if (option == RH_OPTION_CLIP_TO_VIEWPORT) { dev->clip_to_viewport = value ? 1 : 0; return 0; }
+    if (option == RH_OPTION_TIMING) { dev->timing = value ? 1 : 0; return 0; }
     return fail("rh_device_set_option: unknown option %d", option);
 }
 
@@ -632,6 +639,16 @@ void rh_cmdbuf_release(rh_cmdbuf* cb) { if (!cb) return; release_cmds(cb->cmds);
 // ---- execution ---------------------------------------------------------------------------------------------------------------
 namespace {
 
+int timing_mark(rh_device* dev) {
+    if (!dev->timing) return 0;
+    hipEvent_t e = nullptr;
+    if (!dev->event_pool.empty()) { e = dev->event_pool.back(); dev->event_pool.pop_back(); }
+    else RH_HIP(hipEventCreate(&e));
+    RH_HIP(hipEventRecord(e, dev->stream));
+    dev->timing_events.push_back(e);
+    return 0;
+}
+
 int launch_module_kernel(hipFunction_t fn, uint32_t grid, void* args, size_t args_size, hipStream_t s) {
     void* config[] = { HIP_LAUNCH_PARAM_BUFFER_POINTER, args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &args_size, HIP_LAUNCH_PARAM_END };
     RH_HIP(hipModuleLaunchKernel(fn, grid, 1, 1, 256, 1, 1, 0, s, nullptr, config));
@@ -688,6 +705,7 @@ int execute_pass(rh_device* dev, const PassCmd& c) {
     if (dev->tile_start.ensure((size_t)n_tiles * 4) || dev->tile_end.ensure((size_t)n_tiles * 4)) return 1;
     uint64_t total = 0;
     uint32_t* sorted_vals = nullptr;
+    if (timing_mark(dev)) return 1;
     if (n_clusters > 0) {
         const uint32_t n_blocks = (n_clusters + 255) / 256;
         if (dev->ranges.ensure((size_t)n_clusters * sizeof(rh_tile_range)) || dev->block_sums.ensure((size_t)n_blocks * 4) ||
@@ -734,8 +752,10 @@ int execute_pass(rh_device* dev, const PassCmd& c) {
         any_clear = any_clear || a.load_op == RH_LOAD_OP_CLEAR;
     }
     ta.src_factor = pl->targets[0].src_factor; ta.dst_factor = pl->targets[0].dst_factor;
+    if (timing_mark(dev)) return 1;
     if (total > 0 || any_clear)
         if (launch_module_kernel(pl->fs->tile[c.attachments.size() - 1], n_tiles, &ta, sizeof ta, s)) return 1;
+    if (timing_mark(dev)) return 1;
 
     dev->stats.clusters = n_clusters; dev->stats.bin_entries = total;
     dev->stats.tiles_x = p.tiles_x; dev->stats.tiles_y = p.tiles_y; dev->stats.tile_size = RH_TILE;
@@ -770,6 +790,24 @@ int rh_submit(rh_device* dev, rh_cmdbuf* const* list, size_t n) {
     }
     if (!rc) rc = rh_poll(dev, 0);
     return rc;
+}
+
+int rh_device_drain_timings(rh_device* dev, rh_timings* out) {
+    if (!dev || !out) return fail("rh_device_drain_timings: bad argument");
+    if (set_device(dev)) return 1;
+    out->passes = 0; out->bin_ms = 0.0; out->tile_ms = 0.0;
+    const size_t n = dev->timing_events.size() / 3;
+    for (size_t i = 0; i < n; i++) {
+        hipEvent_t e0 = dev->timing_events[3 * i], e1 = dev->timing_events[3 * i + 1], e2 = dev->timing_events[3 * i + 2];
+        RH_HIP(hipEventSynchronize(e2));
+        float a = 0.0f, b = 0.0f;
+        RH_HIP(hipEventElapsedTime(&a, e0, e1));
+        RH_HIP(hipEventElapsedTime(&b, e1, e2));
+        out->passes++; out->bin_ms += a; out->tile_ms += b;
+    }
+    for (hipEvent_t e : dev->timing_events) dev->event_pool.push_back(e);
+    dev->timing_events.clear();
+    return 0;
 }
 
 int rh_device_last_pass_stats(rh_device* dev, rh_pass_stats* out) {

@@ -154,6 +154,17 @@ class Renderer:
     def set_clip_to_viewport(self, enabled):
         _ffi.check(_ffi.lib().rh_device_set_option(self.device, _ffi.OPTION_CLIP_TO_VIEWPORT, 1 if enabled else 0))
 
+    def set_timing(self, enabled):
+        _ffi.check(_ffi.lib().rh_device_set_option(self.device, _ffi.OPTION_TIMING, 1 if enabled else 0))
+
+    def drain_timings(self):
+        t = _ffi.Timings()
+        _ffi.check(_ffi.lib().rh_device_drain_timings(self.device, C.byref(t)))
+        return {"passes": t.passes, "bin_ms": t.bin_ms, "tile_ms": t.tile_ms}
+
+    def stream(self):
+        return _ffi.lib().rh_device_stream(self.device)
+
     def last_pass_stats(self):
         s = _ffi.PassStats()
         _ffi.check(_ffi.lib().rh_device_last_pass_stats(self.device, C.byref(s)))

@@ -12,6 +12,16 @@ from .texture import Texture
 from .video_frame import AtomicUsize, FrameStatus, ImageData, VideoFrame
 
 
+def capture_layout(width, height, bytes_per_texel):
+    """(unpadded_bytes_per_row, padded_bytes_per_row, frame_size_in_bytes): rows padded to wgpu's 256-byte copy
+    alignment (reference src/video_recorder.rs:73-79)."""
+    unpadded_bytes_per_row = width * bytes_per_texel
+    alignment = _ffi.COPY_BYTES_PER_ROW_ALIGNMENT
+    row_padding = (alignment - unpadded_bytes_per_row % alignment) % alignment
+    padded_bytes_per_row = unpadded_bytes_per_row + row_padding
+    return unpadded_bytes_per_row, padded_bytes_per_row, padded_bytes_per_row * height
+
+
 class VideoRecorder:
     def __init__(self, renderer, clear_color, max_buffer_size_in_bytes, process_function):
         self.device = renderer.device
@@ -49,11 +59,7 @@ class VideoRecorder:
         width = math.floor(viewport.width) if viewport is not None else tex.size[0]
         height = math.floor(viewport.height) if viewport is not None else tex.size[1]
         fmt = tex.format
-        unpadded_bytes_per_row = width * fmt.bytes_per_texel()
-        alignment = _ffi.COPY_BYTES_PER_ROW_ALIGNMENT
-        row_padding = (alignment - unpadded_bytes_per_row % alignment) % alignment
-        padded_bytes_per_row = unpadded_bytes_per_row + row_padding
-        frame_size_in_bytes = padded_bytes_per_row * height
+        unpadded_bytes_per_row, padded_bytes_per_row, frame_size_in_bytes = capture_layout(width, height, fmt.bytes_per_texel())
 
         prev_size = self.buffer_size_in_bytes.fetch_add(frame_size_in_bytes)
         drop_frame = prev_size > self.max_buffer_size_in_bytes

@@ -1,0 +1,128 @@
+"""CPU tests of the host-side mirror and of the C-ABI boundary (no compute calls: there is no GPU here)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "renderer_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rh_[a-z0-9_]+)\s*\(", text)) - {"rh_map_callback"})
+
+
+def test_library_exports_every_declared_symbol():
+    from renderer_amd import _ffi
+    from renderer_amd import build
+    build.build_library()
+    lib = C.CDLL(_ffi.LIB_PATH)
+    declared = header_symbols()
+    assert len(declared) >= 40
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/renderer_hip.h but not exported"
+    # the ctypes binding covers exactly the declared surface
+    assert sorted(_ffi.SIGNATURES) == declared
+    assert lib.rh_abi_version() == 3
+
+
+def test_shader_code_objects_are_gfx950_elf():
+    from renderer_amd import Compiler
+    import renderer_amd
+    d = os.path.join(os.path.dirname(renderer_amd.__file__), "shaders")
+    built = Compiler.compile_shaders(d)
+    assert len(built) >= 4
+    readelf = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    for path in built:
+        assert open(path, "rb").read(4) == b"\x7fELF"
+        if os.path.exists(readelf):
+            out = subprocess.check_output([readelf, "-h", "-s", path]).decode()
+            assert "gfx950" in out and "rh_module_info" in out
+            assert ("rh_bin_count" in out) == path.endswith(".vert.co")
+            assert ("rh_tile_1" in out) == path.endswith(".frag.co")
+
+
+def test_buffer_growth_rule():
+    from renderer_amd.buffer import HEADROOM, INITIAL_SIZE, next_power_of_two
+    assert INITIAL_SIZE == 64 and HEADROOM == 1024
+    assert next_power_of_two(8_000_000 + HEADROOM) == 8_388_608          # 1 M vec2 instances
+    assert next_power_of_two(160_000_000 + HEADROOM) == 268_435_456       # 10 M vec4 instances
+    assert next_power_of_two(65 + HEADROOM) == 2048 and next_power_of_two(1024) == 1024 and next_power_of_two(1) == 1
+
+
+class _Fake:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def test_slot_numbering():
+    from renderer_amd.renderer import texture_index, uniform_index
+    from renderer_amd import RendererError
+    with_sampler, without = _Fake(sampler=object()), _Fake(sampler=None)
+    program = _Fake(instances=[1], uniforms=[], textures=[(with_sampler, None)])
+    # quads example: slot 0 = i_offset, slot 1 = t_texture, slot 2 = s_sampler
+    assert texture_index(1, program) == 0
+    with pytest.raises(RendererError, match="sampler is in that slot"):
+        texture_index(2, program)
+    with pytest.raises(RendererError, match="nothing is in that slot"):
+        texture_index(3, program)
+    program = _Fake(instances=[1, 2], uniforms=[3], textures=[(with_sampler, None), (without, None), (with_sampler, None)])
+    # slots: 0,1 instanced; 2 uniform; 3 tex A; 4 sampler A; 5 tex B; 6 tex C; 7 sampler C
+    assert uniform_index(2, program) == 0
+    assert [texture_index(i, program) for i in (3, 5, 6)] == [0, 1, 2]
+    with pytest.raises(RendererError, match="sampler is in that slot"):
+        texture_index(4, program)
+
+
+def test_format_table():
+    from renderer_amd import Format
+    assert [int(f) for f in Format] == [0, 1, 2, 3, 4]
+    assert [f.bytes_per_texel() for f in Format] == [1, 4, 4, 8, 16]
+    assert Format.default() is Format.RgbaU8
+
+
+def test_capture_layout_rule():
+    from renderer_amd.video_recorder import capture_layout
+    # quads example: 1:1 viewport in 1920x1080 -> 1080 px rows of 4320 B padded to 4352 B
+    assert capture_layout(1080, 1080, 4) == (4320, 4352, 4_700_160)
+    # 4K rows are already 256-byte aligned
+    assert capture_layout(3840, 2160, 4) == (15360, 15360, 33_177_600)
+    assert capture_layout(1, 1, 4) == (4, 256, 256)
+
+
+def test_video_frame_bincode_known_answers():
+    from renderer_amd.video_frame import AtomicUsize, FrameStatus, ImageData, VideoFrame
+    from renderer_amd import Format
+    # Captured 4K frame: status 0, Some, 3840 (fb 00 0f), 2160 (fb 70 08), RgbaU8 = 2, 15360 (fb 00 3c) twice,
+    # frame 7, 33177600 = 0x01fa4000 (fc 00 40 fa 01), budget 66355200 = 0x03f48000 (fc 00 80 f4 03)
+    f = VideoFrame(FrameStatus.Captured, ImageData.Bytes(b""), 3840, 2160, Format.RgbaU8, 15360, 15360, 7, 33177600,
+                   AtomicUsize(66355200))
+    f._dropped = True
+    enc = f.encode()
+    assert enc.hex() == "0001" "fb000f" "fb7008" "02" "fb003c" "fb003c" "07" "fc0040fa01" "fc0080f403"
+    g, used = VideoFrame.decode(enc)
+    assert used == len(enc) and g.status is FrameStatus.Captured and g.image_data is not None and g.image_data.bytes() == b""
+    assert (g.width, g.height, g.format, g.frame_number, g.frame_size_in_bytes) == (3840, 2160, Format.RgbaU8, 7, 33177600)
+    # Dropped frame: no image data, Option tag 0
+    d = VideoFrame(FrameStatus.Dropped, None, 250, 251, Format.RgbaU8, 1000, 1024, 300, 257024, AtomicUsize(0))
+    assert d.encode().hex() == "0100" "fa" "fbfb00" "02" "fbe803" "fb0004" "fb2c01" "fc00ec0300" "00"
+    g, _ = VideoFrame.decode(d.encode())
+    assert g.status is FrameStatus.Dropped and g.image_data is None and g.width == 250 and g.height == 251
+
+
+def test_recording_position_adds_rgba8_target():
+    from renderer_amd.pipeline import Pipeline, RecordingPosition
+    from renderer_amd import BlendMode, Format, Target
+    p = Pipeline.__new__(Pipeline)
+    p.blend_mode = BlendMode.pre_multiplied_alpha(); p.targets = [Target.Screen()]
+    p.position_in_recording = RecordingPosition.NONE
+    states = p.create_color_target_states()
+    assert [(s.format, s.src_factor, s.dst_factor) for s in states] == [(int(Format.BgraU8), 1, 3)]
+    p.position_in_recording = RecordingPosition.NotLast
+    states = p.create_color_target_states()
+    assert [s.format for s in states] == [int(Format.BgraU8), int(Format.RgbaU8)]
+    p.handle = None

@@ -1,0 +1,250 @@
+"""CPU tests of the oracle: hand-derived known answers for the rasterisation rules, the committed golden vectors,
+and the LZ4 restatement against the system liblz4 (1.9.3).  No GPU."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import scenes
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = os.path.join(HERE, "golden")
+f32 = np.float32
+
+
+def sha(b):
+    return hashlib.sha256(bytes(b)).hexdigest()
+
+
+# ---- fixtures of the reference ------------------------------------------------------------------------------------------
+def test_letter_f_fixture_hashes():
+    # hashes of the reference's examples/quads/letter_f.png: file, decoded RGBA, and after the example's premultiply
+    from PIL import Image
+    path = os.path.join(GOLDEN, "letter_f.png")
+    assert sha(open(path, "rb").read()) == "9f08fa8630b12d99696ec9c4ccdd3a2f7e3d37f50eb7fdded79ec6cff253191f"
+    raw = np.array(Image.open(path).convert("RGBA"), dtype=np.uint8)
+    assert raw.shape == (256, 256, 4) and (raw[..., 3] == 204).all()
+    assert sha(raw.tobytes()) == "d6ff14de46e2a1e9e0ea27ca504011a93c6a3adcc4a3011fc05f0cb3957d09e9"
+    assert tuple(raw[0, 0]) == (255, 0, 0, 204) and tuple(raw[128, 128]) == (255, 238, 0, 204) and tuple(raw[255, 255]) == (255, 0, 4, 204)
+    pre = scenes.load_letter_f()
+    assert sha(pre.tobytes()) == "aad1072597f3cc12240a9ad1724781e5bd0480ada29681ebbecc2447b5aded47"
+
+
+def test_example_positions_golden():
+    gold = json.load(open(os.path.join(GOLDEN, "example_positions.json")))
+    for k, vals in gold.items():
+        assert np.array_equal(scenes.example_positions(int(k)).reshape(-1), np.array(vals, dtype=f32))
+    # frame 1 by hand: 0.3 + 0.015, -0.3 + 0.01, -0.5 + 0.005, -0.1 + 0.02 in f32
+    p = scenes.example_positions(1).reshape(-1)
+    assert p[0] == f32(f32(0.3) + f32(0.015)) and p[3] == f32(f32(-0.1) + f32(0.02))
+
+
+def test_viewport_letterbox():
+    from renderer_amd.viewport import Viewport
+    v = Viewport(1., 1., 1920., 1080.)
+    assert (v.width, v.height, v.margin_x, v.margin_y) == (1080.0, 1080.0, 420.0, 0.0)
+    v = Viewport(16., 9., 1000., 1000.)
+    assert v.width == 1000.0 and v.margin_x == 0.0 and abs(v.height - 562.5) < 1e-3 and abs(v.margin_y - 218.75) < 1e-3
+
+
+def test_oracle_frames_golden(oracle):
+    gold = json.load(open(os.path.join(GOLDEN, "oracle_frames.json")))
+    for k in ("1", "60"):
+        o = scenes.draw_oracle(scenes.example_scene(int(k), record=True), threads=2)
+        assert sha(o["color"].tobytes()) == gold[k]["screen_bgra_sha256"]
+        assert sha(o["recording"].tobytes()) == gold[k]["recording_rgba_sha256"]
+        assert o["fragments"] == gold[k]["fragments"] == 2 * 108 * 108
+
+
+# ---- rasterisation rules --------------------------------------------------------------------------------------------------
+def flat_texture(rgba):
+    return np.tile(np.array(rgba, dtype=np.uint8), (4, 4, 1))
+
+
+def px_quad_scene(x0, y0, x1, y1, W=32, H=32, blend="additive", rgba=(10, 20, 30, 40), n=1, clear=(0., 0., 0., 0.)):
+    """One axis-aligned quad with corners at pixel coordinates (x0, y0)-(x1, y1) (y down), strip order of the example."""
+    def ndc(x, y):
+        return [x / W * 2 - 1, 1 - y / H * 2]
+    pos = np.array([ndc(x0, y1), ndc(x0, y0), ndc(x1, y1), ndc(x1, y0)], dtype=f32)
+    return dict(shader="hello", width=W, height=H, target="texture", position=pos, uv=scenes.QUAD_UV,
+                instances=np.zeros((n, 2), dtype=f32), texture=flat_texture(rgba), texture_format="rgba_u8",
+                filter="nearest", blend=blend, topology="strip", clear=clear, viewport=None, record=False)
+
+
+def test_top_left_rule_on_pixel_centres(oracle):
+    # edges exactly on pixel centres: left/top centres are inside, right/bottom centres are outside
+    o = scenes.draw_oracle(px_quad_scene(10.5, 5.5, 20.5, 9.5), threads=1)
+    cov = o["color"][..., 3] > 0
+    ys, xs = np.nonzero(cov)
+    assert (xs.min(), xs.max(), ys.min(), ys.max()) == (10, 19, 5, 8)
+    assert cov.sum() == 10 * 4 == o["fragments"]
+
+
+def test_shared_diagonal_covered_exactly_once(oracle):
+    # additive blend of a constant colour: every covered pixel must hold exactly one layer, including the diagonal
+    for (x0, y0, x1, y1) in [(3.0, 3.0, 29.0, 29.0), (2.25, 4.75, 30.5, 17.125), (0.0, 0.0, 32.0, 32.0)]:
+        o = scenes.draw_oracle(px_quad_scene(x0, y0, x1, y1), threads=1)
+        img = o["color"]
+        covered = img[..., 3] > 0
+        assert (img[covered] == np.array([10, 20, 30, 40], dtype=np.uint8)).all()
+        w = int(np.ceil(x1 - 0.5) - np.ceil(x0 - 0.5)); h = int(np.ceil(y1 - 0.5) - np.ceil(y0 - 0.5))
+        assert covered.sum() == w * h == o["fragments"]
+
+
+def test_both_windings_drawn(oracle):
+    s = px_quad_scene(4.0, 4.0, 12.0, 12.0)
+    a = scenes.draw_oracle(s, threads=1)["color"]
+    s["position"] = s["position"][[2, 3, 0, 1]].copy()      # mirrored strip: opposite winding
+    s["uv"] = s["uv"][[2, 3, 0, 1]].copy()
+    b = scenes.draw_oracle(s, threads=1)["color"]
+    assert np.array_equal(a, b) and (a[..., 3] > 0).sum() == 64
+
+
+def test_triangle_list_topology(oracle):
+    s = px_quad_scene(4.0, 4.0, 12.0, 12.0)
+    strip = scenes.draw_oracle(s, threads=1)["color"]
+    s["position"] = s["position"][[0, 1, 2, 1, 3, 2]].copy()
+    s["uv"] = s["uv"][[0, 1, 2, 1, 3, 2]].copy()
+    s["topology"] = "list"
+    assert np.array_equal(scenes.draw_oracle(s, threads=1)["color"], strip)
+
+
+def test_bilinear_texel_centres_and_clamp(oracle):
+    # a 2x2 texture drawn over a 4x4 target: pixel centres sample at u = 1/8, 3/8, 5/8, 7/8 -> unnormalised
+    # -0.25, 0.25, 0.75, 1.25 -> weights 0 (clamped), .25, .75, clamped
+    tex = np.zeros((2, 2, 4), dtype=np.uint8)
+    tex[0, 0] = (0, 0, 0, 255); tex[0, 1] = (200, 0, 0, 255); tex[1, 0] = (0, 100, 0, 255); tex[1, 1] = (200, 100, 0, 255)
+    s = px_quad_scene(0.0, 0.0, 4.0, 4.0, W=4, H=4, blend="additive")
+    s["texture"] = tex; s["filter"] = "linear"
+    img = scenes.draw_oracle(s, threads=1)["color"]
+    assert list(img[0, :, 0]) == [0, 50, 150, 200]          # red ramps left to right
+    assert list(img[:, 0, 1]) == [0, 25, 75, 100]           # green ramps top to bottom
+    s["filter"] = "nearest"
+    img = scenes.draw_oracle(s, threads=1)["color"]
+    assert list(img[0, :, 0]) == [0, 0, 200, 200] and list(img[:, 0, 1]) == [0, 0, 100, 100]
+
+
+def reference_blend(src, dst, mode):
+    """numpy binary32 restatement of out = src*SF + dst*DF, re-quantised: computed on the 0..255 scale."""
+    src = src.astype(f32); a = src[..., 3:4]
+    df = f32(1.0) if mode == "additive" else (f32(1.0) - a)
+    o = (dst.astype(f32) * df).astype(f32)
+    o = (o.astype(np.float64) + (src * f32(255.0)).astype(f32).astype(np.float64))      # fma: one rounding
+    o = np.clip(o.astype(f32), f32(0.0), f32(255.0))
+    return np.rint(o).astype(np.uint8)
+
+
+@pytest.mark.parametrize("mode", ["premultiplied", "additive"])
+def test_blend_against_numpy_formula(oracle, mode):
+    # one flat quad over a 256x256 target pre-filled with every (dst, dst2) byte pair; src sweeps over 8 colours
+    rng = np.random.default_rng(5)
+    W = H = 256
+    dst = np.zeros((H, W, 4), dtype=np.uint8)
+    dst[..., 0] = np.arange(256)[None, :]; dst[..., 1] = np.arange(256)[:, None]
+    dst[..., 2] = rng.integers(0, 256, (H, W)); dst[..., 3] = rng.integers(0, 256, (H, W))
+    for _ in range(8):
+        rgba = tuple(int(v) for v in rng.integers(0, 256, 4))
+        s = px_quad_scene(0.0, 0.0, float(W), float(H), W=W, H=H, blend=mode, rgba=rgba, clear=None)
+        out = scenes.draw_oracle(s, threads=2, initial=dst)["color"]
+        src = (np.array(rgba, dtype=f32) * f32(1.0 / 255.0)).astype(f32)          # sampler output
+        expect = reference_blend(np.broadcast_to(src, dst.shape), dst, mode)
+        assert np.array_equal(out, expect), (rgba, np.argwhere(out != expect)[:3])
+
+
+def test_order_dependence(oracle):
+    s = scenes.random_quads_scene(500, 24, 160, 120, seed=11)
+    a = scenes.draw_oracle(s, threads=1)["color"]
+    s2 = dict(s); s2["instances"] = s["instances"][::-1].copy()
+    b = scenes.draw_oracle(s2, threads=1)["color"]
+    assert not np.array_equal(a, b)                      # alpha blending depends on primitive order
+    # additive without saturation does not (dim the texture so that sums stay below 255)
+    s["blend"] = s2["blend"] = "additive"
+    s["clear"] = s2["clear"] = (0., 0., 0., 0.)
+    s["filter"] = s2["filter"] = "nearest"              # integer-valued sources: per-layer rounding cannot differ
+    s["texture"] = s2["texture"] = (scenes.load_letter_f() // 64).astype(np.uint8)
+    a = scenes.draw_oracle(s, threads=1)["color"]; b = scenes.draw_oracle(s2, threads=1)["color"]
+    assert a.max() < 255 and np.array_equal(a, b)
+
+
+def test_thread_count_invariance(oracle):
+    s = scenes.random_quads_scene(3000, 16, 320, 200, seed=4)
+    a = scenes.draw_oracle(s, threads=1)
+    b = scenes.draw_oracle(s, threads=7)
+    assert np.array_equal(a["color"], b["color"]) and a["fragments"] == b["fragments"]
+
+
+def test_viewport_clip_switch(oracle):
+    # the example's quads poke outside the letterboxed viewport: strict clipping removes those fragments
+    s = scenes.example_scene(600)
+    s["instances"] = np.array([[0.95, 0.0], [-0.95, 0.5]], dtype=f32)
+    strict = scenes.draw_oracle(s, clip_to_viewport=True)
+    loose = scenes.draw_oracle(s, clip_to_viewport=False)
+    assert strict["fragments"] < loose["fragments"] == 2 * 108 * 108
+    img = strict["color"]
+    assert (img[:, :420, :3] == 0).all() and (img[:, 1500:, :3] == 0).all()
+    assert (loose["color"][:, 1500:, :3] != 0).any()
+
+
+def test_load_op_load_keeps_contents(oracle):
+    s = px_quad_scene(8.0, 8.0, 16.0, 16.0, clear=None)
+    init = np.full((32, 32, 4), 7, dtype=np.uint8)
+    out = scenes.draw_oracle(s, threads=1, initial=init)["color"]
+    assert (out[0, 0] == 7).all() and tuple(out[10, 10]) == (17, 27, 37, 47)
+
+
+# ---- LZ4 frame codec ----------------------------------------------------------------------------------------------------------
+def kat_cases():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(GOLDEN, "make_golden.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    return mod.kat_inputs()
+
+
+def test_lz4_restatement_matches_golden_streams(oracle):
+    gold = json.load(open(os.path.join(GOLDEN, "lz4_kat.json")))
+    assert gold["liblz4_version"] == 10903
+    for name, writes in kat_cases().items():
+        g = gold["cases"][name]
+        assert sha(b"".join(writes)) == g["input_sha256"], "generator drifted"
+        s = oracle.Lz4OracleStream()
+        for w in writes:
+            s.write(w)
+        stream = s.finish()
+        assert len(stream) == g["stream_len"] and sha(stream) == g["stream_sha256"], name
+        if "stream_hex" in g:
+            assert stream.hex() == g["stream_hex"]
+        assert stream[:7].hex() == "04224d184040c0"          # magic, FLG, BD, HC
+        dec, consumed, complete = oracle.lz4_decompress_frame(stream, sum(len(w) for w in writes) + 8)
+        assert dec == b"".join(writes) and complete and consumed == len(stream)
+
+
+def test_lz4_small_write_is_stored_block(oracle):
+    s = oracle.Lz4OracleStream(); s.write(b"\x00" * 8); out = s.finish()
+    assert len(out) == 7 + 12 + 4 and out[7:11] == (8 | 0x80000000).to_bytes(4, "little")
+
+
+def test_lz4_restatement_matches_system_liblz4_random(oracle):
+    rng = np.random.default_rng(99)
+    for trial in range(40):
+        a = oracle.Lz4OracleStream(); b = oracle.LibLz4Stream(0)
+        for _ in range(int(rng.integers(1, 6))):
+            n = int(rng.choice([5, 13, 64, 5000, 65536, 65541, 150000]))
+            kind = int(rng.integers(0, 3))
+            if kind == 0:
+                data = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+            elif kind == 1:
+                data = (rng.integers(0, 3, n, dtype=np.uint8) * 100).tobytes()
+            else:
+                data = (rng.integers(0, 256, 4, dtype=np.uint8).tobytes() * (n // 4 + 1))[:n]
+            a.write(data); b.write(data)
+        assert a.finish() == b.finish(), trial
+
+
+def test_lz4_truncated_tail_is_tolerated(oracle):
+    s = oracle.Lz4OracleStream()
+    s.write(b"abcdefgh" * 4000); s.write(b"x" * 70000)
+    stream = s.finish()
+    dec, consumed, complete = oracle.lz4_decompress_frame(stream[:-9], 200000)
+    assert not complete and (b"abcdefgh" * 4000 + b"x" * 70000).startswith(dec) and len(dec) >= 32000

@@ -116,6 +116,13 @@ inline void fetch_texel(const orc_texture& t, int x, int y, uint32_t layer, floa
 }
 
 // Result in [0,1].  Texel values are kept on the 0..255 scale through the lerps and scaled once at the end.
+//
+// Linear filtering, clamp-to-edge, written in the weight-clamp form: with u = s*W - 0.5 the two taps along x are
+// texels ib and min(ib + 1, W - 1) where ib = clamp(floor(u), 0, max(W - 2, 0)), and the weight is
+// a = clamp(u - ib, 0, 1).  Inside the texture this is the textbook (floor(u), frac(u)); beyond the edge texel centres
+// the weight saturates, so the result equals the edge texel exactly -- the same value the Vulkan formulation
+// (both tap indices clamped to the edge) produces.  Rows are combined with lerp(t, b, w) = fma(w, b, fma(-w, t, t)),
+// which returns t at w = 0 and b at w = 1 exactly.
 void sample_2d(const orc_texture& t, float s, float tc, uint32_t layer, float out[4]) {
     const int W = (int)t.width, H = (int)t.height;
     if (layer >= t.layers) layer = t.layers - 1;
@@ -127,19 +134,19 @@ void sample_2d(const orc_texture& t, float s, float tc, uint32_t layer, float ou
         for (int k = 0; k < 4; k++) out[k] = c[k] * INV_255;
         return;
     }
-    float u = fmaf(s, (float)W, -0.5f), v = fmaf(tc, (float)H, -0.5f);
-    float fu = floorf(u), fv = floorf(v);
-    float a = u - fu, b = v - fv;
-    fu = fminf(fmaxf(fu, -1.0f), (float)W); fv = fminf(fmaxf(fv, -1.0f), (float)H);
-    int i0 = clampi((int)fu, 0, W - 1), i1 = clampi((int)fu + 1, 0, W - 1);
-    int j0 = clampi((int)fv, 0, H - 1), j1 = clampi((int)fv + 1, 0, H - 1);
+    const float u = fmaf(s, (float)W, -0.5f), v = fmaf(tc, (float)H, -0.5f);
+    const float ibf = floorf(fminf(fmaxf(u, 0.0f), (float)(W >= 2 ? W - 2 : 0)));
+    const float jbf = floorf(fminf(fmaxf(v, 0.0f), (float)(H >= 2 ? H - 2 : 0)));
+    const float a = fminf(fmaxf(u - ibf, 0.0f), 1.0f), b = fminf(fmaxf(v - jbf, 0.0f), 1.0f);
+    const int ib = (int)ibf, jb = (int)jbf;
+    const int i1 = ib + 1 < W ? ib + 1 : W - 1, j1 = jb + 1 < H ? jb + 1 : H - 1;
     float t00[4], t10[4], t01[4], t11[4];
-    fetch_texel(t, i0, j0, layer, t00); fetch_texel(t, i1, j0, layer, t10);
-    fetch_texel(t, i0, j1, layer, t01); fetch_texel(t, i1, j1, layer, t11);
+    fetch_texel(t, ib, jb, layer, t00); fetch_texel(t, i1, jb, layer, t10);
+    fetch_texel(t, ib, j1, layer, t01); fetch_texel(t, i1, j1, layer, t11);
     for (int k = 0; k < 4; k++) {
         float top = fmaf(a, t10[k] - t00[k], t00[k]);
         float bot = fmaf(a, t11[k] - t01[k], t01[k]);
-        float c = fmaf(b, bot - top, top);
+        float c = fmaf(b, bot, fmaf(-b, top, top));
         out[k] = c * INV_255;
     }
 }
@@ -247,8 +254,9 @@ bool setup_tri(const Shader& sh, Vert a, Vert b, Vert c, const Scissor& sc, Tri&
     auto plane = [&](float f0, float f1, float f2, float& o0, float& ox, float& oy) {
         float d1 = f1 - f0, d2 = f2 - f0;
         o0 = f0;
-        ox = fmaf(d1, e2y, -(d2 * e1y)) * inv;
-        oy = fmaf(d2, e1x, -(d1 * e2x)) * inv;
+        // gradients are stored per 1/256 pixel so that the fragment stage multiplies them by exact fixed-point deltas
+        ox = (fmaf(d1, e2y, -(d2 * e1y)) * inv) * INV_SUBPIXEL;
+        oy = (fmaf(d2, e1x, -(d1 * e2x)) * inv) * INV_SUBPIXEL;
     };
     for (int k = 0; k < sh.n_varyings; k++) {
         if (t.persp) plane(a.var[k] * a.rw, b.var[k] * b.rw, c.var[k] * c.rw, t.v0[k], t.dvdx[k], t.dvdy[k]);
@@ -274,7 +282,8 @@ inline uint8_t to_unorm8(float o) {
 }
 
 // out = src*SF + dst*DF per channel, alpha included (reference src/blend_mode.rs:31-40), destination read back as
-// UNORM8 and the result re-quantised after every fragment.
+// UNORM8 and the result re-quantised after every fragment.  Evaluated on the 0..255 scale:
+//   q = rint(clamp(fma(dst_byte, DF, (src*SF)*255), 0, 255)),  NaN -> 0, ties to even.
 inline void blend_store(const orc_draw& d, const orc_target& tg, size_t pix, const float src[4]) {
     uint8_t* p = tg.data + pix * 4;
     const bool bgra = tg.format == ORC_FMT_BGRA_U8;
@@ -282,8 +291,10 @@ inline void blend_store(const orc_draw& d, const orc_target& tg, size_t pix, con
     uint8_t q[4];
     for (int k = 0; k < 4; k++) {
         int byte = bgra ? (k == 0 ? 2 : (k == 2 ? 0 : k)) : k;
-        float dst = (float)p[byte] * INV_255;
-        q[k] = to_unorm8(fmaf(dst, df, src[k] * sf));
+        float s255 = (src[k] * sf) * 255.0f;
+        float o = fmaf((float)p[byte], df, s255);
+        o = fminf(fmaxf(o, 0.0f), 255.0f);         // NaN -> 0
+        q[k] = (uint8_t)rintf(o);
     }
     if (bgra) { p[0] = q[2]; p[1] = q[1]; p[2] = q[0]; p[3] = q[3]; }
     else { p[0] = q[0]; p[1] = q[1]; p[2] = q[2]; p[3] = q[3]; }
@@ -321,7 +332,7 @@ void shade_tri(const orc_draw& d, const Shader& sh, const Tri& t, int band_y0, i
             for (int e = 0; e < 3; e++)
                 in = in && ((int64_t)t.A[e] * i + (int64_t)t.B[e] * j + t.Cq[e] >= 0);
             if (!in) continue;
-            float dx = (float)(i * 256 - t.X0) * INV_SUBPIXEL, dy = (float)(j * 256 - t.Y0) * INV_SUBPIXEL;
+            float dx = (float)(i * 256 - t.X0), dy = (float)(j * 256 - t.Y0);     // exact: |delta| < 2^24
             float var[MAX_VARYINGS];
             for (int k = 0; k < sh.n_varyings; k++) var[k] = fmaf(t.dvdy[k], dy, fmaf(t.dvdx[k], dx, t.v0[k]));
             if (t.persp) {

@@ -26,21 +26,31 @@ enum : uint32_t { FILTER_LINEAR = 0, FILTER_NEAREST = 1 };
 
 struct Sampler { uint32_t filter; };
 
+typedef float v2f __attribute__((ext_vector_type(2)));                       // maps to packed f32 VALU instructions
+typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));   // two adjacent texels, 4-byte aligned
+
+RH_DEVICE v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+
 struct Texture2D {
     const uint8_t* data; uint32_t width, height, layers, format;
 
-    // Texel (x, y) of `layer`, channels on the 0..255 scale.
+    // Texel (x, y) of `layer`, channels on the 0..255 scale (generic path, any supported format).
     RH_DEVICE float4 fetch(int x, int y, uint32_t layer) const {
-        size_t idx = ((size_t)layer * height + (size_t)y) * width + (size_t)x;
+        const uint32_t idx = (layer * height + (uint32_t)y) * width + (uint32_t)x;
         if (format == FORMAT_R_U8) return make_float4((float)data[idx], 0.0f, 0.0f, 255.0f);
-        uint32_t t = reinterpret_cast<const uint32_t*>(data)[idx];
-        float c0 = (float)(t & 0xffu), c1 = (float)((t >> 8) & 0xffu), c2 = (float)((t >> 16) & 0xffu), c3 = (float)(t >> 24);
+        const uint32_t t = *reinterpret_cast<const uint32_t*>(data + (idx << 2));
+        const float c0 = (float)(t & 0xffu), c1 = (float)((t >> 8) & 0xffu), c2 = (float)((t >> 16) & 0xffu), c3 = (float)(t >> 24);
         if (format == FORMAT_BGRA_U8) return make_float4(c2, c1, c0, c3);
         return make_float4(c0, c1, c2, c3);
     }
 
     // texture(sampler2D(t, s), uv): clamp-to-edge, one mip level, unnormalised coordinate = uv * size
-    // (the only sampler the reference creates: src/texture.rs:141-158).
+    // (the only sampler the reference creates: src/texture.rs:141-158).  Textures are limited to 4 GiB so that texel
+    // byte offsets fit 32 bits.
+    //
+    // Linear filtering in the weight-clamp form: taps ib and min(ib + 1, W - 1) with ib = clamp(floor(u), 0, W - 2)
+    // and weight clamp(u - ib, 0, 1), u = s*W - 0.5; beyond the edge texel centres the weight saturates and the result
+    // is the edge texel exactly.  Rows are combined with lerp(t, b, w) = fma(w, b, fma(-w, t, t)).
     RH_DEVICE float4 sample(Sampler s, float2 uv, uint32_t layer = 0) const {
         const int W = (int)width, H = (int)height;
         if (layer >= layers) layer = layers - 1;
@@ -51,19 +61,36 @@ struct Texture2D {
             float4 c = fetch(i, j, layer);
             return make_float4(c.x * INV_255, c.y * INV_255, c.z * INV_255, c.w * INV_255);
         }
-        float u = __builtin_fmaf(uv.x, (float)W, -0.5f), v = __builtin_fmaf(uv.y, (float)H, -0.5f);
-        float fu = floorf(u), fv = floorf(v);
-        float a = u - fu, b = v - fv;
-        fu = fminf(fmaxf(fu, -1.0f), (float)W); fv = fminf(fmaxf(fv, -1.0f), (float)H);
-        int i0 = min(max((int)fu, 0), W - 1), i1 = min(max((int)fu + 1, 0), W - 1);
-        int j0 = min(max((int)fv, 0), H - 1), j1 = min(max((int)fv + 1, 0), H - 1);
-        float4 t00 = fetch(i0, j0, layer), t10 = fetch(i1, j0, layer), t01 = fetch(i0, j1, layer), t11 = fetch(i1, j1, layer);
+        const float u = __builtin_fmaf(uv.x, (float)W, -0.5f), v = __builtin_fmaf(uv.y, (float)H, -0.5f);
+        const float ibf = floorf(fminf(fmaxf(u, 0.0f), (float)(W >= 2 ? W - 2 : 0)));
+        const float jbf = floorf(fminf(fmaxf(v, 0.0f), (float)(H >= 2 ? H - 2 : 0)));
+        const float a = fminf(fmaxf(u - ibf, 0.0f), 1.0f), b = fminf(fmaxf(v - jbf, 0.0f), 1.0f);
+        const int ib = (int)ibf, jb = (int)jbf;
+        float4 t00, t10, t01, t11;
+        if (format != FORMAT_R_U8 && W >= 2 && H >= 2) {
+            // 4-byte texels: the taps of a row are adjacent and the rows are one pitch apart: two 8-byte loads
+            const uint32_t off = (__umul24(layer * height + (uint32_t)jb, width) + (uint32_t)ib) << 2;
+            const u32x2_a4 r0 = *reinterpret_cast<const u32x2_a4*>(data + off);
+            const u32x2_a4 r1 = *reinterpret_cast<const u32x2_a4*>(data + (width << 2) + off);
+#define RH_UNPACK(t) make_float4((float)((t) & 0xffu), (float)(((t) >> 8) & 0xffu), (float)(((t) >> 16) & 0xffu), (float)((t) >> 24))
+            t00 = RH_UNPACK(r0.x); t10 = RH_UNPACK(r0.y); t01 = RH_UNPACK(r1.x); t11 = RH_UNPACK(r1.y);
+#undef RH_UNPACK
+        } else {
+            const int i1 = min(ib + 1, W - 1), j1 = min(jb + 1, H - 1);
+            t00 = fetch(ib, jb, layer); t10 = fetch(i1, jb, layer); t01 = fetch(ib, j1, layer); t11 = fetch(i1, j1, layer);
+            if (format == FORMAT_BGRA_U8) {       // fetch() already swizzled: undo so that the common swizzle below applies
+                float x;
+                x = t00.x; t00.x = t00.z; t00.z = x; x = t10.x; t10.x = t10.z; t10.z = x;
+                x = t01.x; t01.x = t01.z; t01.z = x; x = t11.x; t11.x = t11.z; t11.z = x;
+            }
+        }
         float4 r;
-#define RH_LERP2(ch) { float top = __builtin_fmaf(a, t10.ch - t00.ch, t00.ch); \
-                       float bot = __builtin_fmaf(a, t11.ch - t01.ch, t01.ch); \
-                       r.ch = __builtin_fmaf(b, bot - top, top) * INV_255; }
+#define RH_LERP2(ch) { const float top = __builtin_fmaf(a, t10.ch - t00.ch, t00.ch); \
+                       const float bot = __builtin_fmaf(a, t11.ch - t01.ch, t01.ch); \
+                       r.ch = __builtin_fmaf(b, bot, __builtin_fmaf(-b, top, top)) * INV_255; }
         RH_LERP2(x) RH_LERP2(y) RH_LERP2(z) RH_LERP2(w)
 #undef RH_LERP2
+        if (format == FORMAT_BGRA_U8) return make_float4(r.z, r.y, r.x, r.w);
         return r;
     }
 };

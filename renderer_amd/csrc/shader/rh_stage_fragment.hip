@@ -1,17 +1,27 @@
 // Fragment-stage code object: compiled once per (vertex source, fragment source) pair with
 //     hipcc --genco --offload-arch=gfx950 -ffp-contract=off -DRH_VERTEX_SOURCE=... -DRH_FRAGMENT_SOURCE=... rh_stage_fragment.hip
-// Exports rh_tile_<A> (A = 1..4 colour attachments): one workgroup per 32x32 screen tile.
+// Exports rh_tile_<A> (A = 1..4 colour attachments): one workgroup per 32x32 screen tile, one wavefront per 16x16
+// region of it.
 //
 // Per tile:
 //   1. the tile's pixels are brought into LDS (cleared, or loaded with coalesced row reads), one u32 RGBA8 per pixel,
-//      stored block-linear (8x8 blocks, padded so that both block-wise and row-wise accesses are conflict-free);
-//   2. the tile's ordered cluster list is walked in batches of RH_BATCH_TRIS triangles: threads set triangles up
-//      (vertex function, snap, integer edge equations with the top-left rule folded into the constant, varying
-//      plane equations) into LDS records; then every wave walks its four 8x8 blocks: lanes test one triangle each
-//      against the block (ballot), the set bits are visited in ascending order -- which is primitive order -- and
-//      every lane (= pixel) evaluates coverage, shades, and blends into its register-held pixel, re-quantising to
-//      UNORM8 after every fragment;
+//      region by region;
+//   2. the tile's ordered cluster list is walked in batches of RH_BATCH_CLUSTERS clusters (a cluster = two consecutive
+//      triangles of one instance, i.e. one quad of a 4-vertex strip).  Threads set clusters up (vertex function, snap,
+//      edge equations with the top-left rule folded into the constant, varying plane equations) into LDS records.
+//      Then every wave walks the batch for its own region: lanes test one cluster each against the region (ballot);
+//      the set bits are visited in ascending order -- which is primitive order.  For every hit the pixels of
+//      (cluster bounding box intersected with the region) are packed linearly onto the lanes, 64 per pass, so small
+//      primitives keep most lanes busy.  A lane evaluates the coverage of both triangles, shades once with the plane
+//      equations of the triangle that covers its pixel, and blends into the LDS pixel (read, blend, re-quantise to
+//      UNORM8, write).  If any pixel of a pass is covered by both triangles of the cluster (overlapping / bow-tie
+//      geometry) the two triangles are shaded one after the other instead.  A region belongs to exactly one wave and
+//      a wave's LDS operations complete in order, so every pixel sees its fragments in primitive order;
 //   3. the tile is written back with coalesced row stores (RGBA or BGRA).
+//
+// Cost model this is written against (measured on MI355X): f32 add/mul/fma issue in 2 cycles per wave64, every other
+// VALU instruction (integer, logic, conversion, packed f32) in about 4.  Hence coverage is evaluated in f32 where that
+// is exact, and integer work per fragment is kept to the byte unpacks and the final pack.
 #include "rh_shader.h"
 #include RH_VERTEX_SOURCE
 #include RH_FRAGMENT_SOURCE
@@ -29,22 +39,26 @@ extern "C" __device__ const rh_module_info_t rh_module_info = {
 namespace rh {
 
 constexpr int NV = N_VARYINGS;
-constexpr int BLOCKS_PER_TILE = (RH_TILE / RH_BLOCK) * (RH_TILE / RH_BLOCK);   // 16
-constexpr int BLOCK_STRIDE = 72;          // 64 pixels + 8 dwords of padding
-constexpr uint32_t BBOX_EMPTY = 0x000000ffu;   // x0 = 255 > x1 = 0
-constexpr uint32_t FLAG_PERSP = 1u;
+constexpr int REGION = 16;                      // a wave owns a 16x16 pixel region of the tile
+constexpr int REGION_STRIDE = REGION * REGION + 16;   // dwords; the padding keeps row-wise tile accesses conflict-free
+constexpr uint32_t BBOX_EMPTY = 0x000000ffu;    // x0 = 255 > x1 = 0
+constexpr uint32_t FLAG_PERSP_A = 1u, FLAG_PERSP_B = 2u, FLAG_HAS_A = 4u, FLAG_HAS_B = 8u, FLAG_BIG = 16u;
+// Edge coefficients below this magnitude (1024 px) make f32 edge evaluation exact; see edges_inside_f32.
+constexpr int32_t F32_EDGE_LIMIT = 1 << 18;
 
-struct alignas(16) TriRecord {
-    int32_t A0, B0, T0, A1;
-    int32_t B1, T1, A2, B2;
-    int32_t T2, X0t, Y0t; uint32_t flags;
-    float q0, dqdx, dqdy, pad0;
-    float v0[NV], dvdx[NV], dvdy[NV];
+// One triangle of a cluster, relative to the tile origin.  Edge e: inside <=> A*lx + B*ly + T >= 0 at tile-relative
+// pixel (lx, ly), top-left rule folded into T.  The same 9 slots hold f32 values (normal case) or i32 values (FLAG_BIG).
+struct TriData {
+    float A[3], B[3], T[3];
+    float XR, YR;                  // reference vertex in 24.8 fixed point relative to the tile origin, as f32 (exact)
+    float v0[NV], dvdx[NV], dvdy[NV];   // gradients per 1/256 pixel
+    float q0, qx, qy;              // 1/w plane (read only when the triangle is perspective)
 };
 
-RH_DEVICE int lds_pixel_index(int lx, int ly) {
-    return ((ly >> 3) * (RH_TILE / RH_BLOCK) + (lx >> 3)) * BLOCK_STRIDE + (ly & 7) * 8 + (lx & 7);
-}
+struct alignas(16) ClusterRecord {
+    TriData t[2];
+    uint32_t flags;
+};
 
 RH_DEVICE uint32_t swap_rb(uint32_t v) { return (v & 0xff00ff00u) | ((v & 0xffu) << 16) | ((v >> 16) & 0xffu); }
 
@@ -52,90 +66,147 @@ RH_DEVICE float blend_factor(uint32_t f, float src_alpha) {
     return f == 0u ? 0.0f : (f == 1u ? 1.0f : (f == 2u ? src_alpha : 1.0f - src_alpha));
 }
 
-RH_DEVICE uint32_t to_unorm8(float o) {
-    o = fminf(fmaxf(o, 0.0f), 1.0f);
-    return (uint32_t)rintf(o * 255.0f);
-}
-
-// out = src*SF + dst*DF for every channel, alpha included; the destination is the stored UNORM8 value and the result
-// is re-quantised (round half to even) after every fragment.
+// out = src*SF + dst*DF for every channel, alpha included; evaluated on the 0..255 scale:
+//   q = rint(clamp(fma(dst_byte, DF, (src*SF)*255), 0, 255)), NaN -> 0, ties to even
+// v_cvt_pk_u8_f32 performs exactly that clamp + round + byte insert.
 RH_DEVICE uint32_t blend(uint32_t dst, float4 s, uint32_t src_factor, uint32_t dst_factor) {
-    const float sf = blend_factor(src_factor, s.w), df = blend_factor(dst_factor, s.w);
-    float d0 = (float)(dst & 0xffu) * INV_255, d1 = (float)((dst >> 8) & 0xffu) * INV_255;
-    float d2 = (float)((dst >> 16) & 0xffu) * INV_255, d3 = (float)(dst >> 24) * INV_255;
-    uint32_t q0 = to_unorm8(__builtin_fmaf(d0, df, s.x * sf));
-    uint32_t q1 = to_unorm8(__builtin_fmaf(d1, df, s.y * sf));
-    uint32_t q2 = to_unorm8(__builtin_fmaf(d2, df, s.z * sf));
-    uint32_t q3 = to_unorm8(__builtin_fmaf(d3, df, s.w * sf));
-    return q0 | (q1 << 8) | (q2 << 16) | (q3 << 24);
+    const float df = blend_factor(dst_factor, s.w);
+    if (src_factor != 1u) { const float sf = blend_factor(src_factor, s.w); s.x *= sf; s.y *= sf; s.z *= sf; s.w *= sf; }
+    const float o0 = __builtin_fmaf((float)(dst & 0xffu), df, s.x * 255.0f);
+    const float o1 = __builtin_fmaf((float)((dst >> 8) & 0xffu), df, s.y * 255.0f);
+    const float o2 = __builtin_fmaf((float)((dst >> 16) & 0xffu), df, s.z * 255.0f);
+    const float o3 = __builtin_fmaf((float)(dst >> 24), df, s.w * 255.0f);
+    uint32_t q = 0;
+    q = __builtin_amdgcn_cvt_pk_u8_f32(o0, 0, q);
+    q = __builtin_amdgcn_cvt_pk_u8_f32(o1, 1, q);
+    q = __builtin_amdgcn_cvt_pk_u8_f32(o2, 2, q);
+    q = __builtin_amdgcn_cvt_pk_u8_f32(o3, 3, q);
+    return q;
 }
 
-RH_DEVICE int32_t clamp_i64_to_i31(int64_t v) {
-    const int64_t lim = (int64_t)1 << 30;
-    return (int32_t)(v < -lim ? -lim : (v > lim - 1 ? lim - 1 : v));
-}
+RH_DEVICE int64_t clamp_i64(int64_t v, int64_t lim) { return v < -lim ? -lim : (v > lim ? lim : v); }
 
-// Triangle setup for tile (ox, oy).  Returns the packed tile-relative bbox, or BBOX_EMPTY when the triangle
-// contributes nothing to this tile.
-RH_DEVICE uint32_t setup_triangle(const rh_draw_params& p, uint32_t cluster, uint32_t which, int ox, int oy, TriRecord& r) {
-    const uint32_t instance = cluster / p.cpi, local = cluster - instance * p.cpi;
-    const uint32_t tri = local * 2 + which;
-    if (tri >= p.tpi) return BBOX_EMPTY;
-    uint32_t idx[3]; tri_vertices(p.topology, tri, idx);
-    SnappedVertex a = run_vertex(p, idx[0], instance);
-    SnappedVertex b = run_vertex(p, idx[1], instance);
-    SnappedVertex c = run_vertex(p, idx[2], instance);
+// Triangle setup relative to tile origin (ox, oy).  Returns false when the triangle contributes nothing to this tile;
+// otherwise fills `t` and grows the tile-relative bbox.  `big` is set when an edge coefficient is too large for the
+// f32 coverage path.
+RH_DEVICE bool setup_triangle(const rh_draw_params& p, SnappedVertex a, SnappedVertex b, SnappedVertex c, int ox, int oy,
+                              TriData& t, int32_t ei[9], bool& persp, bool& big, int& bx0, int& by0, int& bx1, int& by1) {
     int x0, y0, x1, y1;
-    if (!tri_pixel_bbox(p, a, b, c, x0, y0, x1, y1)) return BBOX_EMPTY;
+    if (!tri_pixel_bbox(p, a, b, c, x0, y0, x1, y1)) return false;
     x0 = max(x0, ox); y0 = max(y0, oy); x1 = min(x1, ox + RH_TILE - 1); y1 = min(y1, oy + RH_TILE - 1);
-    if (x0 > x1 || y0 > y1) return BBOX_EMPTY;
+    if (x0 > x1 || y0 > y1) return false;
     const int64_t area2 = (int64_t)(b.X - a.X) * (c.Y - a.Y) - (int64_t)(c.X - a.X) * (b.Y - a.Y);
-    if (area2 == 0) return BBOX_EMPTY;
-    if (area2 < 0) { SnappedVertex t = b; b = c; c = t; }      // no culling: both windings are drawn
-    // Edge e from P to Q: inside <=> A*i + B*j + Cq >= 0 at pixel (i, j), with the top-left rule folded into Cq.
-    // Stored relative to the tile origin and saturated: |A*lx + B*ly| < 2^29 for lx, ly < 32, so the sign survives.
-#define RH_EDGE(P, Q, AA, BB, TT) { \
+    if (area2 == 0) return false;
+    if (area2 < 0) { SnappedVertex s = b; b = c; c = s; }      // no culling: both windings are drawn
+    // T is relative to the tile origin and saturated at +-2^30: |A*lx + B*ly| < 2^29 for lx, ly < 32 keeps the sign.
+#define RH_EDGE(P, Q, K) { \
         const int32_t A_ = P.Y - Q.Y, B_ = Q.X - P.X; \
         const int64_t C_ = -((int64_t)A_ * P.X + (int64_t)B_ * P.Y); \
         const bool tl_ = (A_ > 0) || (A_ == 0 && B_ > 0); \
         const int64_t Cq_ = (C_ + (tl_ ? 0 : -1)) >> RH_SUBPIXEL_BITS; \
-        AA = A_; BB = B_; TT = clamp_i64_to_i31(Cq_ + (int64_t)A_ * ox + (int64_t)B_ * oy); }
-    RH_EDGE(a, b, r.A0, r.B0, r.T0)
-    RH_EDGE(b, c, r.A1, r.B1, r.T1)
-    RH_EDGE(c, a, r.A2, r.B2, r.T2)
+        ei[K] = A_; ei[3 + K] = B_; ei[6 + K] = (int32_t)clamp_i64(Cq_ + (int64_t)A_ * ox + (int64_t)B_ * oy, (int64_t)1 << 30); \
+        if (A_ >= F32_EDGE_LIMIT || A_ <= -F32_EDGE_LIMIT || B_ >= F32_EDGE_LIMIT || B_ <= -F32_EDGE_LIMIT) big = true; }
+    RH_EDGE(a, b, 0)
+    RH_EDGE(b, c, 1)
+    RH_EDGE(c, a, 2)
 #undef RH_EDGE
-    r.X0t = a.X - ox * 256; r.Y0t = a.Y - oy * 256;
+    t.XR = (float)(a.X - ox * 256); t.YR = (float)(a.Y - oy * 256);
     const float k = 1.0f / 256.0f;
     const float e1x = (float)(b.X - a.X) * k, e1y = (float)(b.Y - a.Y) * k;
     const float e2x = (float)(c.X - a.X) * k, e2y = (float)(c.Y - a.Y) * k;
     const float area = __builtin_fmaf(e1x, e2y, -(e2x * e1y));
     const float inv = 1.0f / area;
-    const bool persp = !(a.rw == 1.0f && b.rw == 1.0f && c.rw == 1.0f);
-    r.flags = persp ? FLAG_PERSP : 0u;
+    persp = !(a.rw == 1.0f && b.rw == 1.0f && c.rw == 1.0f);
     const float* fa = reinterpret_cast<const float*>(&a.var);
     const float* fb = reinterpret_cast<const float*>(&b.var);
     const float* fc = reinterpret_cast<const float*>(&c.var);
 #define RH_PLANE(F0, F1, F2, O0, OX, OY) { \
         const float f0_ = (F0), d1_ = (F1) - f0_, d2_ = (F2) - f0_; \
         O0 = f0_; \
-        OX = __builtin_fmaf(d1_, e2y, -(d2_ * e1y)) * inv; \
-        OY = __builtin_fmaf(d2_, e1x, -(d1_ * e2x)) * inv; }
+        OX = (__builtin_fmaf(d1_, e2y, -(d2_ * e1y)) * inv) * k; \
+        OY = (__builtin_fmaf(d2_, e1x, -(d1_ * e2x)) * inv) * k; }
 #pragma unroll
     for (int v = 0; v < NV; v++) {
-        if (persp) RH_PLANE(fa[v] * a.rw, fb[v] * b.rw, fc[v] * c.rw, r.v0[v], r.dvdx[v], r.dvdy[v])
-        else RH_PLANE(fa[v], fb[v], fc[v], r.v0[v], r.dvdx[v], r.dvdy[v])
+        if (persp) RH_PLANE(fa[v] * a.rw, fb[v] * b.rw, fc[v] * c.rw, t.v0[v], t.dvdx[v], t.dvdy[v])
+        else RH_PLANE(fa[v], fb[v], fc[v], t.v0[v], t.dvdx[v], t.dvdy[v])
     }
-    RH_PLANE(a.rw, b.rw, c.rw, r.q0, r.dqdx, r.dqdy)
+    RH_PLANE(a.rw, b.rw, c.rw, t.q0, t.qx, t.qy)
 #undef RH_PLANE
-    r.pad0 = 0.0f;
-    return (uint32_t)(x0 - ox) | ((uint32_t)(y0 - oy) << 8) | ((uint32_t)(x1 - ox) << 16) | ((uint32_t)(y1 - oy) << 24);
+    bx0 = min(bx0, x0 - ox); by0 = min(by0, y0 - oy); bx1 = max(bx1, x1 - ox); by1 = max(by1, y1 - oy);
+    return true;
+}
+
+// Stores the 9 edge values of a triangle: as f32 (T saturated at +-2^24) or, for a BIG cluster, as raw i32 bits.
+RH_DEVICE void store_edges(TriData& t, const int32_t ei[9], bool big) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        if (big) { t.A[k] = __int_as_float(ei[k]); t.B[k] = __int_as_float(ei[3 + k]); t.T[k] = __int_as_float(ei[6 + k]); }
+        else {
+            const int32_t lim = 1 << 24;
+            const int32_t T = ei[6 + k] < -lim ? -lim : (ei[6 + k] > lim ? lim : ei[6 + k]);
+            t.A[k] = (float)ei[k]; t.B[k] = (float)ei[3 + k]; t.T[k] = (float)T;
+        }
+    }
+}
+
+// Sets up both triangles of `cluster`; returns the packed tile-relative bbox of their union (BBOX_EMPTY if neither
+// triangle touches the tile).
+RH_DEVICE uint32_t setup_cluster(const rh_draw_params& p, uint32_t cluster, int ox, int oy, ClusterRecord& r) {
+    const uint32_t instance = cluster / p.cpi, local = cluster - instance * p.cpi;
+    const uint32_t tri0 = local * 2;
+    const bool has_second = tri0 + 1 < p.tpi;
+    // Strip: triangle A = (v0, v1, v2), triangle B = (v1, v3, v2) with v_i = vertex tri0 + i (4 vertex runs).
+    // List:  triangle A = (v0, v1, v2), triangle B = (v3, v4, v5) with v_i = vertex 3*tri0 + i.
+    const bool strip = p.topology == 1u;
+    const uint32_t first = strip ? tri0 : 3 * tri0;
+    const SnappedVertex v0 = run_vertex(p, first, instance);
+    const SnappedVertex v1 = run_vertex(p, first + 1, instance);
+    const SnappedVertex v2 = run_vertex(p, first + 2, instance);
+    int bx0 = 255, by0 = 255, bx1 = -1, by1 = -1;
+    bool persp_a = false, persp_b = false, big = false;
+    int32_t ea[9], eb[9];
+    const bool has_a = setup_triangle(p, v0, v1, v2, ox, oy, r.t[0], ea, persp_a, big, bx0, by0, bx1, by1);
+    bool has_b = false;
+    if (has_second) {
+        const SnappedVertex v3 = run_vertex(p, first + 3, instance);
+        if (strip) has_b = setup_triangle(p, v1, v3, v2, ox, oy, r.t[1], eb, persp_b, big, bx0, by0, bx1, by1);
+        else {
+            const SnappedVertex v4 = run_vertex(p, first + 4, instance);
+            const SnappedVertex v5 = run_vertex(p, first + 5, instance);
+            has_b = setup_triangle(p, v3, v4, v5, ox, oy, r.t[1], eb, persp_b, big, bx0, by0, bx1, by1);
+        }
+    }
+    if (has_a) store_edges(r.t[0], ea, big);
+    if (has_b) store_edges(r.t[1], eb, big);
+    r.flags = (has_a ? FLAG_HAS_A : 0u) | (has_b ? FLAG_HAS_B : 0u) | (persp_a ? FLAG_PERSP_A : 0u) | (persp_b ? FLAG_PERSP_B : 0u) |
+              (big ? FLAG_BIG : 0u);
+    if (!has_a && !has_b) return BBOX_EMPTY;
+    return (uint32_t)bx0 | ((uint32_t)by0 << 8) | ((uint32_t)bx1 << 16) | ((uint32_t)by1 << 24);
+}
+
+// f32 coverage: with |A|, |B| < 2^18 and lx, ly < 32 every product is an exactly representable integer below 2^23, T is
+// an exactly representable integer in [-2^24, 2^24], and |A*lx + B*ly| < 2^24.  Whenever the true edge value
+// A*lx + B*ly + T is within a few units of zero every partial sum is below 2^24 and therefore exact, so the sign test
+// agrees with integer arithmetic; when T is saturated the sign is that of T.
+RH_DEVICE bool edges_inside_f32(const TriData& t, float lxf, float lyf) {
+    const float s0 = __builtin_fmaf(t.A[0], lxf, __builtin_fmaf(t.B[0], lyf, t.T[0]));
+    const float s1 = __builtin_fmaf(t.A[1], lxf, __builtin_fmaf(t.B[1], lyf, t.T[1]));
+    const float s2 = __builtin_fmaf(t.A[2], lxf, __builtin_fmaf(t.B[2], lyf, t.T[2]));
+    return ((__float_as_int(s0) | __float_as_int(s1) | __float_as_int(s2)) >= 0);     // no sign bit set (a zero sum is +0)
+}
+
+RH_DEVICE bool edges_inside_i32(const TriData& t, int lx, int ly) {
+    const int s0 = __mul24(__float_as_int(t.A[0]), lx) + __mul24(__float_as_int(t.B[0]), ly) + __float_as_int(t.T[0]);
+    const int s1 = __mul24(__float_as_int(t.A[1]), lx) + __mul24(__float_as_int(t.B[1]), ly) + __float_as_int(t.T[1]);
+    const int s2 = __mul24(__float_as_int(t.A[2]), lx) + __mul24(__float_as_int(t.B[2]), ly) + __float_as_int(t.T[2]);
+    return (s0 | s1 | s2) >= 0;
 }
 
 template <int NA>
 RH_DEVICE void tile_kernel(const rh_tile_args& a) {
-    __shared__ TriRecord rec[RH_BATCH_TRIS];
-    __shared__ uint32_t rec_bbox[RH_BATCH_TRIS];
-    __shared__ uint32_t tile_px[NA][BLOCKS_PER_TILE * BLOCK_STRIDE];
+    __shared__ ClusterRecord rec[RH_BATCH_CLUSTERS];
+    __shared__ uint32_t rec_bbox[RH_BATCH_CLUSTERS];
+    __shared__ uint32_t tile_px[NA][4 * REGION_STRIDE];
 
     const rh_draw_params& p = a.p;
     const int tid = (int)threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -159,69 +230,96 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a) {
                     if (at.format == FORMAT_BGRA_U8) v = swap_rb(v);
                 }
             }
-            tile_px[t][lds_pixel_index(lx, ly)] = v;
+            tile_px[t][((ly >> 4) * 2 + (lx >> 4)) * REGION_STRIDE + (ly & 15) * REGION + (lx & 15)] = v;
         }
     }
 
     FragmentContext fctx; fctx.p = &p;
 
-    // 2. batches of RH_BATCH_TRIS triangles = RH_BATCH_TRIS / 2 clusters
-    for (uint32_t base = start; base < end; base += RH_BATCH_TRIS / 2) {
+    // this wave's region, tile-relative, intersected with the scissor
+    const int rx0 = (wave & 1) * REGION, ry0 = (wave >> 1) * REGION;
+    const int sx0 = max(rx0, p.sc_x0 - ox), sy0 = max(ry0, p.sc_y0 - oy);
+    const int sx1 = min(rx0 + REGION - 1, p.sc_x1 - 1 - ox), sy1 = min(ry0 + REGION - 1, p.sc_y1 - 1 - oy);
+    const bool region_live = sx0 <= sx1 && sy0 <= sy1;
+    uint32_t* const region_px = &tile_px[0][wave * REGION_STRIDE];
+    const float lane_f = (float)lane;
+
+    // 2. batches of clusters
+    for (uint32_t base = start; base < end; base += RH_BATCH_CLUSTERS) {
         __syncthreads();                                          // tile loaded / previous batch fully consumed
-        if (tid < RH_BATCH_TRIS) {
-            const uint32_t ci = base + (uint32_t)(tid >> 1);
+        if (tid < RH_BATCH_CLUSTERS) {
+            const uint32_t ci = base + (uint32_t)tid;
             uint32_t bb = BBOX_EMPTY;
-            if (ci < end) bb = setup_triangle(p, a.list[ci], (uint32_t)(tid & 1), ox, oy, rec[tid]);
+            if (ci < end) bb = setup_cluster(p, a.list[ci], ox, oy, rec[tid]);
             rec_bbox[tid] = bb;
         }
         __syncthreads();
+        if (!region_live) continue;
 
-        for (int b = 0; b < 4; b++) {
-            const int bx = (wave & 1) * 2 + (b & 1), by = (wave >> 1) * 2 + (b >> 1);
-            const int lx = bx * RH_BLOCK + (lane & 7), ly = by * RH_BLOCK + (lane >> 3);
-            const int gx = ox + lx, gy = oy + ly;
-            const bool in_scissor = gx >= p.sc_x0 && gx < p.sc_x1 && gy >= p.sc_y0 && gy < p.sc_y1;
-            const int pidx = (by * (RH_TILE / RH_BLOCK) + bx) * BLOCK_STRIDE + lane;
-            uint32_t pix[NA];
+        for (int round = 0; round < RH_BATCH_CLUSTERS / 64; round++) {
+            const uint32_t bb = rec_bbox[round * 64 + lane];
+            const int cx0 = (int)(bb & 0xffu), cy0 = (int)((bb >> 8) & 0xffu), cx1 = (int)((bb >> 16) & 0xffu), cy1 = (int)(bb >> 24);
+            const bool hit = cx0 <= sx1 && cx1 >= sx0 && cy0 <= sy1 && cy1 >= sy0;
+            unsigned long long mask = __ballot(hit);
+            while (mask) {
+                const int tl = __builtin_ctzll(mask);
+                mask &= mask - 1;
+                const int ci = round * 64 + tl;
+                const ClusterRecord& r = rec[ci];
+                const uint32_t flags = r.flags;
+                // pixels of (cluster bbox intersected with the region), packed linearly: idx -> (idx % w, idx / w)
+                const uint32_t hb = rec_bbox[ci];
+                const int hx0 = max((int)(hb & 0xffu), sx0), hy0 = max((int)((hb >> 8) & 0xffu), sy0);
+                const int hx1 = min((int)((hb >> 16) & 0xffu), sx1), hy1 = min((int)(hb >> 24), sy1);
+                const int w = hx1 - hx0 + 1, npx = w * (hy1 - hy0 + 1);
+                const float wf = (float)w, invw = __builtin_amdgcn_rcpf(wf);
+                const float hx0f = (float)hx0, hy0f = (float)hy0;
+                for (int first = 0; first < npx; first += 64) {
+                    const float idx_f = lane_f + (float)first;
+                    // floor((idx + 0.5) / w): the half keeps the quotient at least 1/32 away from an integer
+                    const float row_f = floorf(__builtin_fmaf(idx_f, invw, 0.5f * invw));
+                    const float col_f = __builtin_fmaf(-row_f, wf, idx_f);
+                    const float lxf = hx0f + col_f, lyf = hy0f + row_f;          // tile-relative pixel, exact small integers
+                    const bool live = first + lane < npx;
+                    // region-relative LDS index of the pixel
+                    const int pidx = (int)__builtin_fmaf(lyf - (float)ry0, (float)REGION, lxf - (float)rx0);
+                    bool cov_a = false, cov_b = false;
+                    if (flags & FLAG_BIG) {
+                        const int lx = (int)lxf, ly = (int)lyf;
+                        if (flags & FLAG_HAS_A) cov_a = live && edges_inside_i32(r.t[0], lx, ly);
+                        if (flags & FLAG_HAS_B) cov_b = live && edges_inside_i32(r.t[1], lx, ly);
+                    } else {
+                        if (flags & FLAG_HAS_A) cov_a = live && edges_inside_f32(r.t[0], lxf, lyf);
+                        if (flags & FLAG_HAS_B) cov_b = live && edges_inside_f32(r.t[1], lxf, lyf);
+                    }
+                    // one pass when no pixel is covered by both triangles, else A then B
+                    const int passes = __any(cov_a && cov_b) ? 2 : 1;
+                    for (int pass = 0; pass < passes; pass++) {
+                        const bool use_b = passes == 2 ? (pass == 1) : cov_b;
+                        const bool cov = passes == 2 ? (pass == 1 ? cov_b : cov_a) : (cov_a || cov_b);
+                        if (cov) {
+                            const TriData& t = use_b ? r.t[1] : r.t[0];
+                            const float dx = __builtin_fmaf(lxf, 256.0f, -t.XR), dy = __builtin_fmaf(lyf, 256.0f, -t.YR);   // exact
+                            Varyings var; float* vf = reinterpret_cast<float*>(&var);
 #pragma unroll
-            for (int t = 0; t < NA; t++) pix[t] = tile_px[t][pidx];
-            const uint32_t bx0 = (uint32_t)bx * RH_BLOCK, by0 = (uint32_t)by * RH_BLOCK;
-            bool touched = false;
-            for (int round = 0; round < RH_BATCH_TRIS / 64; round++) {
-                const uint32_t bb = rec_bbox[round * 64 + lane];
-                const uint32_t tx0 = bb & 0xffu, ty0 = (bb >> 8) & 0xffu, tx1 = (bb >> 16) & 0xffu, ty1 = bb >> 24;
-                const bool hit = tx0 <= bx0 + (RH_BLOCK - 1) && tx1 >= bx0 && ty0 <= by0 + (RH_BLOCK - 1) && ty1 >= by0;
-                unsigned long long mask = __ballot(hit);
-                while (mask) {
-                    const int tl = __builtin_ctzll(mask);
-                    mask &= mask - 1;
-                    const TriRecord& r = rec[round * 64 + tl];
-                    const int s0 = __mul24(r.A0, lx) + __mul24(r.B0, ly) + r.T0;
-                    const int s1 = __mul24(r.A1, lx) + __mul24(r.B1, ly) + r.T1;
-                    const int s2 = __mul24(r.A2, lx) + __mul24(r.B2, ly) + r.T2;
-                    if (((s0 | s1 | s2) >= 0) && in_scissor) {
-                        const float dx = (float)(lx * 256 - r.X0t) * (1.0f / 256.0f);
-                        const float dy = (float)(ly * 256 - r.Y0t) * (1.0f / 256.0f);
-                        Varyings var; float* vf = reinterpret_cast<float*>(&var);
+                            for (int v = 0; v < NV; v++) vf[v] = __builtin_fmaf(t.dvdy[v], dy, __builtin_fmaf(t.dvdx[v], dx, t.v0[v]));
+                            if (flags & (FLAG_PERSP_A | FLAG_PERSP_B)) {
+                                if (use_b ? (flags & FLAG_PERSP_B) != 0 : (flags & FLAG_PERSP_A) != 0) {
+                                    const float q = __builtin_fmaf(t.qy, dy, __builtin_fmaf(t.qx, dx, t.q0));
 #pragma unroll
-                        for (int v = 0; v < NV; v++) vf[v] = __builtin_fmaf(r.dvdy[v], dy, __builtin_fmaf(r.dvdx[v], dx, r.v0[v]));
-                        if (r.flags & FLAG_PERSP) {
-                            const float q = __builtin_fmaf(r.dqdy, dy, __builtin_fmaf(r.dqdx, dx, r.q0));
+                                    for (int v = 0; v < NV; v++) vf[v] = vf[v] / q;
+                                }
+                            }
+                            Outputs out;
+                            fragment_main(fctx, var, out);
 #pragma unroll
-                            for (int v = 0; v < NV; v++) vf[v] = vf[v] / q;
+                            for (int n = 0; n < NA; n++) {
+                                uint32_t* px = region_px + n * (4 * REGION_STRIDE) + pidx;
+                                *px = blend(*px, out.color[n < RH_FRAGMENT_OUTPUTS ? n : RH_FRAGMENT_OUTPUTS - 1], a.src_factor, a.dst_factor);
+                            }
                         }
-                        Outputs out;
-                        fragment_main(fctx, var, out);
-#pragma unroll
-                        for (int t = 0; t < NA; t++)
-                            pix[t] = blend(pix[t], out.color[t < RH_FRAGMENT_OUTPUTS ? t : RH_FRAGMENT_OUTPUTS - 1], a.src_factor, a.dst_factor);
-                        touched = true;
                     }
                 }
-            }
-            if (touched) {
-#pragma unroll
-                for (int t = 0; t < NA; t++) tile_px[t][pidx] = pix[t];
             }
         }
     }
@@ -236,7 +334,7 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a) {
             const int lx = i & (RH_TILE - 1), ly = i / RH_TILE;
             const uint32_t gx = (uint32_t)(ox + lx), gy = (uint32_t)(oy + ly);
             if (gx < p.width && gy < p.height) {
-                uint32_t v = tile_px[t][lds_pixel_index(lx, ly)];
+                uint32_t v = tile_px[t][((ly >> 4) * 2 + (lx >> 4)) * REGION_STRIDE + (ly & 15) * REGION + (lx & 15)];
                 if (at.format == FORMAT_BGRA_U8) v = swap_rb(v);
                 reinterpret_cast<uint32_t*>(at.ptr)[(size_t)gy * at.pitch_px + gx] = v;
             }

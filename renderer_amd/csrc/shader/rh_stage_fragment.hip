@@ -243,6 +243,7 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a) {
     const bool region_live = sx0 <= sx1 && sy0 <= sy1;
     uint32_t* const region_px = &tile_px[0][wave * REGION_STRIDE];
     const float lane_f = (float)lane;
+    const float region_bias = (float)(ry0 * REGION + rx0);     // pidx = (ly - ry0) * 16 + (lx - rx0)
 
     // 2. batches of clusters
     for (uint32_t base = start; base < end; base += RH_BATCH_CLUSTERS) {
@@ -266,23 +267,25 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a) {
                 mask &= mask - 1;
                 const int ci = round * 64 + tl;
                 const ClusterRecord& r = rec[ci];
-                const uint32_t flags = r.flags;
+                // wave-uniform values are pulled into scalar registers so that the per-hit bookkeeping runs on the scalar unit
+                const uint32_t flags = __builtin_amdgcn_readfirstlane(r.flags);
+                const uint32_t hb = __builtin_amdgcn_readfirstlane(rec_bbox[ci]);
                 // pixels of (cluster bbox intersected with the region), packed linearly: idx -> (idx % w, idx / w)
-                const uint32_t hb = rec_bbox[ci];
                 const int hx0 = max((int)(hb & 0xffu), sx0), hy0 = max((int)((hb >> 8) & 0xffu), sy0);
                 const int hx1 = min((int)((hb >> 16) & 0xffu), sx1), hy1 = min((int)(hb >> 24), sy1);
                 const int w = hx1 - hx0 + 1, npx = w * (hy1 - hy0 + 1);
                 const float wf = (float)w, invw = __builtin_amdgcn_rcpf(wf);
                 const float hx0f = (float)hx0, hy0f = (float)hy0;
+                const float half_invw = 0.5f * invw;
                 for (int first = 0; first < npx; first += 64) {
                     const float idx_f = lane_f + (float)first;
                     // floor((idx + 0.5) / w): the half keeps the quotient at least 1/32 away from an integer
-                    const float row_f = floorf(__builtin_fmaf(idx_f, invw, 0.5f * invw));
+                    const float row_f = floorf(__builtin_fmaf(idx_f, invw, half_invw));
                     const float col_f = __builtin_fmaf(-row_f, wf, idx_f);
                     const float lxf = hx0f + col_f, lyf = hy0f + row_f;          // tile-relative pixel, exact small integers
-                    const bool live = first + lane < npx;
+                    const bool live = idx_f < (float)npx;
                     // region-relative LDS index of the pixel
-                    const int pidx = (int)__builtin_fmaf(lyf - (float)ry0, (float)REGION, lxf - (float)rx0);
+                    const int pidx = (int)__builtin_fmaf(lyf, (float)REGION, lxf - region_bias);
                     bool cov_a = false, cov_b = false;
                     if (flags & FLAG_BIG) {
                         const int lx = (int)lxf, ly = (int)lyf;
@@ -292,11 +295,7 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a) {
                         if (flags & FLAG_HAS_A) cov_a = live && edges_inside_f32(r.t[0], lxf, lyf);
                         if (flags & FLAG_HAS_B) cov_b = live && edges_inside_f32(r.t[1], lxf, lyf);
                     }
-                    // one pass when no pixel is covered by both triangles, else A then B
-                    const int passes = __any(cov_a && cov_b) ? 2 : 1;
-                    for (int pass = 0; pass < passes; pass++) {
-                        const bool use_b = passes == 2 ? (pass == 1) : cov_b;
-                        const bool cov = passes == 2 ? (pass == 1 ? cov_b : cov_a) : (cov_a || cov_b);
+                    auto shade = [&](bool cov, bool use_b) {
                         if (cov) {
                             const TriData& t = use_b ? r.t[1] : r.t[0];
                             const float dx = __builtin_fmaf(lxf, 256.0f, -t.XR), dy = __builtin_fmaf(lyf, 256.0f, -t.YR);   // exact
@@ -318,7 +317,10 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a) {
                                 *px = blend(*px, out.color[n < RH_FRAGMENT_OUTPUTS ? n : RH_FRAGMENT_OUTPUTS - 1], a.src_factor, a.dst_factor);
                             }
                         }
-                    }
+                    };
+                    // one pass when no pixel is covered by both triangles (the usual case), else A then B
+                    if (!__any(cov_a && cov_b)) shade(cov_a || cov_b, cov_b);
+                    else { shade(cov_a, false); shade(cov_b, true); }
                 }
             }
         }

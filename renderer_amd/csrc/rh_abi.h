@@ -15,7 +15,9 @@
 #define RH_SUBPIXEL_BITS 8
 #define RH_TILE 32                 // screen tile edge in pixels (one workgroup per tile)
 #define RH_BLOCK 8                 // one wavefront shades an 8x8 pixel block at a time
-#define RH_BATCH_CLUSTERS 128      // clusters (triangle pairs) set up per batch inside a tile workgroup
+#ifndef RH_BATCH_CLUSTERS
+#define RH_BATCH_CLUSTERS 64       // clusters (triangle pairs) set up per batch inside a tile workgroup
+#endif
 #define RH_TILE_THREADS 256
 
 enum { RH_MODULE_STAGE_VERTEX = 1, RH_MODULE_STAGE_FRAGMENT = 2 };

@@ -36,6 +36,12 @@ extern "C" __device__ const rh_module_info_t rh_module_info = {
     rh::fnv1a(RH_VERTEX_TAG), { 0u, 0u }
 };
 
+// 8 waves per SIMD (64 VGPRs): measured 10 % faster than 5 waves at 85 VGPRs despite a few spilled setup values.
+#ifndef RH_TILE_MIN_WAVES
+#define RH_TILE_MIN_WAVES 8
+#endif
+static_assert(RH_BATCH_CLUSTERS % 64 == 0, "a batch is walked in rounds of 64 clusters");
+
 namespace rh {
 
 constexpr int NV = N_VARYINGS;
@@ -346,7 +352,7 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a) {
 
 } // namespace rh
 
-extern "C" __global__ __launch_bounds__(RH_TILE_THREADS) void rh_tile_1(rh_tile_args a) { rh::tile_kernel<1>(a); }
-extern "C" __global__ __launch_bounds__(RH_TILE_THREADS) void rh_tile_2(rh_tile_args a) { rh::tile_kernel<2>(a); }
-extern "C" __global__ __launch_bounds__(RH_TILE_THREADS) void rh_tile_3(rh_tile_args a) { rh::tile_kernel<3>(a); }
-extern "C" __global__ __launch_bounds__(RH_TILE_THREADS) void rh_tile_4(rh_tile_args a) { rh::tile_kernel<4>(a); }
+extern "C" __global__ __launch_bounds__(RH_TILE_THREADS, RH_TILE_MIN_WAVES) void rh_tile_1(rh_tile_args a) { rh::tile_kernel<1>(a); }
+extern "C" __global__ __launch_bounds__(RH_TILE_THREADS, RH_TILE_MIN_WAVES) void rh_tile_2(rh_tile_args a) { rh::tile_kernel<2>(a); }
+extern "C" __global__ __launch_bounds__(RH_TILE_THREADS, RH_TILE_MIN_WAVES) void rh_tile_3(rh_tile_args a) { rh::tile_kernel<3>(a); }
+extern "C" __global__ __launch_bounds__(RH_TILE_THREADS, RH_TILE_MIN_WAVES) void rh_tile_4(rh_tile_args a) { rh::tile_kernel<4>(a); }

@@ -128,7 +128,8 @@ def shader_code(name):
     d = os.path.join(os.path.dirname(renderer_amd.__file__), "shaders")
     with open(os.path.join(d, f"{name}.vert.co"), "rb") as f:
         vert = f.read()
-    with open(os.path.join(d, f"{name}.frag.co"), "rb") as f:
+    frag_path = os.environ.get("RH_FRAG_CO_OVERRIDE") or os.path.join(d, f"{name}.frag.co")     # kernel experiments
+    with open(frag_path, "rb") as f:
         frag = f.read()
     return vert, frag
 

@@ -216,6 +216,32 @@ typedef struct rh_timings {
 } rh_timings;
 int rh_device_drain_timings(rh_device* dev, rh_timings* out);
 
+/* ---- capture codec: lz4f::WriteCompressor (src/compressor.rs:98,126-129,138-144) and lz4f::BufReadDecompressor
+ *      (src/decompressor.rs:198,216-235) -------------------------------------------------------------------------------- */
+/* Creates `n_streams` independent LZ4F streams (the reference opens one per worker thread/file,
+ * src/compressor.rs:24-26,94-98) with the reference's preferences: compression level `level` (0..2 select the LZ4
+ * "fast" compressor and give identical bytes; higher levels are not implemented), favor_dec_speed off, auto_flush on,
+ * everything else default (block-linked, 64 KiB blocks, no checksums).  Streams are compressed on the GPU, one
+ * workgroup per stream; stream bytes are identical to liblz4's for the same write sequence. */
+int rh_compressor_create(rh_device* dev, uint32_t n_streams, int level, rh_compressor** out);
+void rh_compressor_destroy(rh_compressor* c);
+/* Queues one packet for `stream`, i.e. the four write_all calls of src/compressor.rs:126-129:
+ * [packet_len u64 BE][metadata_len u64 BE][metadata][image bytes], where the image is the whole device buffer `image`
+ * (NULL for a frame without image data: then only the first three writes happen).  The buffer is retained until the
+ * packet has been compressed. */
+int rh_compressor_write_packet(rh_compressor* c, uint32_t stream, const void* metadata, size_t metadata_len, rh_buffer* image);
+/* Compresses everything queued (all streams concurrently) and brings the compressed bytes to the host. */
+int rh_compressor_flush(rh_compressor* c);
+/* Bytes of `stream` ready to be read (the 7-byte frame header precedes the first block). */
+size_t rh_compressor_pending(rh_compressor* c, uint32_t stream);
+/* Moves up to `cap` ready bytes of `stream` into dst. */
+int rh_compressor_read(rh_compressor* c, uint32_t stream, void* dst, size_t cap, size_t* len);
+/* Flushes and appends the LZ4F end mark to `stream` (LZ4F_compressEnd, when the reference drops the writer). */
+int rh_compressor_finish_stream(rh_compressor* c, uint32_t stream);
+/* Host-side LZ4 frame decoder.  Tolerates a truncated tail (src/decompressor.rs:216-235 stops at an unclean end):
+ * decoding stops after the last complete block; *complete is 1 when the end mark was reached. */
+int rh_lz4f_decompress(const void* src, size_t src_len, void* dst, size_t dst_cap, size_t* produced, size_t* consumed, int* complete);
+
 #ifdef __cplusplus
 }
 #endif

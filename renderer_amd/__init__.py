@@ -8,9 +8,13 @@ from .blend_mode import BlendMode
 from .buffer import Buffer
 from .clear_color import ClearColor
 from .compiler import Compiler
+from .compressor import Compressor
+from .decompressor import Decompressor
+from .ffmpeg_pipe import FfmpegPipe
 from .filter_mode import FilterMode
 from .format import Format
 from .instanced import Instanced
+from .png_encoder import PngEncoder
 from .pipeline import BINDINGS_PER_GROUP, Pipeline, RecordingPosition
 from .primitive import Primitive
 from .program import Program

@@ -117,6 +117,14 @@ SIGNATURES = {
     "rh_submit": (C.c_int, [_P, _PP, C.c_size_t]),
     "rh_device_last_pass_stats": (C.c_int, [_P, C.POINTER(PassStats)]),
     "rh_device_drain_timings": (C.c_int, [_P, C.POINTER(Timings)]),
+    "rh_compressor_create": (C.c_int, [_P, C.c_uint32, C.c_int, _PP]),
+    "rh_compressor_destroy": (None, [_P]),
+    "rh_compressor_write_packet": (C.c_int, [_P, C.c_uint32, _P, C.c_size_t, _P]),
+    "rh_compressor_flush": (C.c_int, [_P]),
+    "rh_compressor_pending": (C.c_size_t, [_P, C.c_uint32]),
+    "rh_compressor_read": (C.c_int, [_P, C.c_uint32, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "rh_compressor_finish_stream": (C.c_int, [_P, C.c_uint32]),
+    "rh_lz4f_decompress": (C.c_int, [_P, C.c_size_t, _P, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
 }
 
 _lib = None

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SHADER_INCLUDE = os.path.join(HERE, "csrc", "shader")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--genco", "--no-gpu-bundle-output", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
-         "-I", SHADER_INCLUDE]
+         "-Wno-pass-failed", "-I", SHADER_INCLUDE]
 
 
 class Compiler:

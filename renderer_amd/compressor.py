@@ -1,0 +1,98 @@
+"""Frame compressor (reference src/compressor.rs:15-148): N LZ4-frame stream files `<timestamp>--<i>.sz`, each a
+sequence of packets [packet_len u64 BE][video_frame_len u64 BE][bincode(VideoFrame)][raw padded image].
+
+The reference runs one CPU worker thread per stream.  Here the streams are compressed on the GPU (one workgroup per
+stream, librenderer_hip.so rh_compressor_*): captured frames stay in device memory and only compressed bytes are read
+back.  Frame f goes to stream (f - 1) % n_streams (the reference's assignment is a channel race, so any assignment is
+valid; the decompressor re-orders by frame number).  The terminal statistics display of the reference is not
+reproduced."""
+import ctypes as C
+import datetime
+import os
+
+from . import _ffi
+
+CLEVEL_MAX = 12          # lz4f::CLEVEL_MAX
+
+
+def generate_timestamp(now=None):
+    """Utc::now().to_rfc3339_opts(SecondsFormat::Millis, true) with ':' replaced by '_' (reference src/compressor.rs:71-73)."""
+    now = now or datetime.datetime.now(datetime.timezone.utc)
+    return now.strftime("%Y-%m-%dT%H_%M_%S.") + f"{now.microsecond // 1000:03d}Z"
+
+
+class Compressor:
+    def __init__(self, renderer, directory, max_frames_queued=None, lz4_compression_level=0, print_stats=False,
+                 n_streams=64, timestamp=None):
+        if lz4_compression_level > CLEVEL_MAX:
+            raise AssertionError(f"Please choose a compression level in the range 0..={CLEVEL_MAX}")
+        os.makedirs(directory, exist_ok=True)
+        self.directory = directory
+        self.timestamp = timestamp or generate_timestamp()
+        self.n_streams = n_streams
+        # packets are compressed when every stream has one queued, or when this many frames wait
+        self.max_frames_queued = max_frames_queued if max_frames_queued else n_streams
+        self.print_stats = print_stats
+        out = C.c_void_p()
+        _ffi.check(_ffi.lib().rh_compressor_create(renderer.device, n_streams, lz4_compression_level, C.byref(out)))
+        self.handle = out
+        self.files = [open(os.path.join(directory, f"{self.timestamp}--{i}.sz"), "wb") for i in range(n_streams)]
+        self.queued = []            # frames whose packets are queued on the device (kept alive until compressed)
+        self.frames_captured = 0
+        self.frames_dropped = 0
+        self.raw_video_size = 0
+        self.compressed_size = 0
+
+    def compress_to_disk(self, video_frame):
+        stream = (video_frame.frame_number - 1) % self.n_streams
+        meta = video_frame.encode()
+        image = video_frame.image_data.buffer() if (video_frame.image_data is not None and video_frame.image_data.is_buffer()) else None
+        buf = C.create_string_buffer(meta, len(meta))
+        _ffi.check(_ffi.lib().rh_compressor_write_packet(self.handle, stream, buf, len(meta), image))
+        if video_frame.image_data is not None:
+            self.frames_captured += 1
+            self.raw_video_size += video_frame.frame_size_in_bytes
+        else:
+            self.frames_dropped += 1
+        self.queued.append(video_frame)
+        if len(self.queued) >= min(self.n_streams, self.max_frames_queued):
+            self.flush()
+
+    def flush(self):
+        """Compresses all queued packets (streams run concurrently on the GPU) and appends the bytes to the files."""
+        _ffi.check(_ffi.lib().rh_compressor_flush(self.handle))
+        for frame in self.queued:
+            frame.drop()                # returns the frame's bytes to the capture budget (reference src/video_frame.rs:70-77)
+        self.queued = []
+        self._drain()
+
+    def _drain(self):
+        L = _ffi.lib()
+        for i, f in enumerate(self.files):
+            n = L.rh_compressor_pending(self.handle, i)
+            if n == 0:
+                continue
+            buf = (C.c_uint8 * n)()
+            got = C.c_size_t()
+            _ffi.check(L.rh_compressor_read(self.handle, i, buf, n, C.byref(got)))
+            f.write(memoryview(buf)[:got.value])
+            self.compressed_size += got.value
+
+    def finish(self):
+        """Waits for everything queued, writes the end marks and closes the files (reference src/compressor.rs:46-62)."""
+        if self.handle is None:
+            return
+        self.flush()
+        for i in range(self.n_streams):
+            _ffi.check(_ffi.lib().rh_compressor_finish_stream(self.handle, i))
+        self._drain()
+        for f in self.files:
+            f.close()
+        _ffi.lib().rh_compressor_destroy(self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.finish()
+        except Exception:
+            pass

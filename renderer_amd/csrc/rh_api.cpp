@@ -817,3 +817,238 @@ int rh_device_last_pass_stats(rh_device* dev, rh_pass_stats* out) {
 }
 
 } // extern "C"
+
+// ---- capture codec --------------------------------------------------------------------------------------------------------
+#include "rh_codec.h"
+#include <deque>
+
+struct rh_compressor {
+    rh_device* dev = nullptr;
+    uint32_t n_streams = 0;
+    rh_lz4_stream_state* d_states = nullptr;
+    struct Packet { std::vector<uint8_t> meta; rh_buffer* image = nullptr; };
+    std::vector<std::deque<Packet>> queue;           // per stream
+    std::vector<std::vector<uint8_t>> ready;         // per stream: compressed bytes not yet read
+    // per-round device/host scratch
+    Scratch d_jobs, d_stage, d_out, d_lens;
+    void* h_pinned = nullptr; size_t h_pinned_cap = 0;
+};
+
+namespace {
+
+size_t lz4f_bound(size_t n) { return n + 4 * (n / 65536 + 1); }      // every block stored + one header each
+size_t align16(size_t n) { return (n + 15) & ~(size_t)15; }
+
+int compressor_round(rh_compressor* c) {
+    rh_device* dev = c->dev;
+    hipStream_t s = dev->stream;
+    std::vector<rh_lz4_job> jobs;
+    std::vector<uint32_t> job_stream;
+    std::vector<size_t> stage_off, out_off, out_cap;
+    std::vector<uint8_t> stage;
+    size_t out_total = 0;
+    for (uint32_t st = 0; st < c->n_streams; st++) {
+        if (c->queue[st].empty()) continue;
+        const rh_compressor::Packet& pk = c->queue[st].front();
+        const uint64_t image_len = pk.image ? pk.image->size : 0;
+        const uint64_t packet_len = 16 + pk.meta.size() + image_len;
+        const uint64_t meta_len = pk.meta.size();
+        // staged small writes: [packet_len BE][pad to 16][meta_len BE][pad to 16][metadata][pad]
+        const size_t base = stage.size();
+        stage.resize(base + 32 + align16(pk.meta.size()), 0);
+        for (int i = 0; i < 8; i++) { stage[base + i] = (uint8_t)(packet_len >> (56 - 8 * i)); stage[base + 16 + i] = (uint8_t)(meta_len >> (56 - 8 * i)); }
+        memcpy(stage.data() + base + 32, pk.meta.data(), pk.meta.size());
+        stage_off.push_back(base);
+        const size_t cap = align16(lz4f_bound(8) * 2 + lz4f_bound(pk.meta.size()) + lz4f_bound(image_len));
+        out_off.push_back(out_total); out_cap.push_back(cap);
+        out_total += cap;
+        job_stream.push_back(st);
+    }
+    const uint32_t n = (uint32_t)job_stream.size();
+    if (n == 0) return 0;
+    if (c->d_jobs.ensure(n * sizeof(rh_lz4_job)) || c->d_stage.ensure(stage.size()) || c->d_out.ensure(out_total) || c->d_lens.ensure(n * 8)) return 1;
+    jobs.resize(n);
+    for (uint32_t j = 0; j < n; j++) {
+        const rh_compressor::Packet& pk = c->queue[job_stream[j]].front();
+        rh_lz4_job& jb = jobs[j];
+        memset(&jb, 0, sizeof jb);
+        jb.stream = job_stream[j];
+        const uint8_t* st = c->d_stage.as<uint8_t>() + stage_off[j];
+        jb.write_ptr[0] = st; jb.write_len[0] = 8;
+        jb.write_ptr[1] = st + 16; jb.write_len[1] = 8;
+        jb.write_ptr[2] = st + 32; jb.write_len[2] = pk.meta.size();
+        jb.n_writes = 3;
+        if (pk.image) { jb.write_ptr[3] = (const uint8_t*)pk.image->dptr; jb.write_len[3] = pk.image->size; jb.n_writes = 4; }
+        jb.out = c->d_out.as<uint8_t>() + out_off[j];
+        jb.out_len = c->d_lens.as<unsigned long long>() + j;
+    }
+    RH_HIP(hipMemcpyAsync(c->d_stage.ptr, stage.data(), stage.size(), hipMemcpyHostToDevice, s));
+    RH_HIP(hipMemcpyAsync(c->d_jobs.ptr, jobs.data(), n * sizeof(rh_lz4_job), hipMemcpyHostToDevice, s));
+    RH_HIP(hipStreamSynchronize(s));        // staging vectors go out of scope below; keep the copies simple and safe
+    int rc = rhk::lz4f_compress_launch(c->d_jobs.as<rh_lz4_job>(), n, c->d_states, s);
+    if (rc) return fail("rh_compressor: kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+    std::vector<unsigned long long> lens(n);
+    RH_HIP(hipMemcpyAsync(lens.data(), c->d_lens.ptr, n * 8, hipMemcpyDeviceToHost, s));
+    RH_HIP(hipStreamSynchronize(s));
+    // only the compressed bytes cross PCIe
+    size_t total = 0;
+    for (uint32_t j = 0; j < n; j++) { if (lens[j] > out_cap[j]) return fail("rh_compressor: stream %u overflowed its output area", job_stream[j]); total += lens[j]; }
+    if (total > c->h_pinned_cap) {
+        if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+        c->h_pinned = nullptr; c->h_pinned_cap = 0;
+        RH_HIP(hipHostMalloc(&c->h_pinned, total + total / 2 + 4096, hipHostMallocDefault));
+        c->h_pinned_cap = total + total / 2 + 4096;
+    }
+    size_t off = 0;
+    for (uint32_t j = 0; j < n; j++) {
+        if (lens[j]) RH_HIP(hipMemcpyAsync((uint8_t*)c->h_pinned + off, c->d_out.as<uint8_t>() + out_off[j], lens[j], hipMemcpyDeviceToHost, s));
+        off += lens[j];
+    }
+    RH_HIP(hipStreamSynchronize(s));
+    off = 0;
+    for (uint32_t j = 0; j < n; j++) {
+        std::vector<uint8_t>& r = c->ready[job_stream[j]];
+        r.insert(r.end(), (uint8_t*)c->h_pinned + off, (uint8_t*)c->h_pinned + off + lens[j]);
+        off += lens[j];
+        rh_compressor::Packet& pk = c->queue[job_stream[j]].front();
+        if (pk.image) rh_buffer_release(pk.image);
+        c->queue[job_stream[j]].pop_front();
+    }
+    return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+int rh_compressor_create(rh_device* dev, uint32_t n_streams, int level, rh_compressor** out) {
+    if (!dev || !out || n_streams == 0) return fail("rh_compressor_create: bad argument");
+    if (level < 0 || level > 2) return fail("rh_compressor_create: compression level %d is not implemented on the GPU (0..2 = LZ4 fast)", level);
+    if (set_device(dev)) return 1;
+    rh_compressor* c = new rh_compressor();
+    c->dev = dev; c->n_streams = n_streams;
+    hipError_t e = hipMalloc((void**)&c->d_states, (size_t)n_streams * sizeof(rh_lz4_stream_state));
+    if (e != hipSuccess) { delete c; return fail("rh_compressor_create: %s", hipGetErrorString(e)); }
+    e = hipMemsetAsync(c->d_states, 0, (size_t)n_streams * sizeof(rh_lz4_stream_state), dev->stream);
+    if (e != hipSuccess) { (void)hipFree(c->d_states); delete c; return fail("rh_compressor_create: %s", hipGetErrorString(e)); }
+    c->queue.resize(n_streams); c->ready.resize(n_streams);
+    // LZ4F_compressBegin: magic, FLG (version 01, block-linked), BD (64 KiB blocks), header checksum
+    static const uint8_t header[7] = { 0x04, 0x22, 0x4d, 0x18, 0x40, 0x40, 0xc0 };
+    for (auto& r : c->ready) r.assign(header, header + 7);
+    device_retain(dev);
+    *out = c;
+    return 0;
+}
+
+void rh_compressor_destroy(rh_compressor* c) {
+    if (!c) return;
+    rh_device* dev = c->dev;
+    (void)hipSetDevice(dev->ordinal);
+    (void)hipStreamSynchronize(dev->stream);
+    for (auto& q : c->queue) for (auto& pk : q) if (pk.image) rh_buffer_release(pk.image);
+    Scratch* all[] = { &c->d_jobs, &c->d_stage, &c->d_out, &c->d_lens };
+    for (Scratch* s : all) s->release();
+    if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    if (c->d_states) (void)hipFree(c->d_states);
+    delete c;
+    device_release(dev);
+}
+
+int rh_compressor_write_packet(rh_compressor* c, uint32_t stream, const void* metadata, size_t metadata_len, rh_buffer* image) {
+    if (!c || (!metadata && metadata_len)) return fail("rh_compressor_write_packet: bad argument");
+    if (stream >= c->n_streams) return fail("rh_compressor_write_packet: stream %u out of range (%u streams)", stream, c->n_streams);
+    if (metadata_len == 0) return fail("rh_compressor_write_packet: empty metadata");
+    rh_compressor::Packet pk;
+    pk.meta.assign((const uint8_t*)metadata, (const uint8_t*)metadata + metadata_len);
+    pk.image = image;
+    if (image) rh_buffer_retain(image);
+    c->queue[stream].push_back(std::move(pk));
+    return 0;
+}
+
+int rh_compressor_flush(rh_compressor* c) {
+    if (!c) return fail("rh_compressor_flush: null compressor");
+    if (set_device(c->dev)) return 1;
+    for (;;) {
+        bool any = false;
+        for (auto& q : c->queue) any = any || !q.empty();
+        if (!any) return 0;
+        if (compressor_round(c)) return 1;
+    }
+}
+
+size_t rh_compressor_pending(rh_compressor* c, uint32_t stream) {
+    return (c && stream < c->n_streams) ? c->ready[stream].size() : 0;
+}
+
+int rh_compressor_read(rh_compressor* c, uint32_t stream, void* dst, size_t cap, size_t* len) {
+    if (!c || !len || (!dst && cap)) return fail("rh_compressor_read: bad argument");
+    if (stream >= c->n_streams) return fail("rh_compressor_read: stream %u out of range", stream);
+    std::vector<uint8_t>& r = c->ready[stream];
+    const size_t n = std::min(cap, r.size());
+    if (n) memcpy(dst, r.data(), n);
+    r.erase(r.begin(), r.begin() + n);
+    *len = n;
+    return 0;
+}
+
+int rh_compressor_finish_stream(rh_compressor* c, uint32_t stream) {
+    if (!c) return fail("rh_compressor_finish_stream: null compressor");
+    if (stream >= c->n_streams) return fail("rh_compressor_finish_stream: stream %u out of range", stream);
+    if (rh_compressor_flush(c)) return 1;
+    static const uint8_t end_mark[4] = { 0, 0, 0, 0 };
+    c->ready[stream].insert(c->ready[stream].end(), end_mark, end_mark + 4);
+    return 0;
+}
+
+// LZ4 frame decoder (host).  Block-linked frames: matches may reach into everything decoded so far.
+int rh_lz4f_decompress(const void* src_, size_t n, void* dst_, size_t cap, size_t* produced, size_t* consumed, int* complete) {
+    const uint8_t* src = (const uint8_t*)src_; uint8_t* dst = (uint8_t*)dst_;
+    if (!src || (!dst && cap) || !produced || !consumed || !complete) return fail("rh_lz4f_decompress: bad argument");
+    *produced = 0; *consumed = 0; *complete = 0;
+    auto le32 = [&](size_t at) { return (uint32_t)src[at] | ((uint32_t)src[at + 1] << 8) | ((uint32_t)src[at + 2] << 16) | ((uint32_t)src[at + 3] << 24); };
+    if (n < 7 || le32(0) != 0x184D2204u) return fail("rh_lz4f_decompress: not an LZ4 frame");
+    const uint8_t flg = src[4];
+    if ((flg >> 6) != 1) return fail("rh_lz4f_decompress: unsupported frame version");
+    const bool block_checksum = (flg >> 4) & 1, content_size = (flg >> 3) & 1, content_checksum = (flg >> 2) & 1, dict_id = flg & 1;
+    size_t ip = 6 + (content_size ? 8 : 0) + (dict_id ? 4 : 0) + 1, pos = 0;
+    if (n < ip) return fail("rh_lz4f_decompress: truncated frame header");
+    *consumed = ip;
+    for (;;) {
+        if (n - ip < 4) break;
+        const uint32_t bh = le32(ip);
+        if (bh == 0) { ip += 4; if (content_checksum) { if (n - ip < 4) break; ip += 4; } *complete = 1; break; }
+        const size_t bsz = bh & 0x7fffffffu, trailer = block_checksum ? 4 : 0;
+        if (n - ip - 4 < bsz + trailer) break;                              // truncated block: stop at the last complete one
+        const uint8_t* b = src + ip + 4; const uint8_t* const bend = b + bsz;
+        if (bh & 0x80000000u) {
+            if (cap - pos < bsz) return fail("rh_lz4f_decompress: output buffer too small");
+            memcpy(dst + pos, b, bsz); pos += bsz;
+        } else {
+            while (b < bend) {
+                const unsigned token = *b++;
+                size_t lit = token >> 4;
+                if (lit == 15) { unsigned x; do { if (b >= bend) return fail("rh_lz4f_decompress: malformed block"); x = *b++; lit += x; } while (x == 255); }
+                if ((size_t)(bend - b) < lit) return fail("rh_lz4f_decompress: malformed block");
+                if (cap - pos < lit) return fail("rh_lz4f_decompress: output buffer too small");
+                memcpy(dst + pos, b, lit); pos += lit; b += lit;
+                if (b >= bend) break;                                       // last sequence: literals only
+                if (bend - b < 2) return fail("rh_lz4f_decompress: malformed block");
+                const size_t off = (size_t)b[0] | ((size_t)b[1] << 8); b += 2;
+                size_t ml = token & 15;
+                if (ml == 15) { unsigned x; do { if (b >= bend) return fail("rh_lz4f_decompress: malformed block"); x = *b++; ml += x; } while (x == 255); }
+                ml += 4;
+                if (off == 0 || off > pos) return fail("rh_lz4f_decompress: match offset outside the decoded data");
+                if (cap - pos < ml) return fail("rh_lz4f_decompress: output buffer too small");
+                for (size_t i = 0; i < ml; i++) dst[pos + i] = dst[pos + i - off];
+                pos += ml;
+            }
+        }
+        ip += 4 + bsz + trailer;
+        *consumed = ip; *produced = pos;
+    }
+    *consumed = ip; *produced = pos;
+    return 0;
+}
+
+} // extern "C"

@@ -132,10 +132,11 @@ class Renderer:
         pipeline.set_msaa_samples(msaa_samples)
 
     # ---- recording ----------------------------------------------------------------------------------------------------
-    def start_recording(self, pipelines, clear_color, max_buffer_size_in_megabytes, process_function):
-        """reference src/renderer.rs:178-188"""
+    def start_recording(self, pipelines, clear_color, max_buffer_size_in_megabytes, process_function, keep_on_device=False):
+        """reference src/renderer.rs:178-188.  keep_on_device=True hands frames to process_function without mapping
+        them into host memory (for the GPU Compressor)."""
         max_size_in_bytes = int(np.float32(max_buffer_size_in_megabytes) * np.float32(1024.0) * np.float32(1024.0))
-        self.recorder = VideoRecorder(self, clear_color, max_size_in_bytes, process_function)
+        self.recorder = VideoRecorder(self, clear_color, max_size_in_bytes, process_function, keep_on_device)
         for i, pipeline in enumerate(pipelines):
             is_last = i == len(pipelines) - 1
             pipeline.set_stream_position(RecordingPosition.Last if is_last else RecordingPosition.NotLast)

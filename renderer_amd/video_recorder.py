@@ -23,8 +23,11 @@ def capture_layout(width, height, bytes_per_texel):
 
 
 class VideoRecorder:
-    def __init__(self, renderer, clear_color, max_buffer_size_in_bytes, process_function):
+    def __init__(self, renderer, clear_color, max_buffer_size_in_bytes, process_function, keep_on_device=False):
         self.device = renderer.device
+        # keep_on_device: frames are delivered without mapping them into host memory (for the GPU compressor, which
+        # reads the capture buffer on the device; only compressed bytes are read back)
+        self.keep_on_device = keep_on_device
         self.max_buffer_size_in_bytes = max_buffer_size_in_bytes
         self.process_function = process_function
         size = (renderer.window_size[0], renderer.window_size[1], 1)
@@ -99,7 +102,9 @@ class VideoRecorder:
             if i < len(self.frame_states):
                 continue
             video_frame = self.video_frames[i]
-            if video_frame.image_data is not None:
+            if video_frame.image_data is not None and self.keep_on_device:
+                self.frame_states.append([2])                 # usable as is: the consumer reads device memory
+            elif video_frame.image_data is not None:
                 state = [1]                                   # 1 = mapping
                 key = id(state)
 

@@ -1,0 +1,180 @@
+"""GPU parity of the capture codec: LZ4F streams compressed on the device must be byte-identical to the oracle
+(restatement of liblz4) and to the system liblz4 1.9.3 for the same write sequences, and the recorded-frame pipeline
+(record -> GPU compress -> files -> decompress -> re-order) must return the captured pixels."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_streams(packets_per_stream, n_streams):
+    """packets_per_stream: list (per stream) of lists of (metadata bytes, image bytes | None).  Returns stream bytes."""
+    from renderer_amd import Renderer, _ffi
+    L = _ffi.lib()
+    r = Renderer(64, 64)
+    comp = C.c_void_p()
+    _ffi.check(L.rh_compressor_create(r.device, n_streams, 0, C.byref(comp)))
+    buffers = []
+    rounds = max(len(p) for p in packets_per_stream)
+    for k in range(rounds):
+        for s, packets in enumerate(packets_per_stream):
+            if k >= len(packets):
+                continue
+            meta, image = packets[k]
+            handle = None
+            if image is not None:
+                arr = np.frombuffer(image, dtype=np.uint8)
+                out = C.c_void_p()
+                _ffi.check(L.rh_buffer_create(r.device, len(image), _ffi.BUFFER_COPY_DST | _ffi.BUFFER_MAP_READ,
+                                              arr.ctypes.data, len(image), C.byref(out)))
+                handle = out; buffers.append(out)
+            _ffi.check(L.rh_compressor_write_packet(comp, s, meta, len(meta), handle))
+        _ffi.check(L.rh_compressor_flush(comp))
+    streams = []
+    for s in range(n_streams):
+        _ffi.check(L.rh_compressor_finish_stream(comp, s))
+        n = L.rh_compressor_pending(comp, s)
+        buf = (C.c_uint8 * n)(); got = C.c_size_t()
+        _ffi.check(L.rh_compressor_read(comp, s, buf, n, C.byref(got)))
+        streams.append(bytes(buf[:got.value]))
+    for b in buffers:
+        L.rh_buffer_release(b)
+    L.rh_compressor_destroy(comp)
+    r.close()
+    return streams
+
+
+def reference_stream(cls, packets):
+    s = cls()
+    for meta, image in packets:
+        plen = 16 + len(meta) + (len(image) if image is not None else 0)
+        s.write(plen.to_bytes(8, "big")); s.write(len(meta).to_bytes(8, "big")); s.write(meta)
+        if image is not None:
+            s.write(image)
+    return s.finish()
+
+
+def image_bytes(rng, n, kind):
+    if kind == "flat":
+        return bytes([0, 0, 0, 255]) * (n // 4)
+    if kind == "noise":
+        return rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+    if kind == "runs":
+        out = bytearray()
+        while len(out) < n:
+            out += rng.integers(0, 256, 4, dtype=np.uint8).tobytes() * int(rng.integers(1, 300))
+        return bytes(out[:n])
+    if kind == "text":
+        base = rng.integers(0, 256, 2000, dtype=np.uint8).tobytes()
+        out = bytearray()
+        while len(out) < n:
+            s = int(rng.integers(0, 1900)); out += base[s:s + int(rng.integers(4, 100))]
+        return bytes(out[:n])
+    raise ValueError(kind)
+
+
+def test_streams_byte_identical_to_oracle_and_liblz4(oracle):
+    rng = np.random.default_rng(42)
+    meta = bytes(range(23))
+    kinds = ["flat", "noise", "runs", "text"]
+    sizes = [256, 4352 * 3, 65536, 65536 + 4, 3 * 65536, 200_000, 1_000_000]
+    packets_per_stream = []
+    for s in range(12):
+        packets = []
+        for k in range(3):
+            if (s + k) % 5 == 4:
+                packets.append((meta[:11], None))                    # dropped frame: metadata only
+            else:
+                n = sizes[(s * 3 + k) % len(sizes)]
+                packets.append((meta, image_bytes(rng, n - n % 4, kinds[(s + k) % 4])))
+        packets_per_stream.append(packets)
+    got = gpu_streams(packets_per_stream, len(packets_per_stream))
+    for s, packets in enumerate(packets_per_stream):
+        want = reference_stream(oracle.Lz4OracleStream, packets)
+        assert got[s] == want, f"stream {s}: GPU stream differs from the oracle (len {len(got[s])} vs {len(want)})"
+        assert got[s] == reference_stream(lambda: oracle.LibLz4Stream(0), packets), f"stream {s}: differs from liblz4"
+        # and it decodes back to the packet bytes
+        plain = b"".join((16 + len(m) + (len(i) if i else 0)).to_bytes(8, "big") + len(m).to_bytes(8, "big") + m + (i or b"")
+                         for m, i in packets)
+        dec, _, complete = oracle.lz4_decompress_frame(got[s], len(plain) + 16)
+        assert complete and dec == plain
+
+
+def test_golden_streams_on_gpu(oracle):
+    import hashlib
+    import json
+    import test_oracle_cpu
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "lz4_kat.json")))
+    cases = test_oracle_cpu.kat_cases()
+    # the golden write sequences are packets: 8 B, 8 B, metadata [, image] (+ a second packet in one case)
+    names = sorted(cases)
+    packets_per_stream = []
+    for name in names:
+        w = cases[name]
+        packets = []
+        i = 0
+        while i < len(w):
+            meta = w[i + 2]
+            plen = int.from_bytes(w[i], "big")
+            has_image = plen > 16 + len(meta)
+            packets.append((meta, w[i + 3] if has_image else None))
+            i += 4 if has_image else 3
+        packets_per_stream.append(packets)
+    got = gpu_streams(packets_per_stream, len(names))
+    for name, stream in zip(names, got):
+        assert len(stream) == gold["cases"][name]["stream_len"], name
+        assert hashlib.sha256(stream).hexdigest() == gold["cases"][name]["stream_sha256"], name
+
+
+def test_record_compress_decompress_roundtrip(oracle, tmp_path):
+    """Quads example with recording on: frames stay on the device, are LZ4-compressed there, written as .sz files and
+    come back through the decompressor in frame order with the recorded pixels."""
+    from renderer_amd import Compressor, Decompressor, PngEncoder, Renderer
+    W, H = 320, 180
+    scene = scenes.example_scene(1, width=W, height=H)
+    r = Renderer(W, H)
+    hs = scenes.HipScene(scene, renderer=r)
+    comp = Compressor(r, str(tmp_path), n_streams=3)
+    r.start_recording([hs.pipeline], Renderer.clear_color(0., 0., 0., 1.), 500., comp.compress_to_disk, keep_on_device=True)
+    r.flush()                # the scene set-up uploaded the instance buffer once; a new upload needs a new flush interval
+    expected = []
+    n_frames = 7
+    for k in range(1, n_frames + 1):
+        s = scenes.example_scene(k, width=W, height=H, record=True)
+        r.set_instanced(hs.pipeline, (0, 0), s["instances"])
+        r.render(hs.pipeline, hs.clear, hs.viewport, hs.count)
+        r.finish_frame()
+        expected.append(scenes.draw_oracle(s)["recording"])
+    r.stop_recording([hs.pipeline])
+    comp.finish()
+    files = sorted(os.listdir(tmp_path))
+    assert len(files) == 3 and all(f.endswith(".sz") and "--" in f for f in files)
+    assert Decompressor.can_run(str(tmp_path))
+
+    seen = []
+
+    def in_order(video_frame, result, timestamp):
+        seen.append((video_frame, result))
+
+    Decompressor(str(tmp_path), True).decompress_from_disk(lambda f, ts: PngEncoder.encode_to_bytes(f), in_order)
+    assert [f.frame_number for f, _ in seen] == list(range(1, n_frames + 1))
+    vw = hs.viewport
+    x0, y0 = int(np.ceil(vw.margin_x)), int(np.ceil(vw.margin_y))
+    for k, (frame, (status, png)) in enumerate(seen):
+        assert status == "ok" and png[0] == "ok"
+        assert frame.width == int(vw.width) and frame.height == int(vw.height)
+        rows = np.frombuffer(frame.image_data.bytes(), dtype=np.uint8).reshape(frame.height, frame.padded_bytes_per_row)
+        pixels = rows[:, :frame.unpadded_bytes_per_row].reshape(frame.height, frame.width, 4)
+        want = expected[k][y0:y0 + frame.height, x0:x0 + frame.width]
+        assert np.array_equal(pixels, want), f"frame {k + 1}"
+        # the PNG decodes to the same pixels
+        from PIL import Image
+        import io
+        assert np.array_equal(np.array(Image.open(io.BytesIO(png[1])).convert("RGBA")), want)
+    assert os.listdir(tmp_path) == []          # removed after successful decompression
+    hs.close(); r.close()

@@ -57,6 +57,9 @@ enum {
                                          clip-volume clipping gives; 0: only the attachment bounds restrict them */
     RH_OPTION_TIMING = 1,             /* 1: record HIP events around the binning phase and the tile kernel of every
                                          render pass (read with rh_device_drain_timings); default 0 */
+    RH_OPTION_STRIP_ROW0 = 2,         /* sort-first split of a large target over several devices: render passes touch */
+    RH_OPTION_STRIP_ROW1 = 3,         /* only pixel rows [ROW0, ROW1) (multiples of 32, or the target height); clears
+                                         included.  ROW1 = 0 (default) disables the restriction. */
 };
 
 #define RH_MAX_ATTRIBUTES 8

@@ -20,6 +20,7 @@ BUFFER_VERTEX, BUFFER_STORAGE, BUFFER_UNIFORM, BUFFER_COPY_DST, BUFFER_MAP_READ 
 TEXTURE_BINDING, TEXTURE_COPY_DST, TEXTURE_RENDER_ATTACHMENT, TEXTURE_COPY_SRC = 1, 2, 4, 8
 OPTION_CLIP_TO_VIEWPORT = 0
 OPTION_TIMING = 1
+OPTION_STRIP_ROW0, OPTION_STRIP_ROW1 = 2, 3
 COPY_BYTES_PER_ROW_ALIGNMENT = 256
 MAX_COLOR_TARGETS = 4
 

@@ -4,7 +4,7 @@
 #pragma once
 #include <stdint.h>
 
-#define RH_DEVICE_ABI_VERSION 3u
+#define RH_DEVICE_ABI_VERSION 4u
 #define RH_MODULE_MAGIC 0x52484d4fu   // "RHMO"
 
 #define RH_DEV_MAX_ATTRIBUTES 8
@@ -49,6 +49,7 @@ struct rh_draw_params {
     int32_t sc_x0, sc_y0, sc_x1, sc_y1;              // scissor rectangle in pixels [x0,x1) x [y0,y1)
     uint32_t width, height;                          // attachment size in pixels
     uint32_t tiles_x, tiles_y;
+    uint32_t tile_first;                             // index of the first tile this launch covers (strip rendering)
     uint32_t topology;
     uint32_t vertex_count, instance_count;
     uint32_t tpi;                                    // triangles per instance

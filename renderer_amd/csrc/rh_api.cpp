@@ -66,6 +66,7 @@ struct rh_device {
     uint32_t width = 0, height = 0;
     rh_texture* screen = nullptr;
     int clip_to_viewport = 1;
+    uint32_t strip_row0 = 0, strip_row1 = 0;       // sort-first strip restriction; row1 == 0: none
     std::string name;
     // scratch for binning
     Scratch ranges, block_sums, chunk_tmp, keys_a, vals_a, keys_b, vals_b, hist, tile_start, tile_end;
@@ -261,6 +262,11 @@ int rh_device_set_option(rh_device* dev, int option, int value) {
     if (!dev) return fail("rh_device_set_option: null device");
     if (option == RH_OPTION_CLIP_TO_VIEWPORT) { dev->clip_to_viewport = value ? 1 : 0; return 0; }
     if (option == RH_OPTION_TIMING) { dev->timing = value ? 1 : 0; return 0; }
+    if (option == RH_OPTION_STRIP_ROW0 || option == RH_OPTION_STRIP_ROW1) {
+        if (value < 0) return fail("rh_device_set_option: negative strip row");
+        (option == RH_OPTION_STRIP_ROW0 ? dev->strip_row0 : dev->strip_row1) = (uint32_t)value;
+        return 0;
+    }
     return fail("rh_device_set_option: unknown option %d", option);
 }
 
@@ -691,6 +697,16 @@ int execute_pass(rh_device* dev, const PassCmd& c) {
     p.width = W; p.height = H;
     p.tiles_x = (W + RH_TILE - 1) / RH_TILE; p.tiles_y = (H + RH_TILE - 1) / RH_TILE;
     const uint32_t n_tiles = p.tiles_x * p.tiles_y;
+    // sort-first strip: only tile rows [row0, row1) are rendered (and cleared) by this device
+    uint32_t tile_row0 = 0, tile_row1 = p.tiles_y;
+    if (dev->strip_row1 != 0) {
+        const uint32_t r0 = dev->strip_row0, r1 = std::min(dev->strip_row1, H);
+        if (r0 % RH_TILE || (r1 % RH_TILE && r1 != H) || r0 > r1) return fail("render pass: strip rows [%u, %u) are not multiples of %d", r0, r1, RH_TILE);
+        tile_row0 = r0 / RH_TILE; tile_row1 = (r1 + RH_TILE - 1) / RH_TILE;
+        p.sc_y0 = std::max(p.sc_y0, (int32_t)r0); p.sc_y1 = std::min(p.sc_y1, (int32_t)r1);
+    }
+    p.tile_first = tile_row0 * p.tiles_x;
+    const uint32_t n_launch_tiles = (tile_row1 - tile_row0) * p.tiles_x;
     p.topology = pl->topology;
     p.vertex_count = c.vertex_count; p.instance_count = c.instance_count;
     p.tpi = pl->topology == RH_TOPOLOGY_TRIANGLE_STRIP ? (c.vertex_count >= 3 ? c.vertex_count - 2 : 0) : c.vertex_count / 3;
@@ -753,8 +769,8 @@ int execute_pass(rh_device* dev, const PassCmd& c) {
     }
     ta.src_factor = pl->targets[0].src_factor; ta.dst_factor = pl->targets[0].dst_factor;
     if (timing_mark(dev)) return 1;
-    if (total > 0 || any_clear)
-        if (launch_module_kernel(pl->fs->tile[c.attachments.size() - 1], n_tiles, &ta, sizeof ta, s)) return 1;
+    if ((total > 0 || any_clear) && n_launch_tiles > 0)
+        if (launch_module_kernel(pl->fs->tile[c.attachments.size() - 1], n_launch_tiles, &ta, sizeof ta, s)) return 1;
     if (timing_mark(dev)) return 1;
 
     dev->stats.clusters = n_clusters; dev->stats.bin_entries = total;

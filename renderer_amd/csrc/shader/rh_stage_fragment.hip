@@ -216,7 +216,7 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a) {
 
     const rh_draw_params& p = a.p;
     const int tid = (int)threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const uint32_t tile = blockIdx.x;
+    const uint32_t tile = blockIdx.x + p.tile_first;
     const int ox = (int)(tile % p.tiles_x) * RH_TILE, oy = (int)(tile / p.tiles_x) * RH_TILE;
     const uint32_t start = a.tile_start[tile], end = a.tile_end[tile];
 

@@ -155,6 +155,11 @@ class Renderer:
     def set_clip_to_viewport(self, enabled):
         _ffi.check(_ffi.lib().rh_device_set_option(self.device, _ffi.OPTION_CLIP_TO_VIEWPORT, 1 if enabled else 0))
 
+    def set_strip(self, row0, row1):
+        """Sort-first split: this device renders (and clears) only pixel rows [row0, row1); (0, 0) disables."""
+        _ffi.check(_ffi.lib().rh_device_set_option(self.device, _ffi.OPTION_STRIP_ROW0, int(row0)))
+        _ffi.check(_ffi.lib().rh_device_set_option(self.device, _ffi.OPTION_STRIP_ROW1, int(row1)))
+
     def set_timing(self, enabled):
         _ffi.check(_ffi.lib().rh_device_set_option(self.device, _ffi.OPTION_TIMING, 1 if enabled else 0))
 

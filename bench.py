@@ -23,6 +23,19 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
 
 
+def pmc_traffic_bytes():
+    """HBM bytes per rh_tile_1 launch from the committed counter passes of this same command (tools/prof.sh: one
+    rocprofv3 --pmc run for FETCH_SIZE, one for WRITE_SIZE; both counters are in KiB).  FETCH_SIZE is doubled, the
+    gfx950 correction for its 64-B tally of 128-B read requests; counters cannot be collected from inside this
+    process, so the figure is the profiled one and is None when no profile of the default workload is present."""
+    path = os.path.join(ROOT, "profiles", "r01", "bench_c1_v3_pmc_avg_per_launch.json")
+    try:
+        k = json.load(open(path))["rh_tile_1"]
+        return (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -35,6 +48,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    default_workload = (args.quads, args.side, args.width, args.height) == (1_000_000, 16, 3840, 2160)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -101,6 +115,7 @@ def main():
         tile_ms = timings["tile_ms"] / max(1, timings["passes"])
         bin_ms = timings["bin_ms"] / max(1, timings["passes"])
         achieved = b_alg / (tile_ms * 1e-3) / 1e9 if tile_ms > 0 else 0.0
+        traffic = pmc_traffic_bytes() if default_workload else None
         out = {
             "metric": "instanced quads/s at 4K alpha-blend", "value": value, "unit": "quads/s",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -112,7 +127,7 @@ def main():
                        "parallelism": f"frame-parallel x{n_gpus}" if n_gpus > 1 else "single GPU",
                        "bin_entries": int(stats["bin_entries"]), "tile_px": int(stats["tile_size"])},
             "roofline": {"bound": "hbm", "kernel": "rh_tile_1", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": b_alg, "compulsory_bytes_per_launch": b_min,
                          "kernel_ms": tile_ms, "binning_ms": bin_ms,
                          "fragments_per_s": n_frag / (tile_ms * 1e-3) if tile_ms > 0 else 0.0},

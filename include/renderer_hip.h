@@ -233,12 +233,23 @@ void rh_compressor_destroy(rh_compressor* c);
  * (NULL for a frame without image data: then only the first three writes happen).  The buffer is retained until the
  * packet has been compressed. */
 int rh_compressor_write_packet(rh_compressor* c, uint32_t stream, const void* metadata, size_t metadata_len, rh_buffer* image);
-/* Compresses everything queued (all streams concurrently) and brings the compressed bytes to the host. */
+/* Starts compressing everything queued (all streams concurrently, on a HIP stream of the compressor's own that waits
+ * for the frames rendered so far) and returns while the last round of packets is still being compressed; the bytes of
+ * earlier rounds become ready.  This is the reference's hand-off to its worker threads (src/compressor.rs:64-69): the
+ * caller goes on rendering, and writes the ready bytes to the stream files meanwhile. */
+int rh_compressor_submit(rh_compressor* c);
+/* Compresses everything queued and waits: afterwards every byte is ready. */
 int rh_compressor_flush(rh_compressor* c);
 /* Bytes of `stream` ready to be read (the 7-byte frame header precedes the first block). */
 size_t rh_compressor_pending(rh_compressor* c, uint32_t stream);
 /* Moves up to `cap` ready bytes of `stream` into dst. */
 int rh_compressor_read(rh_compressor* c, uint32_t stream, void* dst, size_t cap, size_t* len);
+/* Zero-copy form of rh_compressor_read: *ptr / *len describe the first ready run of bytes of `stream` (pinned host
+ * memory owned by the compressor, NULL / 0 when nothing is ready); rh_compressor_consume releases the first n ready
+ * bytes.  A run stays valid until it is consumed; runs of different streams may be written out from different threads,
+ * peek and consume themselves are called from the compressor's thread. */
+int rh_compressor_peek(rh_compressor* c, uint32_t stream, const uint8_t** ptr, size_t* len);
+int rh_compressor_consume(rh_compressor* c, uint32_t stream, size_t n);
 /* Flushes and appends the LZ4F end mark to `stream` (LZ4F_compressEnd, when the reference drops the writer). */
 int rh_compressor_finish_stream(rh_compressor* c, uint32_t stream);
 /* Host-side LZ4 frame decoder.  Tolerates a truncated tail (src/decompressor.rs:216-235 stops at an unclean end):

@@ -36,12 +36,13 @@ class Compressor:
         out = C.c_void_p()
         _ffi.check(_ffi.lib().rh_compressor_create(renderer.device, n_streams, lz4_compression_level, C.byref(out)))
         self.handle = out
-        self.files = [open(os.path.join(directory, f"{self.timestamp}--{i}.sz"), "wb") for i in range(n_streams)]
+        self.files = [open(os.path.join(directory, f"{self.timestamp}--{i}.sz"), "wb", buffering=0) for i in range(n_streams)]
         self.queued = []            # frames whose packets are queued on the device (kept alive until compressed)
         self.frames_captured = 0
         self.frames_dropped = 0
         self.raw_video_size = 0
         self.compressed_size = 0
+        self._pool = None
 
     def compress_to_disk(self, video_frame):
         stream = (video_frame.frame_number - 1) % self.n_streams
@@ -56,27 +57,66 @@ class Compressor:
             self.frames_dropped += 1
         self.queued.append(video_frame)
         if len(self.queued) >= min(self.n_streams, self.max_frames_queued):
-            self.flush()
+            self.submit()
 
-    def flush(self):
-        """Compresses all queued packets (streams run concurrently on the GPU) and appends the bytes to the files."""
-        _ffi.check(_ffi.lib().rh_compressor_flush(self.handle))
+    def _release_queued(self):
         for frame in self.queued:
             frame.drop()                # returns the frame's bytes to the capture budget (reference src/video_frame.rs:70-77)
         self.queued = []
+
+    def submit(self):
+        """Hands the queued packets to the GPU (streams run concurrently there) and, while they are being compressed,
+        appends the bytes of the previous hand-off to the files -- the reference's worker threads do both beside the
+        render thread (src/compressor.rs:100-131)."""
+        _ffi.check(_ffi.lib().rh_compressor_submit(self.handle))
+        self._release_queued()          # the library keeps the capture buffers alive until they are compressed
+        self._drain()
+
+    def flush(self):
+        """Compresses all queued packets, waits for them and appends the bytes to the files."""
+        _ffi.check(_ffi.lib().rh_compressor_flush(self.handle))
+        self._release_queued()
         self._drain()
 
     def _drain(self):
+        """Writes every ready byte to its stream file straight from the library's pinned memory; the files are written
+        by a few threads at once (file writes release the interpreter lock)."""
         L = _ffi.lib()
-        for i, f in enumerate(self.files):
-            n = L.rh_compressor_pending(self.handle, i)
-            if n == 0:
-                continue
-            buf = (C.c_uint8 * n)()
-            got = C.c_size_t()
-            _ffi.check(L.rh_compressor_read(self.handle, i, buf, n, C.byref(got)))
-            f.write(memoryview(buf)[:got.value])
-            self.compressed_size += got.value
+        runs = []
+        for i in range(self.n_streams):
+            # peek exposes one run at a time: consume after the write, then look again
+            ptr, n = C.c_void_p(), C.c_size_t()
+            _ffi.check(L.rh_compressor_peek(self.handle, i, C.byref(ptr), C.byref(n)))
+            if n.value:
+                runs.append((i, ptr.value, n.value))
+        while runs:
+            if len(runs) > 1 and sum(n for _, _, n in runs) > (8 << 20):
+                list(self._writers().map(self._write_run, runs))
+            else:
+                for run in runs:
+                    self._write_run(run)
+            nxt = []
+            for i, _, n in runs:
+                _ffi.check(L.rh_compressor_consume(self.handle, i, n))
+                self.compressed_size += n
+                ptr, m = C.c_void_p(), C.c_size_t()
+                _ffi.check(L.rh_compressor_peek(self.handle, i, C.byref(ptr), C.byref(m)))
+                if m.value:
+                    nxt.append((i, ptr.value, m.value))
+            runs = nxt
+
+    def _write_run(self, run):
+        i, ptr, n = run
+        view = memoryview((C.c_uint8 * n).from_address(ptr)).cast("B")
+        done = 0
+        while done < n:                 # an unbuffered file may take less than it is given
+            done += self.files[i].write(view[done:])
+
+    def _writers(self):
+        if self._pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1))
+        return self._pool
 
     def finish(self):
         """Waits for everything queued, writes the end marks and closes the files (reference src/compressor.rs:46-62)."""
@@ -88,6 +128,9 @@ class Compressor:
         self._drain()
         for f in self.files:
             f.close()
+        if self._pool is not None:
+            self._pool.shutdown()
+            self._pool = None
         _ffi.lib().rh_compressor_destroy(self.handle)
         self.handle = None
 

@@ -838,16 +838,30 @@ int rh_device_last_pass_stats(rh_device* dev, rh_pass_stats* out) {
 #include "rh_codec.h"
 #include <deque>
 
+// Compressed bytes wait for the reader in segments: either a small owned vector (frame header, end mark) or a slice
+// of a pinned round buffer that the device-to-host copies filled.  A round buffer is recycled when its last slice has
+// been consumed.
 struct rh_compressor {
     rh_device* dev = nullptr;
     uint32_t n_streams = 0;
+    hipStream_t stream = nullptr;                    // compression runs beside rendering
+    hipEvent_t frames_ready = nullptr;               // recorded on the device's stream when a round is submitted
     rh_lz4_stream_state* d_states = nullptr;
     struct Packet { std::vector<uint8_t> meta; rh_buffer* image = nullptr; };
-    std::vector<std::deque<Packet>> queue;           // per stream
-    std::vector<std::vector<uint8_t>> ready;         // per stream: compressed bytes not yet read
-    // per-round device/host scratch
+    std::vector<std::deque<Packet>> queue;           // per stream: not yet submitted
+    struct RoundBuf { void* h = nullptr; size_t cap = 0; size_t live = 0; };
+    std::vector<RoundBuf> bufs;
+    struct Segment { const uint8_t* ptr = nullptr; size_t len = 0; int buf = -1; std::vector<uint8_t> own; };
+    std::vector<std::deque<Segment>> ready;          // per stream: compressed bytes not yet consumed
+    // the round in flight
+    struct Round {
+        bool active = false;
+        std::vector<uint32_t> job_stream;
+        std::vector<size_t> out_off, out_cap;
+        std::vector<rh_buffer*> images;
+    } round;
     Scratch d_jobs, d_stage, d_out, d_lens;
-    void* h_pinned = nullptr; size_t h_pinned_cap = 0;
+    unsigned long long* h_lens = nullptr; size_t h_lens_cap = 0;
 };
 
 namespace {
@@ -855,14 +869,23 @@ namespace {
 size_t lz4f_bound(size_t n) { return n + 4 * (n / 65536 + 1); }      // every block stored + one header each
 size_t align16(size_t n) { return (n + 15) & ~(size_t)15; }
 
-int compressor_round(rh_compressor* c) {
+void push_owned(rh_compressor* c, uint32_t stream, const uint8_t* p, size_t n) {
+    rh_compressor::Segment sg; sg.own.assign(p, p + n);
+    c->ready[stream].push_back(std::move(sg));
+    rh_compressor::Segment& back = c->ready[stream].back();
+    back.ptr = back.own.data(); back.len = n;
+}
+
+// Starts compressing the first queued packet of every stream (one workgroup per stream).  Returns at once; the result
+// is collected by compressor_complete_round.
+int compressor_submit_round(rh_compressor* c) {
     rh_device* dev = c->dev;
-    hipStream_t s = dev->stream;
+    rh_compressor::Round& R = c->round;
     std::vector<rh_lz4_job> jobs;
-    std::vector<uint32_t> job_stream;
-    std::vector<size_t> stage_off, out_off, out_cap;
+    std::vector<size_t> stage_off;
     std::vector<uint8_t> stage;
     size_t out_total = 0;
+    R.job_stream.clear(); R.out_off.clear(); R.out_cap.clear(); R.images.clear();
     for (uint32_t st = 0; st < c->n_streams; st++) {
         if (c->queue[st].empty()) continue;
         const rh_compressor::Packet& pk = c->queue[st].front();
@@ -876,61 +899,99 @@ int compressor_round(rh_compressor* c) {
         memcpy(stage.data() + base + 32, pk.meta.data(), pk.meta.size());
         stage_off.push_back(base);
         const size_t cap = align16(lz4f_bound(8) * 2 + lz4f_bound(pk.meta.size()) + lz4f_bound(image_len));
-        out_off.push_back(out_total); out_cap.push_back(cap);
+        R.out_off.push_back(out_total); R.out_cap.push_back(cap);
         out_total += cap;
-        job_stream.push_back(st);
+        R.job_stream.push_back(st);
     }
-    const uint32_t n = (uint32_t)job_stream.size();
+    const uint32_t n = (uint32_t)R.job_stream.size();
     if (n == 0) return 0;
     if (c->d_jobs.ensure(n * sizeof(rh_lz4_job)) || c->d_stage.ensure(stage.size()) || c->d_out.ensure(out_total) || c->d_lens.ensure(n * 8)) return 1;
+    if (n > c->h_lens_cap) {
+        if (c->h_lens) (void)hipHostFree(c->h_lens);
+        c->h_lens = nullptr; c->h_lens_cap = 0;
+        RH_HIP(hipHostMalloc((void**)&c->h_lens, (size_t)n * 2 * 8, hipHostMallocDefault));
+        c->h_lens_cap = (size_t)n * 2;
+    }
     jobs.resize(n);
     for (uint32_t j = 0; j < n; j++) {
-        const rh_compressor::Packet& pk = c->queue[job_stream[j]].front();
+        rh_compressor::Packet& pk = c->queue[R.job_stream[j]].front();
         rh_lz4_job& jb = jobs[j];
         memset(&jb, 0, sizeof jb);
-        jb.stream = job_stream[j];
+        jb.stream = R.job_stream[j];
         const uint8_t* st = c->d_stage.as<uint8_t>() + stage_off[j];
         jb.write_ptr[0] = st; jb.write_len[0] = 8;
         jb.write_ptr[1] = st + 16; jb.write_len[1] = 8;
         jb.write_ptr[2] = st + 32; jb.write_len[2] = pk.meta.size();
         jb.n_writes = 3;
         if (pk.image) { jb.write_ptr[3] = (const uint8_t*)pk.image->dptr; jb.write_len[3] = pk.image->size; jb.n_writes = 4; }
-        jb.out = c->d_out.as<uint8_t>() + out_off[j];
+        jb.out = c->d_out.as<uint8_t>() + R.out_off[j];
         jb.out_len = c->d_lens.as<unsigned long long>() + j;
+        R.images.push_back(pk.image);                 // stays retained until the round completes
+        c->queue[R.job_stream[j]].pop_front();
     }
-    RH_HIP(hipMemcpyAsync(c->d_stage.ptr, stage.data(), stage.size(), hipMemcpyHostToDevice, s));
-    RH_HIP(hipMemcpyAsync(c->d_jobs.ptr, jobs.data(), n * sizeof(rh_lz4_job), hipMemcpyHostToDevice, s));
-    RH_HIP(hipStreamSynchronize(s));        // staging vectors go out of scope below; keep the copies simple and safe
-    int rc = rhk::lz4f_compress_launch(c->d_jobs.as<rh_lz4_job>(), n, c->d_states, s);
+    // the captured frames are produced on the device's stream
+    RH_HIP(hipEventRecord(c->frames_ready, dev->stream));
+    RH_HIP(hipStreamWaitEvent(c->stream, c->frames_ready, 0));
+    RH_HIP(hipMemcpyAsync(c->d_stage.ptr, stage.data(), stage.size(), hipMemcpyHostToDevice, c->stream));
+    RH_HIP(hipMemcpyAsync(c->d_jobs.ptr, jobs.data(), n * sizeof(rh_lz4_job), hipMemcpyHostToDevice, c->stream));
+    RH_HIP(hipStreamSynchronize(c->stream));        // the pageable staging vectors go out of scope below
+    int rc = rhk::lz4f_compress_launch(c->d_jobs.as<rh_lz4_job>(), n, c->d_states, c->stream);
     if (rc) return fail("rh_compressor: kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
-    std::vector<unsigned long long> lens(n);
-    RH_HIP(hipMemcpyAsync(lens.data(), c->d_lens.ptr, n * 8, hipMemcpyDeviceToHost, s));
-    RH_HIP(hipStreamSynchronize(s));
-    // only the compressed bytes cross PCIe
+    RH_HIP(hipMemcpyAsync(c->h_lens, c->d_lens.ptr, n * 8, hipMemcpyDeviceToHost, c->stream));
+    R.active = true;
+    return 0;
+}
+
+// Waits for the round in flight and brings exactly its compressed bytes to the host (only they cross PCIe).
+int compressor_complete_round(rh_compressor* c) {
+    rh_compressor::Round& R = c->round;
+    if (!R.active) return 0;
+    R.active = false;
+    const uint32_t n = (uint32_t)R.job_stream.size();
+    RH_HIP(hipStreamSynchronize(c->stream));
     size_t total = 0;
-    for (uint32_t j = 0; j < n; j++) { if (lens[j] > out_cap[j]) return fail("rh_compressor: stream %u overflowed its output area", job_stream[j]); total += lens[j]; }
-    if (total > c->h_pinned_cap) {
-        if (c->h_pinned) (void)hipHostFree(c->h_pinned);
-        c->h_pinned = nullptr; c->h_pinned_cap = 0;
-        RH_HIP(hipHostMalloc(&c->h_pinned, total + total / 2 + 4096, hipHostMallocDefault));
-        c->h_pinned_cap = total + total / 2 + 4096;
+    for (uint32_t j = 0; j < n; j++) {
+        if (c->h_lens[j] > R.out_cap[j]) return fail("rh_compressor: stream %u overflowed its output area", R.job_stream[j]);
+        total += c->h_lens[j];
     }
+    int bi = -1;
+    for (size_t i = 0; i < c->bufs.size(); i++) if (c->bufs[i].live == 0 && c->bufs[i].cap >= total) { bi = (int)i; break; }
+    if (bi < 0) {
+        for (size_t i = 0; i < c->bufs.size(); i++) if (c->bufs[i].live == 0) { bi = (int)i; break; }
+        if (bi < 0) { c->bufs.emplace_back(); bi = (int)c->bufs.size() - 1; }
+        rh_compressor::RoundBuf& b = c->bufs[bi];
+        if (b.h) (void)hipHostFree(b.h);
+        b.h = nullptr; b.cap = 0;
+        const size_t want = total + total / 4 + 4096;
+        RH_HIP(hipHostMalloc(&b.h, want, hipHostMallocDefault));
+        b.cap = want;
+    }
+    rh_compressor::RoundBuf& b = c->bufs[bi];
     size_t off = 0;
     for (uint32_t j = 0; j < n; j++) {
-        if (lens[j]) RH_HIP(hipMemcpyAsync((uint8_t*)c->h_pinned + off, c->d_out.as<uint8_t>() + out_off[j], lens[j], hipMemcpyDeviceToHost, s));
-        off += lens[j];
+        const size_t len = (size_t)c->h_lens[j];
+        if (len) RH_HIP(hipMemcpyAsync((uint8_t*)b.h + off, c->d_out.as<uint8_t>() + R.out_off[j], len, hipMemcpyDeviceToHost, c->stream));
+        off += len;
     }
-    RH_HIP(hipStreamSynchronize(s));
+    RH_HIP(hipStreamSynchronize(c->stream));
     off = 0;
     for (uint32_t j = 0; j < n; j++) {
-        std::vector<uint8_t>& r = c->ready[job_stream[j]];
-        r.insert(r.end(), (uint8_t*)c->h_pinned + off, (uint8_t*)c->h_pinned + off + lens[j]);
-        off += lens[j];
-        rh_compressor::Packet& pk = c->queue[job_stream[j]].front();
-        if (pk.image) rh_buffer_release(pk.image);
-        c->queue[job_stream[j]].pop_front();
+        const size_t len = (size_t)c->h_lens[j];
+        if (len) {
+            rh_compressor::Segment sg; sg.ptr = (const uint8_t*)b.h + off; sg.len = len; sg.buf = bi;
+            c->ready[R.job_stream[j]].push_back(std::move(sg));
+            b.live++;
+        }
+        off += len;
+        if (R.images[j]) rh_buffer_release(R.images[j]);
     }
+    R.images.clear();
     return 0;
+}
+
+bool compressor_queue_empty(const rh_compressor* c) {
+    for (const auto& q : c->queue) if (!q.empty()) return false;
+    return true;
 }
 
 } // namespace
@@ -944,13 +1005,21 @@ int rh_compressor_create(rh_device* dev, uint32_t n_streams, int level, rh_compr
     rh_compressor* c = new rh_compressor();
     c->dev = dev; c->n_streams = n_streams;
     hipError_t e = hipMalloc((void**)&c->d_states, (size_t)n_streams * sizeof(rh_lz4_stream_state));
-    if (e != hipSuccess) { delete c; return fail("rh_compressor_create: %s", hipGetErrorString(e)); }
-    e = hipMemsetAsync(c->d_states, 0, (size_t)n_streams * sizeof(rh_lz4_stream_state), dev->stream);
-    if (e != hipSuccess) { (void)hipFree(c->d_states); delete c; return fail("rh_compressor_create: %s", hipGetErrorString(e)); }
+    if (e == hipSuccess) e = hipMemsetAsync(c->d_states, 0, (size_t)n_streams * sizeof(rh_lz4_stream_state), dev->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(dev->stream);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->frames_ready, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        if (c->frames_ready) (void)hipEventDestroy(c->frames_ready);
+        if (c->stream) (void)hipStreamDestroy(c->stream);
+        if (c->d_states) (void)hipFree(c->d_states);
+        delete c;
+        return fail("rh_compressor_create: %s", hipGetErrorString(e));
+    }
     c->queue.resize(n_streams); c->ready.resize(n_streams);
     // LZ4F_compressBegin: magic, FLG (version 01, block-linked), BD (64 KiB blocks), header checksum
     static const uint8_t header[7] = { 0x04, 0x22, 0x4d, 0x18, 0x40, 0x40, 0xc0 };
-    for (auto& r : c->ready) r.assign(header, header + 7);
+    for (uint32_t i = 0; i < n_streams; i++) push_owned(c, i, header, 7);
     device_retain(dev);
     *out = c;
     return 0;
@@ -960,12 +1029,17 @@ void rh_compressor_destroy(rh_compressor* c) {
     if (!c) return;
     rh_device* dev = c->dev;
     (void)hipSetDevice(dev->ordinal);
+    (void)hipStreamSynchronize(c->stream);
     (void)hipStreamSynchronize(dev->stream);
     for (auto& q : c->queue) for (auto& pk : q) if (pk.image) rh_buffer_release(pk.image);
+    for (rh_buffer* b : c->round.images) if (b) rh_buffer_release(b);
     Scratch* all[] = { &c->d_jobs, &c->d_stage, &c->d_out, &c->d_lens };
     for (Scratch* s : all) s->release();
-    if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    for (auto& b : c->bufs) if (b.h) (void)hipHostFree(b.h);
+    if (c->h_lens) (void)hipHostFree(c->h_lens);
     if (c->d_states) (void)hipFree(c->d_states);
+    (void)hipEventDestroy(c->frames_ready);
+    (void)hipStreamDestroy(c->stream);
     delete c;
     device_release(dev);
 }
@@ -982,29 +1056,66 @@ int rh_compressor_write_packet(rh_compressor* c, uint32_t stream, const void* me
     return 0;
 }
 
-int rh_compressor_flush(rh_compressor* c) {
-    if (!c) return fail("rh_compressor_flush: null compressor");
+int rh_compressor_submit(rh_compressor* c) {
+    if (!c) return fail("rh_compressor_submit: null compressor");
     if (set_device(c->dev)) return 1;
     for (;;) {
-        bool any = false;
-        for (auto& q : c->queue) any = any || !q.empty();
-        if (!any) return 0;
-        if (compressor_round(c)) return 1;
+        if (compressor_complete_round(c)) return 1;
+        if (compressor_queue_empty(c)) return 0;
+        if (compressor_submit_round(c)) return 1;
+        if (compressor_queue_empty(c)) return 0;      // the last round stays in flight
     }
 }
 
+int rh_compressor_flush(rh_compressor* c) {
+    if (!c) return fail("rh_compressor_flush: null compressor");
+    if (rh_compressor_submit(c)) return 1;
+    return compressor_complete_round(c);
+}
+
 size_t rh_compressor_pending(rh_compressor* c, uint32_t stream) {
-    return (c && stream < c->n_streams) ? c->ready[stream].size() : 0;
+    if (!c || stream >= c->n_streams) return 0;
+    size_t n = 0;
+    for (const auto& sg : c->ready[stream]) n += sg.len;
+    return n;
+}
+
+int rh_compressor_peek(rh_compressor* c, uint32_t stream, const uint8_t** ptr, size_t* len) {
+    if (!c || !ptr || !len) return fail("rh_compressor_peek: bad argument");
+    if (stream >= c->n_streams) return fail("rh_compressor_peek: stream %u out of range", stream);
+    if (c->ready[stream].empty()) { *ptr = nullptr; *len = 0; return 0; }
+    *ptr = c->ready[stream].front().ptr; *len = c->ready[stream].front().len;
+    return 0;
+}
+
+int rh_compressor_consume(rh_compressor* c, uint32_t stream, size_t n) {
+    if (!c) return fail("rh_compressor_consume: null compressor");
+    if (stream >= c->n_streams) return fail("rh_compressor_consume: stream %u out of range", stream);
+    while (n) {
+        if (c->ready[stream].empty()) return fail("rh_compressor_consume: more bytes than are ready");
+        rh_compressor::Segment& sg = c->ready[stream].front();
+        const size_t k = std::min(n, sg.len);
+        sg.ptr += k; sg.len -= k; n -= k;
+        if (sg.len == 0) {
+            if (sg.buf >= 0) c->bufs[sg.buf].live--;
+            c->ready[stream].pop_front();
+        }
+    }
+    return 0;
 }
 
 int rh_compressor_read(rh_compressor* c, uint32_t stream, void* dst, size_t cap, size_t* len) {
     if (!c || !len || (!dst && cap)) return fail("rh_compressor_read: bad argument");
     if (stream >= c->n_streams) return fail("rh_compressor_read: stream %u out of range", stream);
-    std::vector<uint8_t>& r = c->ready[stream];
-    const size_t n = std::min(cap, r.size());
-    if (n) memcpy(dst, r.data(), n);
-    r.erase(r.begin(), r.begin() + n);
-    *len = n;
+    size_t done = 0;
+    while (done < cap && !c->ready[stream].empty()) {
+        const rh_compressor::Segment& sg = c->ready[stream].front();
+        const size_t k = std::min(cap - done, sg.len);
+        memcpy((uint8_t*)dst + done, sg.ptr, k);
+        done += k;
+        if (rh_compressor_consume(c, stream, k)) return 1;
+    }
+    *len = done;
     return 0;
 }
 
@@ -1013,7 +1124,7 @@ int rh_compressor_finish_stream(rh_compressor* c, uint32_t stream) {
     if (stream >= c->n_streams) return fail("rh_compressor_finish_stream: stream %u out of range", stream);
     if (rh_compressor_flush(c)) return 1;
     static const uint8_t end_mark[4] = { 0, 0, 0, 0 };
-    c->ready[stream].insert(c->ready[stream].end(), end_mark, end_mark + 4);
+    push_owned(c, stream, end_mark, 4);
     return 0;
 }
 

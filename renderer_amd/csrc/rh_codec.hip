@@ -4,11 +4,17 @@
 // The reference compresses captured frames on CPU worker threads, one LZ4F stream per thread/file
 // (reference src/compressor.rs:88-144, via the lzzzz crate = liblz4): preferences level 0, auto-flush, block-linked,
 // 64 KiB blocks, no checksums; every Write::write_all is one LZ4F_compressUpdate.  A stream's bytes depend only on its
-// own write sequence, so streams are independent -- that is the parallelism used here: each stream's state (hash
-// table, 64 KiB dictionary, offsets) lives in device memory and a workgroup replays the sequential LZ4 "fast"
-// algorithm for its stream with the current 64 KiB block, the 64 KiB of history before it and the hash table resident
-// in LDS.  The wave's lanes cooperate on the data-parallel parts (block loads, match-length counting, literal copies,
-// dictionary saves); the match search itself is inherently serial and runs wave-uniformly.
+// own write sequence, so streams are independent: each stream's state (hash table, 64 KiB dictionary, offsets) lives
+// in device memory and one wavefront replays the LZ4 "fast" algorithm for its stream with the current 64 KiB block,
+// the 64 KiB of history before it and the hash table resident in LDS.
+//
+// The match search of LZ4 is a sequential walk (position, hash, table look-up, table insert, compare, advance by a
+// step that grows with the number of misses).  The walk without a match is known in advance, so the 64 lanes evaluate
+// the next 64 positions of it at once: every lane hashes its position and takes as candidate the closest earlier lane
+// of the batch with the same hash (that lane's insert would have been seen by the sequential walk) or else the table
+// entry; the first lane whose candidate passes the tests is where the sequential walk would have stopped, and exactly
+// the inserts of the lanes up to it are applied.  Match-length counting, the backward catch-up, literal copies, block
+// loads and dictionary saves are lane-parallel as well; the token bookkeeping between matches is wave-uniform.
 //
 // The output is byte-identical to liblz4 1.9.x for the same write sequence (LZ4_compress_fast_continue with
 // acceleration 1, byU32 table, 64-bit hash5; LZ4_saveDict after every update; LZ4_renormDictT).
@@ -23,43 +29,53 @@ constexpr int MINMATCH = 4, LASTLITERALS = 5, MFLIMIT = 12, LZ4_MINLENGTH = MFLI
 constexpr int HASHLOG = 12, SKIP_TRIGGER = 6;
 constexpr uint32_t DISTANCE_MAX = 65535u, ML_MASK = 15u, RUN_MASK = 15u;
 constexpr uint32_t BLOCK_UNCOMPRESSED_FLAG = 0x80000000u;
-constexpr int CUR = KB64;                     // byte offset of the current block inside `buf`
+constexpr uint32_t CUR = KB64;                // virtual offset of the current block
+constexpr uint32_t RING_DWORDS = 2 * KB64 / 4;
 
-// LDS: [ 64 KiB history | 64 KiB current block + 16 B slack ] followed by the hash table.  History byte at distance d
-// before the block is buf[CUR - d], so a match index maps to one flat offset whether it lies in the dictionary, in the
-// previous blocks of the same write, or in the current block.
+// LDS: a 128 KiB ring of bytes and the hash table.  Code addresses the ring with *virtual* offsets: the current block
+// starts at CUR, the history byte at distance d before the block is at CUR - d, so a match index maps to one flat offset
+// whether it lies in the dictionary, in the previous blocks of the same write, or in the current block.  The byte at
+// virtual offset v is stored at (v + rot) mod 128 KiB; after a full 64 KiB block `rot` advances by 64 KiB, which turns
+// the block into the history of the next one without moving a byte.
 struct Lds {
-    uint8_t buf[2 * KB64 + 16];
+    uint32_t ring[RING_DWORDS];
     uint32_t hash[1 << HASHLOG];
+};
+
+struct Ring {
+    const uint32_t* w;
+    uint32_t rot;
+    __device__ __forceinline__ uint32_t rd32(uint32_t v) const {
+        const uint32_t a = v + rot, i = (a >> 2) & (RING_DWORDS - 1u);
+        return __builtin_amdgcn_alignbyte(w[(i + 1u) & (RING_DWORDS - 1u)], w[i], a & 3u);
+    }
+    __device__ __forceinline__ uint64_t rd64(uint32_t v) const {
+        const uint32_t a = v + rot, i = (a >> 2) & (RING_DWORDS - 1u), s = a & 3u;
+        const uint32_t x = w[i], y = w[(i + 1u) & (RING_DWORDS - 1u)], z = w[(i + 2u) & (RING_DWORDS - 1u)];
+        return (uint64_t)__builtin_amdgcn_alignbyte(y, x, s) | ((uint64_t)__builtin_amdgcn_alignbyte(z, y, s) << 32);
+    }
+    __device__ __forceinline__ uint32_t byte(uint32_t v) const {
+        const uint32_t a = (v + rot) & (2u * KB64 - 1u);
+        return reinterpret_cast<const uint8_t*>(w)[a];
+    }
+    __device__ __forceinline__ uint32_t hash5(uint32_t v) const {
+        const uint64_t prime5bytes = 889523592379ULL;
+        return (uint32_t)(((rd64(v) << 24) * prime5bytes) >> (64 - HASHLOG));
+    }
 };
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
-__device__ __forceinline__ uint32_t rd32(const uint8_t* buf, uint32_t off) {
-    const uint32_t* w = reinterpret_cast<const uint32_t*>(buf);
-    const uint32_t i = off >> 2;
-    return __builtin_amdgcn_alignbyte(w[i + 1], w[i], off & 3u);
-}
-__device__ __forceinline__ uint64_t rd64(const uint8_t* buf, uint32_t off) {
-    const uint32_t* w = reinterpret_cast<const uint32_t*>(buf);
-    const uint32_t i = off >> 2, s = off & 3u;
-    const uint32_t a = w[i], b = w[i + 1], c = w[i + 2];
-    return (uint64_t)__builtin_amdgcn_alignbyte(b, a, s) | ((uint64_t)__builtin_amdgcn_alignbyte(c, b, s) << 32);
-}
-__device__ __forceinline__ uint32_t hash5(const uint8_t* buf, uint32_t off) {
-    const uint64_t prime5bytes = 889523592379ULL;
-    return (uint32_t)(((rd64(buf, off) << 24) * prime5bytes) >> (64 - HASHLOG));
-}
-
-// Number of equal bytes of buf[ip..] and buf[match..], stopping at `limit` (an offset bounding ip).  256 bytes per step.
-__device__ __forceinline__ uint32_t count_match(const uint8_t* buf, uint32_t ip, uint32_t match, uint32_t limit, int lane) {
+// Number of equal bytes of ring[ip..] and ring[match..], stopping at `limit` (a virtual offset bounding ip).  256 bytes
+// per step.
+__device__ __forceinline__ uint32_t count_match(const Ring& R, uint32_t ip, uint32_t match, uint32_t limit, int lane) {
     uint32_t n = 0;
     for (;;) {
         const uint32_t p = ip + n + (uint32_t)lane * 4u;
         uint32_t avail = p < limit ? limit - p : 0u; if (avail > 4u) avail = 4u;
         uint32_t same = 0;
         if (avail) {
-            const uint32_t d = rd32(buf, p) ^ rd32(buf, match + n + (uint32_t)lane * 4u);
+            const uint32_t d = R.rd32(p) ^ R.rd32(match + n + (uint32_t)lane * 4u);
             same = d ? (uint32_t)__builtin_ctz(d) >> 3 : 4u;
             if (same > avail) same = avail;
         }
@@ -72,69 +88,156 @@ __device__ __forceinline__ uint32_t count_match(const uint8_t* buf, uint32_t ip,
     }
 }
 
-// Cooperative copy of n bytes from LDS to global memory.
-__device__ __forceinline__ void copy_out(uint8_t* dst, const uint8_t* src, uint32_t n, int lane) {
-    for (uint32_t i = (uint32_t)lane; i < n; i += 64u) dst[i] = src[i];
+// Cooperative copy of n bytes from the ring (virtual offset v) to global memory: bytes up to the first 4-byte boundary
+// of dst, then whole dwords, then the tail.
+__device__ __forceinline__ void copy_out(uint8_t* dst, const Ring& R, uint32_t v, uint32_t n, int lane) {
+    uint32_t head = (uint32_t)((4u - ((uintptr_t)dst & 3u)) & 3u);
+    if (head > n) head = n;
+    if ((uint32_t)lane < head) dst[lane] = (uint8_t)R.byte(v + (uint32_t)lane);
+    const uint32_t words = (n - head) >> 2;
+    uint32_t* d32 = reinterpret_cast<uint32_t*>(dst + head);
+    for (uint32_t i = (uint32_t)lane; i < words; i += 64u) d32[i] = R.rd32(v + head + 4u * i);
+    const uint32_t done = head + 4u * words;
+    if (done + (uint32_t)lane < n) dst[done + lane] = (uint8_t)R.byte(v + done + (uint32_t)lane);
 }
 
 struct Stream {
     uint32_t current_offset;
-    uint32_t dict_size;       // bytes of valid history held at the end of the history half of `buf`
+    uint32_t dict_size;       // bytes of valid history held before the block
 };
 
-// LZ4_compress_generic (limitedOutput, byU32) on the block cur = buf[CUR .. CUR + n).  `ext_dict` selects the
+// Distance walked by the match search after k misses: it advances by 1 for the first 65 positions, then by
+// (63 + j) >> 6 after the j-th miss (LZ4: step = searchMatchNb++ >> skipTrigger, searchMatchNb starting at 64).
+__device__ __forceinline__ uint32_t walk(uint32_t k) {
+    if (k == 0u) return 0u;
+    const uint32_t m = 62u + k, q = m >> 6, r = m & 63u;
+    return 1u + 32u * q * (q - 1u) + q * (r + 1u);
+}
+
+// LZ4_compress_generic (limitedOutput, byU32) on the block [CUR, CUR + n) of the ring.  `ext_dict` selects the
 // usingExtDict rules (first block of a write; history = saved dictionary) against withPrefix64k (later blocks of the
 // same write).  Returns the compressed size, or 0 when it does not fit in max_out bytes.
-__device__ uint32_t compress_block(Lds& L, Stream& st, uint32_t n, uint8_t* out, uint32_t max_out, bool ext_dict, bool dict_small, int lane) {
-    const uint8_t* buf = L.buf;
+//
+// The sequential algorithm between two matches is: [insert ip-2; test-and-insert ip] (after a match) or [insert the
+// block's first byte] (at the start), then the miss walk from the next position.  One round evaluates 64 consecutive
+// steps of that sequence: the `pre` leading lanes of the first round take the special positions, the others the walk.
+__device__ uint32_t compress_block(Lds& L, const Ring& R, Stream& st, uint32_t n, uint8_t* out, uint32_t max_out, bool ext_dict,
+                                   bool dict_small, int lane) {
     const uint32_t start_index = st.current_offset;
     const uint32_t dict_size = st.dict_size;
-    // index -> flat offset: off = index - start_index + CUR
-    const uint32_t bias = (uint32_t)CUR - start_index;
+    // index -> virtual offset: off = index - start_index + CUR
+    const uint32_t bias = CUR - start_index;
     const uint32_t prefix_idx_limit = start_index - dict_size;
-    // Flat offset of the first reachable history byte.  Within one write the prefix can be longer than the 64 KiB held
+    // Virtual offset of the first reachable history byte.  Within one write the prefix can be longer than the 64 KiB held
     // here, but a match never reaches further back than 65535 bytes before the block (offsets are at most 65535 and
     // the catch-up loop stops at the block's first byte), so clamping does not change any decision.
-    const uint32_t dict_start = (uint32_t)CUR - (dict_size < KB64 ? dict_size : KB64);
-    const uint32_t iend = (uint32_t)CUR + n;
+    const uint32_t dict_start = CUR - (dict_size < KB64 ? dict_size : KB64);
+    const uint32_t iend = CUR + n;
     const uint32_t mflimit_plus_one = iend - MFLIMIT + 1;
     const uint32_t matchlimit = iend - LASTLITERALS;
+    const unsigned long long below = (1ull << lane) - 1ull;                 // lanes before this one
+    const unsigned long long above = ~((2ull << lane) - 1ull);              // lanes after this one
     uint32_t ip = CUR, anchor = CUR;
     uint32_t op = 0;                                                        // bytes written to `out`
-    uint32_t low_limit = ext_dict ? (uint32_t)CUR : dict_start;
-    uint32_t match = 0, token_pos = 0, token = 0, forward_h;
+    uint32_t low_limit = ext_dict ? CUR : dict_start;
+    uint32_t match = 0, token_pos = 0, token = 0;
+    uint32_t pre = 1;                                                       // 1: block start, 2: after a match
 
     st.dict_size += n;
     st.current_offset += n;
 
     if ((int)n < LZ4_MINLENGTH) goto last_literals;
 
-    if (lane == 0) L.hash[hash5(buf, ip)] = ip - bias;
-    ip++; forward_h = hash5(buf, ip);
-
     for (;;) {
-        {   uint32_t forward_ip = ip;
-            uint32_t step = 1, search_match_nb = 1u << SKIP_TRIGGER;
-            for (;;) {
-                const uint32_t h = forward_h;
-                const uint32_t current = forward_ip - bias;
-                const uint32_t match_index = uni(L.hash[h]);
-                ip = forward_ip;
-                forward_ip += step;
-                step = (search_match_nb++ >> SKIP_TRIGGER);
-                if (forward_ip > mflimit_plus_one) goto last_literals;
-                match = match_index + bias;
-                if (ext_dict) low_limit = match_index < start_index ? dict_start : (uint32_t)CUR;
-                forward_h = hash5(buf, forward_ip);
-                if (lane == 0) L.hash[h] = current;
-                if (dict_small && match_index < prefix_idx_limit) continue;
-                if (match_index + DISTANCE_MAX < current) continue;
-                if (uni(rd32(buf, match)) == uni(rd32(buf, ip))) break;
+        // ---- match search
+        bool found = false, immediate = false;
+        {   const uint32_t w0 = ip + 1u;                                    // the miss walk starts behind ip
+            for (uint32_t r0 = 0; ; r0 += 64u) {
+                const uint32_t idx = r0 + (uint32_t)lane;
+                uint32_t p; bool valid = true, tests = true;
+                if (idx < pre) {
+                    // pre == 1: insert the block's first position; pre == 2: insert ip - 2, then test-and-insert ip
+                    p = (pre == 2u && idx == 0u) ? ip - 2u : ip;
+                    tests = (pre == 2u && idx == 1u);
+                } else {
+                    const uint32_t k = idx - pre;
+                    p = w0 + walk(k);
+                    // the sequential walk leaves for the last literals when the position after this one passes the
+                    // limit, before it inserts or tests this one
+                    valid = w0 + walk(k + 1u) <= mflimit_plus_one;
+                }
+                const unsigned long long vm = __ballot(valid);
+                uint32_t h = 0, seq = 0;
+                if (valid) {
+                    const uint64_t s8 = R.rd64(p);
+                    seq = (uint32_t)s8;
+                    h = (uint32_t)(((s8 << 24) * 889523592379ULL) >> (64 - HASHLOG));
+                }
+                const uint32_t mine = p - bias;
+                // candidate: the table entry, unless an earlier lane of this round has the same hash.  All valid lanes
+                // insert tentatively; a lane that does not read its own value back shares its hash with another lane.
+                uint32_t mi = 0, old = 0, back = 0;
+                // (volatile: other lanes write the same table, so a lane's own store must not be forwarded to its load)
+                volatile uint32_t* const table = L.hash;
+                if (valid) { old = table[h]; table[h] = mine; back = table[h]; }
+                mi = old;
+                unsigned long long same = 1ull << lane;                     // lanes of this round with the same hash
+                const bool collisions = __ballot(valid && back != mine) != 0ull;
+                if (collisions) {
+                    if (valid) table[h] = old;                              // undo, then resolve exactly
+                    // one step per hash value that occurs more than once: its lanes learn their group
+                    unsigned long long losers = __ballot(valid && back != mine);
+                    while (losers) {
+                        const uint32_t hl = (uint32_t)__builtin_amdgcn_readlane((int)h, __builtin_ctzll(losers));
+                        const bool in_group = valid && h == hl;
+                        const unsigned long long group = __ballot(in_group);
+                        if (in_group) same = group;
+                        losers &= ~group;
+                    }
+                    const unsigned long long prev = valid ? (same & below) : 0ull;
+                    const uint32_t from_lane = (uint32_t)__shfl((int)mine, prev ? 63 - __builtin_clzll(prev) : lane);   // all lanes take part
+                    if (prev) mi = from_lane;
+                }
+                bool hit = false;
+                if (valid && tests) {
+                    const bool ok = !(dict_small && mi < prefix_idx_limit) && (mi + DISTANCE_MAX >= mine);
+                    if (ok) hit = R.rd32(mi + bias) == seq;
+                }
+                const unsigned long long hits = __ballot(hit);
+                const int first_invalid = (~vm) ? __builtin_ctzll(~vm) : 64;
+                const int last_insert = hits ? __builtin_ctzll(hits) : first_invalid - 1;
+                if (collisions) {
+                    const unsigned long long inserting = last_insert < 0 ? 0ull : (last_insert >= 63 ? ~0ull : (2ull << last_insert) - 1ull);
+                    // of the lanes that insert, the last one per hash value leaves its position in the table
+                    if (lane <= last_insert && (same & above & inserting) == 0ull) table[h] = mine;
+                } else if (valid && lane > last_insert) table[h] = old;    // take back the inserts behind the stop
+                if (hits) {
+                    const int e = __builtin_ctzll(hits);
+                    ip = (uint32_t)__builtin_amdgcn_readlane((int)p, e);
+                    const uint32_t match_index = (uint32_t)__builtin_amdgcn_readlane((int)mi, e);
+                    match = match_index + bias;
+                    if (ext_dict) low_limit = match_index < start_index ? dict_start : CUR;
+                    found = true;
+                    immediate = (pre == 2u && r0 == 0u && e == 1);         // the test right behind the previous match
+                    break;
+                }
+                if (first_invalid < 64) break;
             }
         }
-        // catch up
-        while (ip > anchor && match > low_limit && uni(buf[ip - 1]) == uni(buf[match - 1])) { ip--; match--; }
-        {   const uint32_t lit = ip - anchor;
+        if (!found) goto last_literals;
+        if (immediate) { token_pos = op++; token = 0; }
+        else {
+            // ---- catch up: extend the match backwards, 64 bytes per round
+            while (ip > anchor) {
+                const uint32_t d = (uint32_t)lane + 1u;
+                bool ok = (int32_t)(ip - anchor) >= (int32_t)d && (int32_t)(match - low_limit) >= (int32_t)d;
+                if (ok) ok = R.byte(ip - d) == R.byte(match - d);
+                const unsigned long long stop = __ballot(!ok);
+                const uint32_t c = stop ? (uint32_t)__builtin_ctzll(stop) : 64u;
+                ip -= c; match -= c;
+                if (c < 64u) break;
+            }
+            const uint32_t lit = ip - anchor;
             token_pos = op++;
             if (op + lit + (2 + 1 + LASTLITERALS) + lit / 255 > max_out) return 0;
             if (lit >= RUN_MASK) {
@@ -147,16 +250,16 @@ __device__ uint32_t compress_block(Lds& L, Stream& st, uint32_t n, uint8_t* out,
                 if (lane == 0) out[op] = (uint8_t)(len - n255 * 255u);
                 op++;
             } else token = lit << 4;
-            copy_out(out + op, buf + anchor, lit, lane);
+            copy_out(out + op, R, anchor, lit, lane);
             op += lit;
         }
-next_match:
         {   const uint32_t offset = ip - match;
             if (lane == 0) { out[op] = (uint8_t)offset; out[op + 1] = (uint8_t)(offset >> 8); }
             op += 2;
         }
-        {   // match length: buf is flat, so a match that starts in the history simply runs on into the current block
-            uint32_t match_code = count_match(buf, ip + MINMATCH, match + MINMATCH, matchlimit, lane);
+        {   // match length: the ring is flat in virtual offsets, so a match that starts in the history simply runs on
+            // into the current block
+            uint32_t match_code = count_match(R, ip + MINMATCH, match + MINMATCH, matchlimit, lane);
             ip += match_code + MINMATCH;
             if (op + (1 + LASTLITERALS) + (match_code + 240) / 255 > max_out) return 0;
             if (match_code >= ML_MASK) {
@@ -172,20 +275,7 @@ next_match:
         }
         anchor = ip;
         if (ip >= mflimit_plus_one) break;
-        if (lane == 0) L.hash[hash5(buf, ip - 2)] = ip - 2 - bias;
-        {   const uint32_t h = hash5(buf, ip);
-            const uint32_t current = ip - bias;
-            const uint32_t match_index = uni(L.hash[h]);
-            match = match_index + bias;
-            if (ext_dict) low_limit = match_index < start_index ? dict_start : (uint32_t)CUR;
-            if (lane == 0) L.hash[h] = current;
-            if ((dict_small ? match_index >= prefix_idx_limit : true) && match_index + DISTANCE_MAX >= current &&
-                uni(rd32(buf, match)) == uni(rd32(buf, ip))) {
-                token_pos = op++; token = 0;
-                goto next_match;
-            }
-        }
-        forward_h = hash5(buf, ++ip);
+        pre = 2;
     }
 last_literals:
     {   const uint32_t last_run = iend - anchor;
@@ -200,7 +290,7 @@ last_literals:
             if (lane == 0) out[op] = (uint8_t)(acc - n255 * 255u);
             op++;
         } else { if (lane == 0) out[op] = (uint8_t)(last_run << 4); op++; }
-        copy_out(out + op, buf + anchor, last_run, lane);
+        copy_out(out + op, R, anchor, last_run, lane);
         op += last_run;
     }
     return op;
@@ -213,9 +303,11 @@ last_literals:
 extern "C" __global__ __launch_bounds__(64) void rh_lz4f_compress(const rh_lz4_job* jobs, rh_lz4_stream_state* states) {
     extern __shared__ uint8_t lds_raw[];
     Lds& L = *reinterpret_cast<Lds*>(lds_raw);
+    uint8_t* const ring8 = reinterpret_cast<uint8_t*>(L.ring);
     const int lane = (int)threadIdx.x;
     const rh_lz4_job job = jobs[blockIdx.x];
     rh_lz4_stream_state& S = states[job.stream];
+    Ring R; R.w = L.ring; R.rot = 0;
 
     // bring the stream state into LDS
     for (int i = lane; i < (1 << HASHLOG); i += 64) L.hash[i] = S.hash[i];
@@ -223,7 +315,7 @@ extern "C" __global__ __launch_bounds__(64) void rh_lz4f_compress(const rh_lz4_j
     {   const uint32_t d = st.dict_size;              // <= 64 KiB, stored at the end of S.dict
         for (uint32_t i = (uint32_t)lane * 16u; i < d; i += 64u * 16u) {
             const uint32_t off = KB64 - ((d + 15u) & ~15u) + i;
-            *reinterpret_cast<uint4*>(L.buf + off) = *reinterpret_cast<const uint4*>(S.dict + off);
+            *reinterpret_cast<uint4*>(ring8 + off) = *reinterpret_cast<const uint4*>(S.dict + off);
         }
     }
     __syncthreads();
@@ -248,15 +340,17 @@ extern "C" __global__ __launch_bounds__(64) void rh_lz4f_compress(const rh_lz4_j
                 // a dictionary shorter than 4 bytes is dropped (LZ4_compress_fast_continue)
                 if (st.dict_size - 1u < 3u) st.dict_size = 0;
             }
-            // load the block behind the history (byte loop handles unaligned tails; sources are 4-byte aligned)
+            // load the block behind the history: `rot` is 0 or 64 KiB, so the block is one contiguous, 16-byte aligned
+            // half of the ring (the byte loop handles unaligned sources and tails)
             {   const uint8_t* s = src + done;
+                uint8_t* const blk8 = ring8 + ((CUR + R.rot) & (2u * KB64 - 1u));
                 if ((reinterpret_cast<uintptr_t>(s) & 15u) == 0) {
-                    for (uint32_t i = (uint32_t)lane * 16u; i < n; i += 64u * 16u)
-                        *reinterpret_cast<uint4*>(L.buf + CUR + i) = (i + 16u <= n) ? *reinterpret_cast<const uint4*>(s + i) : make_uint4(0, 0, 0, 0);
+                    for (uint32_t i = (uint32_t)lane * 16u; i + 16u <= n; i += 64u * 16u)
+                        *reinterpret_cast<uint4*>(blk8 + i) = *reinterpret_cast<const uint4*>(s + i);
                     const uint32_t tail = n & ~15u;
-                    for (uint32_t i = tail + (uint32_t)lane; i < n; i += 64u) L.buf[CUR + i] = s[i];
+                    for (uint32_t i = tail + (uint32_t)lane; i < n; i += 64u) blk8[i] = s[i];
                 } else {
-                    for (uint32_t i = (uint32_t)lane; i < n; i += 64u) L.buf[CUR + i] = s[i];
+                    for (uint32_t i = (uint32_t)lane; i < n; i += 64u) blk8[i] = s[i];
                 }
             }
             __syncthreads();
@@ -264,30 +358,33 @@ extern "C" __global__ __launch_bounds__(64) void rh_lz4f_compress(const rh_lz4_j
             const bool ext = first_block;
             uint8_t* blk = out + op;
             Stream before = st;
-            uint32_t c = compress_block(L, st, n, blk + 4, n - 1, ext, small, lane);
+            uint32_t c = compress_block(L, R, st, n, blk + 4, n - 1, ext, small, lane);
             if (c == 0) { st = before; st.dict_size += n; st.current_offset += n; }      // state advances even when the block is stored
             if (ext) st.dict_size = n;                      // external-dictionary mode: the block becomes the new dictionary
             __syncthreads();
             if (c == 0) {
                 c = n;
                 if (lane == 0) { const uint32_t h = n | BLOCK_UNCOMPRESSED_FLAG; blk[0] = (uint8_t)h; blk[1] = (uint8_t)(h >> 8); blk[2] = (uint8_t)(h >> 16); blk[3] = (uint8_t)(h >> 24); }
-                copy_out(blk + 4, L.buf + CUR, n, lane);
+                copy_out(blk + 4, R, CUR, n, lane);
             } else if (lane == 0) { blk[0] = (uint8_t)c; blk[1] = (uint8_t)(c >> 8); blk[2] = (uint8_t)(c >> 16); blk[3] = (uint8_t)(c >> 24); }
             op += 4u + c;
             done += n;
             first_block = false;
-            // the block just compressed becomes history: slide the last 64 KiB of [history | block] down
+            // the block just compressed becomes history
             {   const uint32_t keep = st.dict_size < KB64 ? st.dict_size : KB64;      // == LZ4_saveDict size after the last block
-                // move buf[CUR + n - keep .. CUR + n) to buf[CUR - keep .. CUR), ascending, 1 KiB per step, reads before writes
-                const uint32_t src_off = CUR + n - keep, dst_off = CUR - keep;
-                if (n > 0 && src_off != dst_off) {
+                if (n == KB64) {
+                    R.rot ^= KB64;                          // the full block is now the 64 KiB before CUR
+                } else if (n > 0) {
+                    // slide the last `keep` bytes of [history | block] down by n: virtual [CUR + n - keep, CUR + n) ->
+                    // [CUR - keep, CUR), ascending, 1 KiB per step, reads before writes
+                    const uint32_t src_off = CUR + n - keep + R.rot, dst_off = CUR - keep + R.rot;
                     for (uint32_t i = 0; i < keep; i += 64u * 16u) {
                         const uint32_t j = i + (uint32_t)lane * 16u;
                         uint8_t tmp[16];
                         const bool act = j < keep;
-                        if (act) for (int k = 0; k < 16; k++) tmp[k] = (j + k < keep) ? L.buf[src_off + j + k] : 0;
+                        if (act) for (int k = 0; k < 16; k++) tmp[k] = (j + k < keep) ? ring8[(src_off + j + k) & (2u * KB64 - 1u)] : 0;
                         __syncthreads();
-                        if (act) for (int k = 0; k < 16; k++) if (j + k < keep) L.buf[dst_off + j + k] = tmp[k];
+                        if (act) for (int k = 0; k < 16; k++) if (j + k < keep) ring8[(dst_off + j + k) & (2u * KB64 - 1u)] = tmp[k];
                         __syncthreads();
                     }
                 }
@@ -297,13 +394,14 @@ extern "C" __global__ __launch_bounds__(64) void rh_lz4f_compress(const rh_lz4_j
         }
     }
 
-    // persist the stream state
+    // persist the stream state: the history is the 64 KiB half before the block position
     __syncthreads();
     for (int i = lane; i < (1 << HASHLOG); i += 64) S.hash[i] = L.hash[i];
     {   const uint32_t d = st.dict_size;
+        const uint8_t* const hist8 = ring8 + (R.rot & (2u * KB64 - 1u));          // virtual [0, 64 KiB)
         for (uint32_t i = (uint32_t)lane * 16u; i < ((d + 15u) & ~15u); i += 64u * 16u) {
             const uint32_t off = KB64 - ((d + 15u) & ~15u) + i;
-            *reinterpret_cast<uint4*>(S.dict + off) = *reinterpret_cast<const uint4*>(L.buf + off);
+            *reinterpret_cast<uint4*>(S.dict + off) = *reinterpret_cast<const uint4*>(hist8 + off);
         }
     }
     if (lane == 0) { S.current_offset = st.current_offset; S.dict_size = st.dict_size; *job.out_len = op; }

@@ -1,0 +1,121 @@
+#!/usr/bin/env python3
+"""Recorded frames/s (BASELINE.json configs[4] shape, one GPU's share): animated quads at 4K with the recording
+attachment, every frame copied into a capture buffer that stays on the device, LZ4F-compressed on the GPU into
+`n_streams` stream files; only compressed bytes cross PCIe.  Prints one JSON line with the end-to-end frames/s
+(wall clock including file writes) and a phase breakdown, beside liblz4 level 0 on one host core on the same frames.
+
+usage: python3 tools/bench_capture.py [--frames 128] [--streams 64] [--quads 100000] [--side 32] [--out /tmp/rh_cap]
+"""
+import argparse
+import json
+import os
+import shutil
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=128)
+    ap.add_argument("--streams", type=int, default=64)
+    ap.add_argument("--quads", type=int, default=100_000)
+    ap.add_argument("--side", type=int, default=32)
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--out", default="/tmp/rh_cap")
+    ap.add_argument("--cpu-frames", type=int, default=4, help="frames compressed by liblz4 on one host core for the baseline")
+    args = ap.parse_args()
+
+    import numpy as np
+    import scenes
+    from renderer_amd import Compressor, Renderer
+
+    W, H = args.width, args.height
+    scene = scenes.random_quads_scene(args.quads, args.side, W, H, seed=4, target="screen")
+    rng = np.random.default_rng(4)
+    vel = rng.uniform(-0.01, 0.01, scene["instances"].shape).astype(np.float32)
+    pos = scene["instances"].copy()
+
+    shutil.rmtree(args.out, ignore_errors=True)
+    r = Renderer(W, H)
+    hs = scenes.HipScene(scene, renderer=r)
+    comp = Compressor(r, args.out, n_streams=args.streams)
+    t_compress = [0.0]
+
+    def sink(frame):
+        t = time.perf_counter()
+        comp.compress_to_disk(frame)
+        t_compress[0] += time.perf_counter() - t
+
+    # budget: all streams' frames may be queued on the device at once (33 MB each at 4K)
+    r.start_recording([hs.pipeline], Renderer.clear_color(0., 0., 0., 1.), float((args.streams + 2) * W * H * 4), sink,
+                      keep_on_device=True)
+    r.flush()
+
+    def step():
+        nonlocal pos, vel
+        pos = (pos + vel).astype(np.float32)                       # the example's bounce rule, vectorised in f32
+        out = (pos > np.float32(0.9)) | (pos < np.float32(-0.9))
+        vel = np.where(out, -vel, vel).astype(np.float32)
+        r.set_instanced(hs.pipeline, (0, 0), pos)
+        r.render(hs.pipeline, hs.clear, hs.viewport, hs.count)
+        r.finish_frame()
+
+    for _ in range(2):
+        step()
+    comp.flush()
+    r.synchronize()
+    t_compress[0] = 0.0
+    raw0, packed0 = comp.raw_video_size, comp.compressed_size
+
+    t0 = time.perf_counter()
+    for _ in range(args.frames):
+        step()
+    comp.flush()
+    r.synchronize()
+    elapsed = time.perf_counter() - t0
+    raw = comp.raw_video_size - raw0
+    packed = comp.compressed_size - packed0
+    last = hs.read_recording()
+    r.stop_recording([hs.pipeline])
+    comp.finish()
+
+    out = {"metric": "recorded frames/s", "value": args.frames / elapsed, "unit": "frames/s", "n_gpus": 1,
+           "frames": args.frames, "streams": args.streams,
+           "config": {"workload": f"{args.quads} animated quads {args.side}x{args.side} px, {W}x{H}, recording attachment, "
+                                  f"GPU LZ4F level 0 into {args.streams} streams, .sz files in {args.out}"},
+           "ms_per_frame": elapsed / args.frames * 1e3,
+           "compress_ms_per_frame": t_compress[0] / args.frames * 1e3,
+           "raw_MB_per_frame": raw / args.frames / 1e6, "compressed_MB_per_frame": packed / args.frames / 1e6,
+           "raw_GBps": raw / elapsed / 1e9}
+
+    # CPU baseline: liblz4 1.9.3 level 0, one stream on one core, the last recorded frame repeated
+    from oracle import loader as O
+    import ctypes as C
+    s = O.LibLz4Stream(0)
+    img = np.ascontiguousarray(last).tobytes()
+    src = (C.c_uint8 * len(img)).from_buffer_copy(img)
+    cap = s.L.LZ4F_compressBound(len(img), C.byref(s.prefs))
+    dst = (C.c_uint8 * cap)()
+    s.write((16 + 23 + len(img)).to_bytes(8, "big")); s.write((23).to_bytes(8, "big")); s.write(bytes(23))
+    cpu_s = 0.0
+    for _ in range(args.cpu_frames):                           # only the library call on the image is timed
+        t1 = time.perf_counter()
+        n = s.L.LZ4F_compressUpdate(s.ctx, dst, cap, src, len(img), None)
+        cpu_s += time.perf_counter() - t1
+        assert not s.L.LZ4F_isError(n)
+    out["cpu_baseline"] = {"value": args.cpu_frames / cpu_s, "unit": "frames/s", "cores": 1, "kind": "reference-library",
+                           "sample": f"liblz4 1.9.3 level 0, {args.cpu_frames} frames of {len(img)} B on one core "
+                                     f"(compress only, no rendering), {cpu_s:.2f} s"}
+    print(json.dumps(out), flush=True)
+    hs.close()
+    r.close()
+    shutil.rmtree(args.out, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -21,6 +21,7 @@ TEXTURE_BINDING, TEXTURE_COPY_DST, TEXTURE_RENDER_ATTACHMENT, TEXTURE_COPY_SRC =
 OPTION_CLIP_TO_VIEWPORT = 0
 OPTION_TIMING = 1
 OPTION_STRIP_ROW0, OPTION_STRIP_ROW1 = 2, 3
+OPTION_GENERAL_KERNELS = 4
 COPY_BYTES_PER_ROW_ALIGNMENT = 256
 MAX_COLOR_TARGETS = 4
 

@@ -4,7 +4,7 @@
 #pragma once
 #include <stdint.h>
 
-#define RH_DEVICE_ABI_VERSION 4u
+#define RH_DEVICE_ABI_VERSION 5u
 #define RH_MODULE_MAGIC 0x52484d4fu   // "RHMO"
 
 #define RH_DEV_MAX_ATTRIBUTES 8
@@ -82,4 +82,8 @@ struct rh_tile_args {
     rh_attach_dev att[RH_DEV_MAX_TARGETS];
     uint32_t n_att;
     uint32_t src_factor, dst_factor;
+    // Which specialisation of the kernel body to run: 0 = every state read at run time; otherwise
+    // 1 + (blend_class - 1) * 2 + (texture_class - 1) with blend_class 1 = (One, OneMinusSrcAlpha), 2 = (One, One) and
+    // texture_class 1 = every bound texture RGBA8 at least 2x2 with linear samplers, 2 = the same with nearest samplers.
+    uint32_t variant;
 };

@@ -67,6 +67,7 @@ struct rh_device {
     rh_texture* screen = nullptr;
     int clip_to_viewport = 1;
     uint32_t strip_row0 = 0, strip_row1 = 0;       // sort-first strip restriction; row1 == 0: none
+    int general_kernels = 0;                       // RH_OPTION_GENERAL_KERNELS
     std::string name;
     // scratch for binning
     Scratch ranges, block_sums, chunk_tmp, keys_a, vals_a, keys_b, vals_b, hist, tile_start, tile_end;
@@ -261,6 +262,7 @@ int rh_device_info(rh_device* dev, char* name, size_t cap) {
 int rh_device_set_option(rh_device* dev, int option, int value) {
     if (!dev) return fail("rh_device_set_option: null device");
     if (option == RH_OPTION_CLIP_TO_VIEWPORT) { dev->clip_to_viewport = value ? 1 : 0; return 0; }
+    if (option == RH_OPTION_GENERAL_KERNELS) { dev->general_kernels = value ? 1 : 0; return 0; }
     if (option == RH_OPTION_TIMING) { dev->timing = value ? 1 : 0; return 0; }
     if (option == RH_OPTION_STRIP_ROW0 || option == RH_OPTION_STRIP_ROW1) {
         if (value < 0) return fail("rh_device_set_option: negative strip row");
@@ -768,6 +770,18 @@ int execute_pass(rh_device* dev, const PassCmd& c) {
         any_clear = any_clear || a.load_op == RH_LOAD_OP_CLEAR;
     }
     ta.src_factor = pl->targets[0].src_factor; ta.dst_factor = pl->targets[0].dst_factor;
+    // pick the specialised kernel body when the pipeline state allows it (the results are identical either way)
+    {   uint32_t blend_class = 0, tex_class = 0;
+        if (ta.src_factor == RH_BLEND_ONE && ta.dst_factor == RH_BLEND_ONE_MINUS_SRC_ALPHA) blend_class = 1;
+        else if (ta.src_factor == RH_BLEND_ONE && ta.dst_factor == RH_BLEND_ONE) blend_class = 2;
+        bool all_rgba8 = true, any_linear = false, any_nearest = false;
+        for (const SlotRef& sl : pl->slots) {
+            if (sl.kind == RH_SLOT_TEXTURE && (sl.tex->format != RH_FORMAT_RGBA_U8 || sl.tex->width < 2 || sl.tex->height < 2)) all_rgba8 = false;
+            if (sl.kind == RH_SLOT_SAMPLER) { if (sl.filter == RH_FILTER_LINEAR) any_linear = true; else any_nearest = true; }
+        }
+        if (all_rgba8 && !(any_linear && any_nearest)) tex_class = any_nearest ? 2 : 1;
+        ta.variant = (blend_class && tex_class && !dev->general_kernels) ? 1 + (blend_class - 1) * 2 + (tex_class - 1) : 0;
+    }
     if (timing_mark(dev)) return 1;
     if ((total > 0 || any_clear) && n_launch_tiles > 0)
         if (launch_module_kernel(pl->fs->tile[c.attachments.size() - 1], n_launch_tiles, &ta, sizeof ta, s)) return 1;

@@ -24,7 +24,9 @@ constexpr float INV_255 = 1.0f / 255.0f;
 enum : uint32_t { FORMAT_R_U8 = 0, FORMAT_BGRA_U8 = 1, FORMAT_RGBA_U8 = 2 };
 enum : uint32_t { FILTER_LINEAR = 0, FILTER_NEAREST = 1 };
 
-struct Sampler { uint32_t filter; };
+// `static_*` members are compile-time constants in the specialised kernel bodies (0 = decide at run time): after
+// inlining, the branches on format and filter fold away.
+struct Sampler { uint32_t filter; uint32_t static_filter; };
 
 typedef float v2f __attribute__((ext_vector_type(2)));                       // maps to packed f32 VALU instructions
 typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));   // two adjacent texels, 4-byte aligned
@@ -33,9 +35,11 @@ RH_DEVICE v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, 
 
 struct Texture2D {
     const uint8_t* data; uint32_t width, height, layers, format;
+    uint32_t static_rgba8;      // 1: known to be RGBA8 and at least 2x2
 
     // Texel (x, y) of `layer`, channels on the 0..255 scale (generic path, any supported format).
     RH_DEVICE float4 fetch(int x, int y, uint32_t layer) const {
+        const uint32_t format = static_rgba8 ? (uint32_t)FORMAT_RGBA_U8 : this->format;
         const uint32_t idx = (layer * height + (uint32_t)y) * width + (uint32_t)x;
         if (format == FORMAT_R_U8) return make_float4((float)data[idx], 0.0f, 0.0f, 255.0f);
         const uint32_t t = *reinterpret_cast<const uint32_t*>(data + (idx << 2));
@@ -53,8 +57,10 @@ struct Texture2D {
     // is the edge texel exactly.  Rows are combined with lerp(t, b, w) = fma(w, b, fma(-w, t, t)).
     RH_DEVICE float4 sample(Sampler s, float2 uv, uint32_t layer = 0) const {
         const int W = (int)width, H = (int)height;
+        const uint32_t format = static_rgba8 ? (uint32_t)FORMAT_RGBA_U8 : this->format;
+        const uint32_t filter = s.static_filter ? s.static_filter - 1u : s.filter;
         if (layer >= layers) layer = layers - 1;
-        if (s.filter == FILTER_NEAREST) {
+        if (filter == FILTER_NEAREST) {
             float u = floorf(uv.x * (float)W), v = floorf(uv.y * (float)H);
             u = fminf(fmaxf(u, -1.0f), (float)W); v = fminf(fmaxf(v, -1.0f), (float)H);
             int i = min(max((int)u, 0), W - 1), j = min(max((int)v, 0), H - 1);
@@ -67,7 +73,7 @@ struct Texture2D {
         const float a = fminf(fmaxf(u - ibf, 0.0f), 1.0f), b = fminf(fmaxf(v - jbf, 0.0f), 1.0f);
         const int ib = (int)ibf, jb = (int)jbf;
         float4 t00, t10, t01, t11;
-        if (format != FORMAT_R_U8 && W >= 2 && H >= 2) {
+        if (static_rgba8 || (format != FORMAT_R_U8 && W >= 2 && H >= 2)) {
             // 4-byte texels: the taps of a row are adjacent and the rows are one pitch apart: two 8-byte loads
             const uint32_t off = (__umul24(layer * height + (uint32_t)jb, width) + (uint32_t)ib) << 2;
             const u32x2_a4 r0 = *reinterpret_cast<const u32x2_a4*>(data + off);
@@ -97,6 +103,7 @@ struct Texture2D {
 
 struct BindingContext {
     const rh_draw_params* p;
+    uint32_t static_rgba8 = 0, static_filter = 0;
     template <typename T> RH_DEVICE const T* storage(uint32_t set, uint32_t binding) const {
         return reinterpret_cast<const T*>(p->slots[set * 4 + binding].ptr);
     }
@@ -105,10 +112,10 @@ struct BindingContext {
     }
     RH_DEVICE Texture2D texture2d(uint32_t set, uint32_t binding) const {
         const rh_slot_dev& s = p->slots[set * 4 + binding];
-        return Texture2D{ reinterpret_cast<const uint8_t*>(s.ptr), s.width, s.height, s.layers, s.format };
+        return Texture2D{ reinterpret_cast<const uint8_t*>(s.ptr), s.width, s.height, s.layers, s.format, static_rgba8 };
     }
     RH_DEVICE Sampler sampler(uint32_t set, uint32_t binding) const {
-        return Sampler{ p->slots[set * 4 + binding].filter };
+        return Sampler{ p->slots[set * 4 + binding].filter, static_filter };
     }
 };
 

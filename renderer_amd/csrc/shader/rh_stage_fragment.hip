@@ -19,6 +19,10 @@
 //      a wave's LDS operations complete in order, so every pixel sees its fragments in primitive order;
 //   3. the tile is written back with coalesced row stores (RGBA or BGRA).
 //
+// The kernel body exists in several specialisations (template parameters BLEND and TEX, selected per launch by
+// rh_tile_args::variant): with the blend factors and the texture format / filter known at compile time the per-fragment
+// branches on pipeline state fold away; variant 0 reads every state at run time.
+//
 // Cost model this is written against (measured on MI355X): f32 add/mul/fma issue in 2 cycles per wave64, every other
 // VALU instruction (integer, logic, conversion, packed f32) in about 4.  Hence coverage is evaluated in f32 where that
 // is exact, and integer work per fragment is kept to the byte unpacks and the final pack.
@@ -54,7 +58,7 @@ constexpr int32_t F32_EDGE_LIMIT = 1 << 18;
 
 // One triangle of a cluster, relative to the tile origin.  Edge e: inside <=> A*lx + B*ly + T >= 0 at tile-relative
 // pixel (lx, ly), top-left rule folded into T.  The same 9 slots hold f32 values (normal case) or i32 values (FLAG_BIG).
-struct TriData {
+struct alignas(16) TriData {
     float A[3], B[3], T[3];
     float XR, YR;                  // reference vertex in 24.8 fixed point relative to the tile origin, as f32 (exact)
     float v0[NV], dvdx[NV], dvdy[NV];   // gradients per 1/256 pixel
@@ -75,9 +79,16 @@ RH_DEVICE float blend_factor(uint32_t f, float src_alpha) {
 // out = src*SF + dst*DF for every channel, alpha included; evaluated on the 0..255 scale:
 //   q = rint(clamp(fma(dst_byte, DF, (src*SF)*255), 0, 255)), NaN -> 0, ties to even
 // v_cvt_pk_u8_f32 performs exactly that clamp + round + byte insert.
+// BLEND: 0 = factors read at run time, 1 = (One, OneMinusSrcAlpha), 2 = (One, One); the results are identical.
+template <int BLEND>
 RH_DEVICE uint32_t blend(uint32_t dst, float4 s, uint32_t src_factor, uint32_t dst_factor) {
-    const float df = blend_factor(dst_factor, s.w);
-    if (src_factor != 1u) { const float sf = blend_factor(src_factor, s.w); s.x *= sf; s.y *= sf; s.z *= sf; s.w *= sf; }
+    float df;
+    if (BLEND == 1) df = 1.0f - s.w;
+    else if (BLEND == 2) df = 1.0f;
+    else {
+        df = blend_factor(dst_factor, s.w);
+        if (src_factor != 1u) { const float sf = blend_factor(src_factor, s.w); s.x *= sf; s.y *= sf; s.z *= sf; s.w *= sf; }
+    }
     const float o0 = __builtin_fmaf((float)(dst & 0xffu), df, s.x * 255.0f);
     const float o1 = __builtin_fmaf((float)((dst >> 8) & 0xffu), df, s.y * 255.0f);
     const float o2 = __builtin_fmaf((float)((dst >> 16) & 0xffu), df, s.z * 255.0f);
@@ -208,11 +219,25 @@ RH_DEVICE bool edges_inside_i32(const TriData& t, int lx, int ly) {
     return (s0 | s1 | s2) >= 0;
 }
 
+constexpr int TRI_FLOATS = (int)(sizeof(TriData) / sizeof(float));
+// float offsets inside TriData of the values a fragment reads from the triangle that covers it
+constexpr int OFF_XR = 9, OFF_YR = 10, OFF_V0 = 11, OFF_DVDX = OFF_V0 + NV, OFF_DVDY = OFF_DVDX + NV, OFF_Q0 = OFF_DVDY + NV;
+static_assert(offsetof(TriData, XR) == OFF_XR * 4 && offsetof(TriData, v0) == OFF_V0 * 4 && offsetof(TriData, q0) == OFF_Q0 * 4,
+              "fragment-side offsets must match TriData");
+
+// The LDS of a tile workgroup; declared once per exported kernel and shared by its specialisations.
 template <int NA>
-RH_DEVICE void tile_kernel(const rh_tile_args& a) {
-    __shared__ ClusterRecord rec[RH_BATCH_CLUSTERS];
-    __shared__ uint32_t rec_bbox[RH_BATCH_CLUSTERS];
-    __shared__ uint32_t tile_px[NA][4 * REGION_STRIDE];
+struct TileLds {
+    ClusterRecord rec[RH_BATCH_CLUSTERS];
+    uint32_t rec_bbox[RH_BATCH_CLUSTERS];
+    uint32_t tile_px[NA][4 * REGION_STRIDE];
+};
+
+template <int NA, int BLEND, int TEX>
+RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA>& lds) {
+    ClusterRecord* const rec = lds.rec;
+    uint32_t* const rec_bbox = lds.rec_bbox;
+    uint32_t (* const tile_px)[4 * REGION_STRIDE] = lds.tile_px;
 
     const rh_draw_params& p = a.p;
     const int tid = (int)threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -241,6 +266,8 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a) {
     }
 
     FragmentContext fctx; fctx.p = &p;
+    fctx.static_rgba8 = TEX != 0 ? 1u : 0u;
+    fctx.static_filter = TEX == 1 ? 1u + FILTER_LINEAR : (TEX == 2 ? 1u + FILTER_NEAREST : 0u);
 
     // this wave's region, tile-relative, intersected with the scissor
     const int rx0 = (wave & 1) * REGION, ry0 = (wave >> 1) * REGION;
@@ -273,60 +300,71 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a) {
                 mask &= mask - 1;
                 const int ci = round * 64 + tl;
                 const ClusterRecord& r = rec[ci];
+                const float* const rf = reinterpret_cast<const float*>(&r);          // t[0] at 0, t[1] at TRI_FLOATS
                 // wave-uniform values are pulled into scalar registers so that the per-hit bookkeeping runs on the scalar unit
                 const uint32_t flags = __builtin_amdgcn_readfirstlane(r.flags);
                 const uint32_t hb = __builtin_amdgcn_readfirstlane(rec_bbox[ci]);
+                const bool has_a = (flags & FLAG_HAS_A) != 0u, has_b = (flags & FLAG_HAS_B) != 0u;
+                const bool any_persp = (flags & (FLAG_PERSP_A | FLAG_PERSP_B)) != 0u;
                 // pixels of (cluster bbox intersected with the region), packed linearly: idx -> (idx % w, idx / w)
                 const int hx0 = max((int)(hb & 0xffu), sx0), hy0 = max((int)((hb >> 8) & 0xffu), sy0);
                 const int hx1 = min((int)((hb >> 16) & 0xffu), sx1), hy1 = min((int)(hb >> 24), sy1);
                 const int w = hx1 - hx0 + 1, npx = w * (hy1 - hy0 + 1);
                 const float wf = (float)w, invw = __builtin_amdgcn_rcpf(wf);
-                const float hx0f = (float)hx0, hy0f = (float)hy0;
+                const float hx0f = (float)hx0, hy0f = (float)hy0, npxf = (float)npx;
                 const float half_invw = 0.5f * invw;
+                bool overlapped = false, ov_a = false, ov_b = false;
                 for (int first = 0; first < npx; first += 64) {
                     const float idx_f = lane_f + (float)first;
                     // floor((idx + 0.5) / w): the half keeps the quotient at least 1/32 away from an integer
                     const float row_f = floorf(__builtin_fmaf(idx_f, invw, half_invw));
                     const float col_f = __builtin_fmaf(-row_f, wf, idx_f);
                     const float lxf = hx0f + col_f, lyf = hy0f + row_f;          // tile-relative pixel, exact small integers
-                    const bool live = idx_f < (float)npx;
+                    const bool live = idx_f < npxf;
                     // region-relative LDS index of the pixel
                     const int pidx = (int)__builtin_fmaf(lyf, (float)REGION, lxf - region_bias);
-                    bool cov_a = false, cov_b = false;
+                    // coverage of both triangles (a missing triangle's record holds stale values: masked by has_*)
+                    bool in_a, in_b;
                     if (flags & FLAG_BIG) {
                         const int lx = (int)lxf, ly = (int)lyf;
-                        if (flags & FLAG_HAS_A) cov_a = live && edges_inside_i32(r.t[0], lx, ly);
-                        if (flags & FLAG_HAS_B) cov_b = live && edges_inside_i32(r.t[1], lx, ly);
+                        in_a = edges_inside_i32(r.t[0], lx, ly); in_b = edges_inside_i32(r.t[1], lx, ly);
                     } else {
-                        if (flags & FLAG_HAS_A) cov_a = live && edges_inside_f32(r.t[0], lxf, lyf);
-                        if (flags & FLAG_HAS_B) cov_b = live && edges_inside_f32(r.t[1], lxf, lyf);
+                        in_a = edges_inside_f32(r.t[0], lxf, lyf); in_b = edges_inside_f32(r.t[1], lxf, lyf);
                     }
+                    const bool cov_a = live && has_a && in_a, cov_b = live && has_b && in_b;
+                    // One shading pass when no pixel is covered by both triangles (the usual case): every lane takes
+                    // the plane equations of the triangle that covers it.  Otherwise A's fragments, then B's.
                     auto shade = [&](bool cov, bool use_b) {
+                        // per-lane choice of the triangle = per-lane LDS address (one copy of the shading code)
+                        const float* const tp = rf + (use_b ? TRI_FLOATS : 0);
+                        const float dx = __builtin_fmaf(lxf, 256.0f, -tp[OFF_XR]), dy = __builtin_fmaf(lyf, 256.0f, -tp[OFF_YR]);   // exact
+                        Varyings var; float* vf = reinterpret_cast<float*>(&var);
+#pragma unroll
+                        for (int v = 0; v < NV; v++) vf[v] = __builtin_fmaf(tp[OFF_DVDY + v], dy, __builtin_fmaf(tp[OFF_DVDX + v], dx, tp[OFF_V0 + v]));
+                        if (any_persp) {
+                            const bool persp = use_b ? (flags & FLAG_PERSP_B) != 0u : (flags & FLAG_PERSP_A) != 0u;
+                            const float q = __builtin_fmaf(tp[OFF_Q0 + 2], dy, __builtin_fmaf(tp[OFF_Q0 + 1], dx, tp[OFF_Q0]));
+#pragma unroll
+                            for (int v = 0; v < NV; v++) vf[v] = persp ? vf[v] / q : vf[v];
+                        }
                         if (cov) {
-                            const TriData& t = use_b ? r.t[1] : r.t[0];
-                            const float dx = __builtin_fmaf(lxf, 256.0f, -t.XR), dy = __builtin_fmaf(lyf, 256.0f, -t.YR);   // exact
-                            Varyings var; float* vf = reinterpret_cast<float*>(&var);
-#pragma unroll
-                            for (int v = 0; v < NV; v++) vf[v] = __builtin_fmaf(t.dvdy[v], dy, __builtin_fmaf(t.dvdx[v], dx, t.v0[v]));
-                            if (flags & (FLAG_PERSP_A | FLAG_PERSP_B)) {
-                                if (use_b ? (flags & FLAG_PERSP_B) != 0 : (flags & FLAG_PERSP_A) != 0) {
-                                    const float q = __builtin_fmaf(t.qy, dy, __builtin_fmaf(t.qx, dx, t.q0));
-#pragma unroll
-                                    for (int v = 0; v < NV; v++) vf[v] = vf[v] / q;
-                                }
-                            }
                             Outputs out;
                             fragment_main(fctx, var, out);
 #pragma unroll
                             for (int n = 0; n < NA; n++) {
                                 uint32_t* px = region_px + n * (4 * REGION_STRIDE) + pidx;
-                                *px = blend(*px, out.color[n < RH_FRAGMENT_OUTPUTS ? n : RH_FRAGMENT_OUTPUTS - 1], a.src_factor, a.dst_factor);
+                                *px = blend<BLEND>(*px, out.color[n < RH_FRAGMENT_OUTPUTS ? n : RH_FRAGMENT_OUTPUTS - 1], a.src_factor, a.dst_factor);
                             }
                         }
                     };
-                    // one pass when no pixel is covered by both triangles (the usual case), else A then B
-                    if (!__any(cov_a && cov_b)) shade(cov_a || cov_b, cov_b);
-                    else { shade(cov_a, false); shade(cov_b, true); }
+                    if (__builtin_expect(!__any(cov_a && cov_b), 1)) shade(cov_a || cov_b, cov_b);
+                    else overlapped = true, ov_a = cov_a, ov_b = cov_b;
+                    if (__builtin_expect(overlapped, 0)) {
+                        // overlapping triangles inside the cluster (bow-tie, folded quads): strictly A before B
+#pragma nounroll
+                        for (int phase = 0; phase < 2; phase++) shade(phase ? ov_b : ov_a, phase != 0);
+                        overlapped = false;
+                    }
                 }
             }
         }
@@ -350,9 +388,26 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a) {
     }
 }
 
+// Runs the specialisation rh_tile_args::variant names; one and two attachments (plain and recorded rendering) have the
+// specialised bodies, more attachments use the general one.
+template <int NA>
+RH_DEVICE void tile_dispatch(const rh_tile_args& a) {
+    __shared__ TileLds<NA> lds;
+    if (NA <= 2) {
+        switch (a.variant) {
+            case 1: tile_kernel<NA, 1, 1>(a, lds); return;
+            case 2: tile_kernel<NA, 1, 2>(a, lds); return;
+            case 3: tile_kernel<NA, 2, 1>(a, lds); return;
+            case 4: tile_kernel<NA, 2, 2>(a, lds); return;
+            default: break;
+        }
+    }
+    tile_kernel<NA, 0, 0>(a, lds);
+}
+
 } // namespace rh
 
-extern "C" __global__ __launch_bounds__(RH_TILE_THREADS, RH_TILE_MIN_WAVES) void rh_tile_1(rh_tile_args a) { rh::tile_kernel<1>(a); }
-extern "C" __global__ __launch_bounds__(RH_TILE_THREADS, RH_TILE_MIN_WAVES) void rh_tile_2(rh_tile_args a) { rh::tile_kernel<2>(a); }
-extern "C" __global__ __launch_bounds__(RH_TILE_THREADS, RH_TILE_MIN_WAVES) void rh_tile_3(rh_tile_args a) { rh::tile_kernel<3>(a); }
-extern "C" __global__ __launch_bounds__(RH_TILE_THREADS, RH_TILE_MIN_WAVES) void rh_tile_4(rh_tile_args a) { rh::tile_kernel<4>(a); }
+extern "C" __global__ __launch_bounds__(RH_TILE_THREADS, RH_TILE_MIN_WAVES) void rh_tile_1(rh_tile_args a) { rh::tile_dispatch<1>(a); }
+extern "C" __global__ __launch_bounds__(RH_TILE_THREADS, RH_TILE_MIN_WAVES) void rh_tile_2(rh_tile_args a) { rh::tile_dispatch<2>(a); }
+extern "C" __global__ __launch_bounds__(RH_TILE_THREADS, RH_TILE_MIN_WAVES) void rh_tile_3(rh_tile_args a) { rh::tile_dispatch<3>(a); }
+extern "C" __global__ __launch_bounds__(RH_TILE_THREADS, RH_TILE_MIN_WAVES) void rh_tile_4(rh_tile_args a) { rh::tile_dispatch<4>(a); }

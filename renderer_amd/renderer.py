@@ -160,6 +160,10 @@ class Renderer:
         _ffi.check(_ffi.lib().rh_device_set_option(self.device, _ffi.OPTION_STRIP_ROW0, int(row0)))
         _ffi.check(_ffi.lib().rh_device_set_option(self.device, _ffi.OPTION_STRIP_ROW1, int(row1)))
 
+    def set_general_kernels(self, enabled):
+        """Forces the kernel body that reads all pipeline state at run time (identical results; for testing)."""
+        _ffi.check(_ffi.lib().rh_device_set_option(self.device, _ffi.OPTION_GENERAL_KERNELS, 1 if enabled else 0))
+
     def set_timing(self, enabled):
         _ffi.check(_ffi.lib().rh_device_set_option(self.device, _ffi.OPTION_TIMING, 1 if enabled else 0))
 

@@ -45,10 +45,12 @@ def main():
     ap.add_argument("--side", type=int, default=16, help="quad edge in pixels (headline: 16)")
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--workload", choices=["c1", "c2"], default="c1",
+                    help="c1 (headline): --quads quads of --side px, alpha blend; c2: --quads quads of 2..8 px, additive")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    default_workload = (args.quads, args.side, args.width, args.height) == (1_000_000, 16, 3840, 2160)
+    default_workload = (args.workload, args.quads, args.side, args.width, args.height) == ("c1", 1_000_000, 16, 3840, 2160)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -66,7 +68,10 @@ def main():
     from renderer_amd import Renderer
 
     # every rank renders a different frame of the same distribution
-    scene = scenes.random_quads_scene(args.quads, args.side, args.width, args.height, seed=1 + rank)
+    if args.workload == "c2":
+        scene = scenes.tiny_quads_scene(args.quads, args.width, args.height, seed=2 + rank)
+    else:
+        scene = scenes.random_quads_scene(args.quads, args.side, args.width, args.height, seed=1 + rank)
     renderer = Renderer(args.width, args.height, hip_ordinal=local_rank)
     hs = scenes.HipScene(scene, renderer=renderer)
 
@@ -108,7 +113,11 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         # Algorithmic bytes of one tile-kernel launch (one frame): every instance record read once, every blended
         # fragment a read-modify-write of its 4-byte target texel, plus the distinct texels of the texture.
-        n_frag = args.quads * args.side * args.side
+        if args.workload == "c2":
+            side_px = np.rint(scene["instances"][:, 2] * args.width).astype(np.int64)
+            n_frag = int((side_px * side_px).sum())
+        else:
+            n_frag = args.quads * args.side * args.side
         tex_bytes = scene["texture"].nbytes
         b_alg = args.quads * scene["instances"].shape[1] * 4 + n_frag * 2 * 4 * 1 + tex_bytes
         b_min = args.quads * scene["instances"].shape[1] * 4 + args.width * args.height * 4 + tex_bytes
@@ -117,15 +126,17 @@ def main():
         achieved = b_alg / (tile_ms * 1e-3) / 1e9 if tile_ms > 0 else 0.0
         traffic = pmc_traffic_bytes() if default_workload else None
         out = {
-            "metric": "instanced quads/s at 4K alpha-blend", "value": value, "unit": "quads/s",
+            "metric": "instanced quads/s at 4K alpha-blend" if args.workload == "c1" else "instanced quads/s at 4K additive tiny quads", "value": value, "unit": "quads/s",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32->unorm8",
             "data": "synthetic",
-            "config": {"workload": f"{args.quads} instanced textured quads {args.side}x{args.side} px, pre-multiplied alpha blend, "
-                                   f"linear filter, {args.width}x{args.height} RGBA8 texture target, clear each frame "
-                                   "(BASELINE.json configs[1])",
+            "config": {"workload": (f"{args.quads} instanced textured quads {args.side}x{args.side} px, pre-multiplied alpha blend, "
+                                    f"linear filter, {args.width}x{args.height} RGBA8 texture target, clear each frame "
+                                    "(BASELINE.json configs[1])") if args.workload == "c1" else
+                                   (f"{args.quads} instanced textured quads of 2..8 px, additive blend, linear filter, "
+                                    f"{args.width}x{args.height} RGBA8 texture target, clear each frame (BASELINE.json configs[2])"),
                        "parallelism": f"frame-parallel x{n_gpus}" if n_gpus > 1 else "single GPU",
-                       "bin_entries": int(stats["bin_entries"]), "tile_px": int(stats["tile_size"])},
+                       "bin_entries": int(stats["bin_entries"]), "tile_px": [int(stats["tile_w"]), int(stats["tile_h"])]},
             "roofline": {"bound": "hbm", "kernel": "rh_tile_1", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": b_alg, "compulsory_bytes_per_launch": b_min,

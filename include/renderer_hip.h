@@ -209,7 +209,7 @@ typedef struct rh_pass_stats {
     uint64_t clusters;        /* binning units (pairs of consecutive triangles) */
     uint64_t bin_entries;     /* (cluster, tile) pairs after binning */
     uint32_t tiles_x, tiles_y;
-    uint32_t tile_size;
+    uint32_t tile_w, tile_h;    /* pixels per tile (one workgroup) */
 } rh_pass_stats;
 int rh_device_last_pass_stats(rh_device* dev, rh_pass_stats* out);
 

@@ -4,7 +4,7 @@
 #pragma once
 #include <stdint.h>
 
-#define RH_DEVICE_ABI_VERSION 5u
+#define RH_DEVICE_ABI_VERSION 6u
 #define RH_MODULE_MAGIC 0x52484d4fu   // "RHMO"
 
 #define RH_DEV_MAX_ATTRIBUTES 8
@@ -13,8 +13,8 @@
 
 // Rasteriser geometry
 #define RH_SUBPIXEL_BITS 8
-#define RH_TILE 32                 // screen tile edge in pixels (one workgroup per tile)
-#define RH_BLOCK 8                 // one wavefront shades an 8x8 pixel block at a time
+#define RH_TILE_W 64               // screen tile in pixels (one workgroup per tile; each of its four wavefronts
+#define RH_TILE_H 32               // owns a 32x16 region of it)
 #ifndef RH_BATCH_CLUSTERS
 #define RH_BATCH_CLUSTERS 64       // clusters (triangle pairs) set up per batch inside a tile workgroup
 #endif

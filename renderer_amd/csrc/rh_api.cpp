@@ -697,14 +697,14 @@ int execute_pass(rh_device* dev, const PassCmd& c) {
         p.sc_y1 = std::min((int)H, (int)std::ceil((double)vy + (double)vh - 0.5));
     }
     p.width = W; p.height = H;
-    p.tiles_x = (W + RH_TILE - 1) / RH_TILE; p.tiles_y = (H + RH_TILE - 1) / RH_TILE;
+    p.tiles_x = (W + RH_TILE_W - 1) / RH_TILE_W; p.tiles_y = (H + RH_TILE_H - 1) / RH_TILE_H;
     const uint32_t n_tiles = p.tiles_x * p.tiles_y;
     // sort-first strip: only tile rows [row0, row1) are rendered (and cleared) by this device
     uint32_t tile_row0 = 0, tile_row1 = p.tiles_y;
     if (dev->strip_row1 != 0) {
         const uint32_t r0 = dev->strip_row0, r1 = std::min(dev->strip_row1, H);
-        if (r0 % RH_TILE || (r1 % RH_TILE && r1 != H) || r0 > r1) return fail("render pass: strip rows [%u, %u) are not multiples of %d", r0, r1, RH_TILE);
-        tile_row0 = r0 / RH_TILE; tile_row1 = (r1 + RH_TILE - 1) / RH_TILE;
+        if (r0 % RH_TILE_H || (r1 % RH_TILE_H && r1 != H) || r0 > r1) return fail("render pass: strip rows [%u, %u) are not multiples of %d", r0, r1, RH_TILE_H);
+        tile_row0 = r0 / RH_TILE_H; tile_row1 = (r1 + RH_TILE_H - 1) / RH_TILE_H;
         p.sc_y0 = std::max(p.sc_y0, (int32_t)r0); p.sc_y1 = std::min(p.sc_y1, (int32_t)r1);
     }
     p.tile_first = tile_row0 * p.tiles_x;
@@ -788,7 +788,7 @@ int execute_pass(rh_device* dev, const PassCmd& c) {
     if (timing_mark(dev)) return 1;
 
     dev->stats.clusters = n_clusters; dev->stats.bin_entries = total;
-    dev->stats.tiles_x = p.tiles_x; dev->stats.tiles_y = p.tiles_y; dev->stats.tile_size = RH_TILE;
+    dev->stats.tiles_x = p.tiles_x; dev->stats.tiles_y = p.tiles_y; dev->stats.tile_w = RH_TILE_W; dev->stats.tile_h = RH_TILE_H;
     return 0;
 }
 

@@ -1,6 +1,6 @@
 // Fragment-stage code object: compiled once per (vertex source, fragment source) pair with
 //     hipcc --genco --offload-arch=gfx950 -ffp-contract=off -DRH_VERTEX_SOURCE=... -DRH_FRAGMENT_SOURCE=... rh_stage_fragment.hip
-// Exports rh_tile_<A> (A = 1..4 colour attachments): one workgroup per 32x32 screen tile, one wavefront per 16x16
+// Exports rh_tile_<A> (A = 1..4 colour attachments): one workgroup per 64x32 screen tile, one wavefront per 32x16
 // region of it.
 //
 // Per tile:
@@ -49,12 +49,13 @@ static_assert(RH_BATCH_CLUSTERS % 64 == 0, "a batch is walked in rounds of 64 cl
 namespace rh {
 
 constexpr int NV = N_VARYINGS;
-constexpr int REGION = 16;                      // a wave owns a 16x16 pixel region of the tile
-constexpr int REGION_STRIDE = REGION * REGION + 16;   // dwords; the padding keeps row-wise tile accesses conflict-free
+constexpr int REGION_W = RH_TILE_W / 2, REGION_H = RH_TILE_H / 2;     // a wave owns a 32x16 pixel region of the tile
+constexpr int REGION_STRIDE = REGION_W * REGION_H + 16;                // dwords per region in LDS
+static_assert(RH_TILE_THREADS == 256 && REGION_W == 32 && RH_TILE_W <= 128 && RH_TILE_H <= 128, "four waves, 2x2 regions, 8-bit tile-relative boxes");
 constexpr uint32_t BBOX_EMPTY = 0x000000ffu;    // x0 = 255 > x1 = 0
 constexpr uint32_t FLAG_PERSP_A = 1u, FLAG_PERSP_B = 2u, FLAG_HAS_A = 4u, FLAG_HAS_B = 8u, FLAG_BIG = 16u;
-// Edge coefficients below this magnitude (1024 px) make f32 edge evaluation exact; see edges_inside_f32.
-constexpr int32_t F32_EDGE_LIMIT = 1 << 18;
+// Edge coefficients below this magnitude (512 px) make f32 edge evaluation exact; see edges_inside_f32.
+constexpr int32_t F32_EDGE_LIMIT = 1 << 17;
 
 // One triangle of a cluster, relative to the tile origin.  Edge e: inside <=> A*lx + B*ly + T >= 0 at tile-relative
 // pixel (lx, ly), top-left rule folded into T.  The same 9 slots hold f32 values (normal case) or i32 values (FLAG_BIG).
@@ -110,12 +111,13 @@ RH_DEVICE bool setup_triangle(const rh_draw_params& p, SnappedVertex a, SnappedV
                               TriData& t, int32_t ei[9], bool& persp, bool& big, int& bx0, int& by0, int& bx1, int& by1) {
     int x0, y0, x1, y1;
     if (!tri_pixel_bbox(p, a, b, c, x0, y0, x1, y1)) return false;
-    x0 = max(x0, ox); y0 = max(y0, oy); x1 = min(x1, ox + RH_TILE - 1); y1 = min(y1, oy + RH_TILE - 1);
+    x0 = max(x0, ox); y0 = max(y0, oy); x1 = min(x1, ox + RH_TILE_W - 1); y1 = min(y1, oy + RH_TILE_H - 1);
     if (x0 > x1 || y0 > y1) return false;
     const int64_t area2 = (int64_t)(b.X - a.X) * (c.Y - a.Y) - (int64_t)(c.X - a.X) * (b.Y - a.Y);
     if (area2 == 0) return false;
     if (area2 < 0) { SnappedVertex s = b; b = c; c = s; }      // no culling: both windings are drawn
-    // T is relative to the tile origin and saturated at +-2^30: |A*lx + B*ly| < 2^29 for lx, ly < 32 keeps the sign.
+    // T is relative to the tile origin and saturated at +-2^30: |A*lx + B*ly| < 2^30 for |A|, |B| < 2^23, lx < 64, ly < 32
+    // keeps the sign (and the sum inside 32 bits).
 #define RH_EDGE(P, Q, K) { \
         const int32_t A_ = P.Y - Q.Y, B_ = Q.X - P.X; \
         const int64_t C_ = -((int64_t)A_ * P.X + (int64_t)B_ * P.Y); \
@@ -201,8 +203,8 @@ RH_DEVICE uint32_t setup_cluster(const rh_draw_params& p, uint32_t cluster, int 
     return (uint32_t)bx0 | ((uint32_t)by0 << 8) | ((uint32_t)bx1 << 16) | ((uint32_t)by1 << 24);
 }
 
-// f32 coverage: with |A|, |B| < 2^18 and lx, ly < 32 every product is an exactly representable integer below 2^23, T is
-// an exactly representable integer in [-2^24, 2^24], and |A*lx + B*ly| < 2^24.  Whenever the true edge value
+// f32 coverage: with |A|, |B| < 2^17, lx < 64 and ly < 32 every product is an exactly representable integer below 2^23,
+// T is an exactly representable integer in [-2^24, 2^24], and |A*lx + B*ly| < 2^24.  Whenever the true edge value
 // A*lx + B*ly + T is within a few units of zero every partial sum is below 2^24 and therefore exact, so the sign test
 // agrees with integer arithmetic; when T is saturated the sign is that of T.
 RH_DEVICE bool edges_inside_f32(const TriData& t, float lxf, float lyf) {
@@ -242,7 +244,7 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA>& lds) {
     const rh_draw_params& p = a.p;
     const int tid = (int)threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const uint32_t tile = blockIdx.x + p.tile_first;
-    const int ox = (int)(tile % p.tiles_x) * RH_TILE, oy = (int)(tile / p.tiles_x) * RH_TILE;
+    const int ox = (int)(tile % p.tiles_x) * RH_TILE_W, oy = (int)(tile / p.tiles_x) * RH_TILE_H;
     const uint32_t start = a.tile_start[tile], end = a.tile_end[tile];
 
     // 1. bring the tile into LDS
@@ -250,8 +252,8 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA>& lds) {
     for (int t = 0; t < NA; t++) {
         const rh_attach_dev& at = a.att[t];
         if (at.load_op == 0u && start == end) continue;          // untouched tile of a Load attachment
-        for (int i = tid; i < RH_TILE * RH_TILE; i += RH_TILE_THREADS) {
-            const int lx = i & (RH_TILE - 1), ly = i / RH_TILE;
+        for (int i = tid; i < RH_TILE_W * RH_TILE_H; i += RH_TILE_THREADS) {
+            const int lx = i & (RH_TILE_W - 1), ly = i / RH_TILE_W;
             const uint32_t gx = (uint32_t)(ox + lx), gy = (uint32_t)(oy + ly);
             uint32_t v = 0;
             if (gx < p.width && gy < p.height) {
@@ -261,7 +263,7 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA>& lds) {
                     if (at.format == FORMAT_BGRA_U8) v = swap_rb(v);
                 }
             }
-            tile_px[t][((ly >> 4) * 2 + (lx >> 4)) * REGION_STRIDE + (ly & 15) * REGION + (lx & 15)] = v;
+            tile_px[t][((ly / REGION_H) * 2 + (lx / REGION_W)) * REGION_STRIDE + (ly % REGION_H) * REGION_W + (lx % REGION_W)] = v;
         }
     }
 
@@ -270,13 +272,13 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA>& lds) {
     fctx.static_filter = TEX == 1 ? 1u + FILTER_LINEAR : (TEX == 2 ? 1u + FILTER_NEAREST : 0u);
 
     // this wave's region, tile-relative, intersected with the scissor
-    const int rx0 = (wave & 1) * REGION, ry0 = (wave >> 1) * REGION;
+    const int rx0 = (wave & 1) * REGION_W, ry0 = (wave >> 1) * REGION_H;
     const int sx0 = max(rx0, p.sc_x0 - ox), sy0 = max(ry0, p.sc_y0 - oy);
-    const int sx1 = min(rx0 + REGION - 1, p.sc_x1 - 1 - ox), sy1 = min(ry0 + REGION - 1, p.sc_y1 - 1 - oy);
+    const int sx1 = min(rx0 + REGION_W - 1, p.sc_x1 - 1 - ox), sy1 = min(ry0 + REGION_H - 1, p.sc_y1 - 1 - oy);
     const bool region_live = sx0 <= sx1 && sy0 <= sy1;
     uint32_t* const region_px = &tile_px[0][wave * REGION_STRIDE];
     const float lane_f = (float)lane;
-    const float region_bias = (float)(ry0 * REGION + rx0);     // pidx = (ly - ry0) * 16 + (lx - rx0)
+    const float region_bias = (float)(ry0 * REGION_W + rx0);   // pidx = (ly - ry0) * REGION_W + (lx - rx0)
 
     // 2. batches of clusters
     for (uint32_t base = start; base < end; base += RH_BATCH_CLUSTERS) {
@@ -322,7 +324,7 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA>& lds) {
                     const float lxf = hx0f + col_f, lyf = hy0f + row_f;          // tile-relative pixel, exact small integers
                     const bool live = idx_f < npxf;
                     // region-relative LDS index of the pixel
-                    const int pidx = (int)__builtin_fmaf(lyf, (float)REGION, lxf - region_bias);
+                    const int pidx = (int)__builtin_fmaf(lyf, (float)REGION_W, lxf - region_bias);
                     // coverage of both triangles (a missing triangle's record holds stale values: masked by has_*)
                     bool in_a, in_b;
                     if (flags & FLAG_BIG) {
@@ -376,11 +378,11 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA>& lds) {
     for (int t = 0; t < NA; t++) {
         const rh_attach_dev& at = a.att[t];
         if (at.load_op == 0u && start == end) continue;
-        for (int i = tid; i < RH_TILE * RH_TILE; i += RH_TILE_THREADS) {
-            const int lx = i & (RH_TILE - 1), ly = i / RH_TILE;
+        for (int i = tid; i < RH_TILE_W * RH_TILE_H; i += RH_TILE_THREADS) {
+            const int lx = i & (RH_TILE_W - 1), ly = i / RH_TILE_W;
             const uint32_t gx = (uint32_t)(ox + lx), gy = (uint32_t)(oy + ly);
             if (gx < p.width && gy < p.height) {
-                uint32_t v = tile_px[t][((ly >> 4) * 2 + (lx >> 4)) * REGION_STRIDE + (ly & 15) * REGION + (lx & 15)];
+                uint32_t v = tile_px[t][((ly / REGION_H) * 2 + (lx / REGION_W)) * REGION_STRIDE + (ly % REGION_H) * REGION_W + (lx % REGION_W)];
                 if (at.format == FORMAT_BGRA_U8) v = swap_rb(v);
                 reinterpret_cast<uint32_t*>(at.ptr)[(size_t)gy * at.pitch_px + gx] = v;
             }

@@ -34,8 +34,8 @@ extern "C" __global__ __launch_bounds__(256) void rh_bin_count(rh_bin_count_args
         }
         rh_tile_range r; r.lo = 1u; r.hi = 0u;          // x0 = 1 > x1 = 0: empty
         if (bx1 >= bx0 && by1 >= by0) {
-            uint32_t tx0 = (uint32_t)bx0 / RH_TILE, ty0 = (uint32_t)by0 / RH_TILE;
-            uint32_t tx1 = (uint32_t)bx1 / RH_TILE, ty1 = (uint32_t)by1 / RH_TILE;
+            uint32_t tx0 = (uint32_t)bx0 / RH_TILE_W, ty0 = (uint32_t)by0 / RH_TILE_H;
+            uint32_t tx1 = (uint32_t)bx1 / RH_TILE_W, ty1 = (uint32_t)by1 / RH_TILE_H;
             r.lo = tx0 | (ty0 << 16); r.hi = tx1 | (ty1 << 16);
             count = (tx1 - tx0 + 1) * (ty1 - ty0 + 1);
         }

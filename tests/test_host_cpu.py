@@ -126,3 +126,13 @@ def test_recording_position_adds_rgba8_target():
     states = p.create_color_target_states()
     assert [s.format for s in states] == [int(Format.BgraU8), int(Format.RgbaU8)]
     p.handle = None
+
+
+def test_cpp_host_mirror_builds():
+    """The C++ mirror of the reference API compiles against the C ABI header and links with the library."""
+    import subprocess
+    from renderer_amd import build
+    exe = build.build_examples()
+    assert os.path.exists(exe)
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 2 and "usage" in out.stderr

@@ -28,7 +28,7 @@ def pmc_traffic_bytes():
     rocprofv3 --pmc run for FETCH_SIZE, one for WRITE_SIZE; both counters are in KiB).  FETCH_SIZE is doubled, the
     gfx950 correction for its 64-B tally of 128-B read requests; counters cannot be collected from inside this
     process, so the figure is the profiled one and is None when no profile of the default workload is present."""
-    path = os.path.join(ROOT, "profiles", "r01", "bench_c1_v3_pmc_avg_per_launch.json")
+    path = os.path.join(ROOT, "profiles", "r01", "bench_c1_v5_pmc_avg_per_launch.json")
     try:
         k = json.load(open(path))["rh_tile_1"]
         return (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0

@@ -53,7 +53,7 @@ constexpr int REGION_W = RH_TILE_W / 2, REGION_H = RH_TILE_H / 2;     // a wave 
 constexpr int REGION_STRIDE = REGION_W * REGION_H + 16;                // dwords per region in LDS
 static_assert(RH_TILE_THREADS == 256 && REGION_W == 32 && RH_TILE_W <= 128 && RH_TILE_H <= 128, "four waves, 2x2 regions, 8-bit tile-relative boxes");
 constexpr uint32_t BBOX_EMPTY = 0x000000ffu;    // x0 = 255 > x1 = 0
-constexpr uint32_t FLAG_PERSP_A = 1u, FLAG_PERSP_B = 2u, FLAG_HAS_A = 4u, FLAG_HAS_B = 8u, FLAG_BIG = 16u;
+constexpr uint32_t FLAG_PERSP_A = 1u, FLAG_PERSP_B = 2u, FLAG_HAS_A = 4u, FLAG_HAS_B = 8u, FLAG_BIG = 16u, FLAG_RECT = 32u;
 // Edge coefficients below this magnitude (512 px) make f32 edge evaluation exact; see edges_inside_f32.
 constexpr int32_t F32_EDGE_LIMIT = 1 << 17;
 
@@ -185,11 +185,18 @@ RH_DEVICE uint32_t setup_cluster(const rh_draw_params& p, uint32_t cluster, int 
     bool persp_a = false, persp_b = false, big = false;
     int32_t ea[9], eb[9];
     const bool has_a = setup_triangle(p, v0, v1, v2, ox, oy, r.t[0], ea, persp_a, big, bx0, by0, bx1, by1);
-    bool has_b = false;
+    bool has_b = false, rect = false;
+    int32_t rminX = 0, rmaxX = 0, rminY = 0, rmaxY = 0;
     if (has_second) {
         const SnappedVertex v3 = run_vertex(p, first + 3, instance);
-        if (strip) has_b = setup_triangle(p, v1, v3, v2, ox, oy, r.t[1], eb, persp_b, big, bx0, by0, bx1, by1);
-        else {
+        if (strip) {
+            has_b = setup_triangle(p, v1, v3, v2, ox, oy, r.t[1], eb, persp_b, big, bx0, by0, bx1, by1);
+            // a strip quad whose snapped corners form an axis-aligned rectangle split along v1-v2
+            const bool columns = v0.X == v1.X && v2.X == v3.X && v0.Y == v2.Y && v1.Y == v3.Y;
+            const bool rows = v0.Y == v1.Y && v2.Y == v3.Y && v0.X == v2.X && v1.X == v3.X;
+            rect = has_a && has_b && !big && (columns || rows) && v0.X != v3.X && v0.Y != v3.Y;
+            rminX = min(v0.X, v3.X); rmaxX = max(v0.X, v3.X); rminY = min(v0.Y, v3.Y); rmaxY = max(v0.Y, v3.Y);
+        } else {
             const SnappedVertex v4 = run_vertex(p, first + 4, instance);
             const SnappedVertex v5 = run_vertex(p, first + 5, instance);
             has_b = setup_triangle(p, v3, v4, v5, ox, oy, r.t[1], eb, persp_b, big, bx0, by0, bx1, by1);
@@ -198,8 +205,17 @@ RH_DEVICE uint32_t setup_cluster(const rh_draw_params& p, uint32_t cluster, int 
     if (has_a) store_edges(r.t[0], ea, big);
     if (has_b) store_edges(r.t[1], eb, big);
     r.flags = (has_a ? FLAG_HAS_A : 0u) | (has_b ? FLAG_HAS_B : 0u) | (persp_a ? FLAG_PERSP_A : 0u) | (persp_b ? FLAG_PERSP_B : 0u) |
-              (big ? FLAG_BIG : 0u);
+              (big ? FLAG_BIG : 0u) | (rect ? FLAG_RECT : 0u);
     if (!has_a && !has_b) return BBOX_EMPTY;
+    if (rect) {
+        // Exact pixel set of the rectangle under the top-left rule: left and top edges take pixel centres on them, right
+        // and bottom edges do not.  Inside it every pixel belongs to exactly one of the two triangles, decided by the
+        // shared diagonal alone (edge 1 of triangle A).
+        const int ex0 = max(max(p.sc_x0, ox), (rminX + 255) >> 8), ex1 = min(min(p.sc_x1 - 1, ox + RH_TILE_W - 1), (rmaxX - 1) >> 8);
+        const int ey0 = max(max(p.sc_y0, oy), (rminY + 255) >> 8), ey1 = min(min(p.sc_y1 - 1, oy + RH_TILE_H - 1), (rmaxY - 1) >> 8);
+        if (ex0 > ex1 || ey0 > ey1) return BBOX_EMPTY;
+        return (uint32_t)(ex0 - ox) | ((uint32_t)(ey0 - oy) << 8) | ((uint32_t)(ex1 - ox) << 16) | ((uint32_t)(ey1 - oy) << 24);
+    }
     return (uint32_t)bx0 | ((uint32_t)by0 << 8) | ((uint32_t)bx1 << 16) | ((uint32_t)by1 << 24);
 }
 
@@ -315,7 +331,6 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA>& lds) {
                 const float wf = (float)w, invw = __builtin_amdgcn_rcpf(wf);
                 const float hx0f = (float)hx0, hy0f = (float)hy0, npxf = (float)npx;
                 const float half_invw = 0.5f * invw;
-                bool overlapped = false, ov_a = false, ov_b = false;
                 for (int first = 0; first < npx; first += 64) {
                     const float idx_f = lane_f + (float)first;
                     // floor((idx + 0.5) / w): the half keeps the quotient at least 1/32 away from an integer
@@ -326,14 +341,24 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA>& lds) {
                     // region-relative LDS index of the pixel
                     const int pidx = (int)__builtin_fmaf(lyf, (float)REGION_W, lxf - region_bias);
                     // coverage of both triangles (a missing triangle's record holds stale values: masked by has_*)
-                    bool in_a, in_b;
-                    if (flags & FLAG_BIG) {
-                        const int lx = (int)lxf, ly = (int)lyf;
-                        in_a = edges_inside_i32(r.t[0], lx, ly); in_b = edges_inside_i32(r.t[1], lx, ly);
+                    bool cov_a, cov_b, overlap = false;
+                    if (flags & FLAG_RECT) {
+                        // every pixel of the box is covered; the shared diagonal (edge 1 of A) says by which triangle
+                        const TriData& ta = r.t[0];
+                        const bool in_a = __float_as_int(__builtin_fmaf(ta.A[1], lxf, __builtin_fmaf(ta.B[1], lyf, ta.T[1]))) >= 0;
+                        cov_a = live && in_a; cov_b = live && !in_a;
                     } else {
-                        in_a = edges_inside_f32(r.t[0], lxf, lyf); in_b = edges_inside_f32(r.t[1], lxf, lyf);
+                        // (a missing triangle's record holds stale values: masked by has_*)
+                        bool in_a, in_b;
+                        if (flags & FLAG_BIG) {
+                            const int lx = (int)lxf, ly = (int)lyf;
+                            in_a = edges_inside_i32(r.t[0], lx, ly); in_b = edges_inside_i32(r.t[1], lx, ly);
+                        } else {
+                            in_a = edges_inside_f32(r.t[0], lxf, lyf); in_b = edges_inside_f32(r.t[1], lxf, lyf);
+                        }
+                        cov_a = live && has_a && in_a; cov_b = live && has_b && in_b;
+                        overlap = __any(cov_a && cov_b);
                     }
-                    const bool cov_a = live && has_a && in_a, cov_b = live && has_b && in_b;
                     // One shading pass when no pixel is covered by both triangles (the usual case): every lane takes
                     // the plane equations of the triangle that covers it.  Otherwise A's fragments, then B's.
                     auto shade = [&](bool cov, bool use_b) {
@@ -359,13 +384,11 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA>& lds) {
                             }
                         }
                     };
-                    if (__builtin_expect(!__any(cov_a && cov_b), 1)) shade(cov_a || cov_b, cov_b);
-                    else overlapped = true, ov_a = cov_a, ov_b = cov_b;
-                    if (__builtin_expect(overlapped, 0)) {
+                    if (__builtin_expect(!overlap, 1)) shade(cov_a || cov_b, cov_b);
+                    else {
                         // overlapping triangles inside the cluster (bow-tie, folded quads): strictly A before B
 #pragma nounroll
-                        for (int phase = 0; phase < 2; phase++) shade(phase ? ov_b : ov_a, phase != 0);
-                        overlapped = false;
+                        for (int phase = 0; phase < 2; phase++) shade(phase ? cov_b : cov_a, phase != 0);
                     }
                 }
             }

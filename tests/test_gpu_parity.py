@@ -100,3 +100,45 @@ def test_load_op_and_second_pass_sampling_target(oracle):
     h2.draw()
     assert_same(h2.read_color(), want, "pass 2")
     r.close()
+
+
+@pytest.mark.parametrize("topology", ["strip", "list"])
+def test_axis_aligned_edges_on_pixel_centres(oracle, topology):
+    """Quads whose edges fall exactly on pixel centres and on pixel boundaries: the top-left rule decides every border
+    pixel.  Strip quads take the rectangle path of the tile kernel (exact box + diagonal), list quads the general edge
+    functions; both must agree with the oracle, which only has the general rule."""
+    W = H = 256
+    f32 = np.float32
+    rng = np.random.default_rng(11)
+    n = 600
+    # centres on a half-pixel lattice, half extents in half pixels: corners land on k/2 pixel coordinates
+    cx = (rng.integers(8, 2 * W - 8, n) * f32(0.5) / f32(W / 2) - f32(1.0)).astype(f32)
+    cy = (rng.integers(8, 2 * H - 8, n) * f32(0.5) / f32(H / 2) - f32(1.0)).astype(f32)
+    hx, hy = f32(7.5 / (W / 2)), f32(5.0 / (H / 2))
+    scene = scenes.random_quads_scene(n, 16, W, H, seed=11, blend="additive", filter="nearest")
+    scene["instances"] = np.stack([cx, cy], axis=1).astype(f32)
+    corners = np.array([[-hx, -hy], [-hx, hy], [hx, -hy], [hx, hy]], dtype=f32)
+    if topology == "strip":
+        scene["position"] = corners
+    else:
+        order = [0, 1, 2, 1, 3, 2]
+        scene["position"] = corners[order]
+        scene["uv"] = scenes.QUAD_UV[order]
+        scene["topology"] = "list"
+    orc = scenes.draw_oracle(scene)
+    hip = scenes.draw_hip(scene)
+    assert_same(hip["color"], orc["color"], f"ties/{topology}")
+    assert orc["fragments"] > 0
+
+
+def test_general_and_specialised_kernel_bodies_agree(oracle):
+    """The state-specialised kernel bodies and the general body give identical bytes."""
+    scene = scenes.random_quads_scene(5000, 24, 512, 288, seed=5)
+    want = scenes.draw_oracle(scene)["color"]
+    for general in (False, True):
+        hs = scenes.HipScene(scene)
+        hs.renderer.set_general_kernels(general)
+        hs.draw()
+        got = hs.read_color()
+        hs.close()
+        assert_same(got, want, f"general={general}")

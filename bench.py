@@ -8,6 +8,10 @@ librenderer_hip.so.  Inputs (instance buffer, attributes, texture) are resident 
 N > 1 (launched by torch.distributed.run, one rank per GPU): the path shards by frame -- every rank renders its own
 frames with no data-path collective -- so the job value is the sum over ranks ("weak" scaling).
 
+After the quads/s leg the same process measures the second half of the metric, recorded frames/s: 128 frames of
+BASELINE.json configs[4]'s scene (100,000 animated 32x32 quads at 4K, recording attachment) are rendered, captured on
+the device and LZ4F-compressed there into stream files; the result is the "capture" object of the same JSON line.
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -19,6 +23,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
 
@@ -48,6 +53,9 @@ def main():
     ap.add_argument("--workload", choices=["c1", "c2"], default="c1",
                     help="c1 (headline): --quads quads of --side px, alpha blend; c2: --quads quads of 2..8 px, additive")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--capture-frames", type=int, default=256,
+                    help="frames of the recorded-frames/s leg (BASELINE.json configs[4] shape, per GPU); 0 skips it")
+    ap.add_argument("--capture-streams", type=int, default=128)
     args = ap.parse_args()
 
     default_workload = (args.workload, args.quads, args.side, args.width, args.height) == ("c1", 1_000_000, 16, 3840, 2160)
@@ -107,6 +115,36 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # release the quads scene before the recording leg
+    hs.close()
+    renderer.close()
+
+    # Second half of the metric: recorded frames/s.  Every rank renders, records and GPU-compresses its own frames into
+    # its own stream files (frame-parallel, no data-path collective); the job value is the sum over ranks.
+    capture = None
+    if args.capture_frames > 0 and args.workload == "c1":
+        import bench_capture
+        cap_s, cap_info, cap_error = float("inf"), None, None
+        try:
+            cap_s, cap_info, _ = bench_capture.run_capture(
+                frames=args.capture_frames, streams=args.capture_streams, out=f"/tmp/rh_bench_capture_{os.getpid()}_{rank}",
+                hip_ordinal=local_rank, seed=4 + rank)
+        except Exception as e:                   # e.g. no room for the stream files: report it, keep the quads/s line
+            cap_error = f"rank {rank}: {type(e).__name__}: {e}"
+        if dist is not None:
+            # ranks start the leg together (they all left the barrier of the first leg) and the slowest one counts
+            import torch
+            t = torch.tensor([cap_s], dtype=torch.float64, device=f"cuda:{local_rank}")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            cap_s = float(t.item())
+        if cap_info is None or cap_s == float("inf"):
+            capture = {"metric": "recorded frames/s", "value": None, "error": cap_error or "failed on another rank"}
+        else:
+            capture = {"metric": "recorded frames/s", "value": args.capture_frames * n_gpus / cap_s, "unit": "frames/s",
+                       "frames_per_gpu": args.capture_frames, "streams_per_gpu": args.capture_streams,
+                       "ms_per_frame_per_gpu": cap_s / args.capture_frames * 1e3, "workload": cap_info["workload"],
+                       "raw_MB_per_frame": cap_info["raw_MB_per_frame"], "compressed_MB_per_frame": cap_info["compressed_MB_per_frame"]}
+
     if rank == 0:
         total_quads = args.quads * args.steps * n_gpus
         value = total_quads / elapsed
@@ -152,10 +190,10 @@ def main():
             out["cpu_baseline"] = {"value": args.quads / cpu_s, "unit": "quads/s", "cores": cores, "kind": "port",
                                    "sample": f"one full frame of the same scene ({args.quads} quads, {orc['fragments']} fragments) "
                                              f"on {cores} threads, {cpu_s:.2f} s wall; CPU restatement, not lavapipe"}
+        if capture is not None:
+            out["capture"] = capture
         print(json.dumps(out), flush=True)
 
-    hs.close()
-    renderer.close()
     if dist is not None:
         dist.destroy_process_group()
 

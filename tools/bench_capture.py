@@ -18,6 +18,78 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+def run_capture(frames=128, streams=64, quads=100_000, side=32, width=3840, height=2160, out="/tmp/rh_cap", hip_ordinal=0,
+                seed=4, before_timing=None, after_timing=None):
+    """Renders and records `frames` frames; returns (elapsed seconds, info dict, last recorded image).  `before_timing`
+    and `after_timing` are called around the timed loop (multi-process runs put their barriers there)."""
+    import numpy as np
+    import scenes
+    from renderer_amd import Compressor, Renderer
+
+    W, H = width, height
+    scene = scenes.random_quads_scene(quads, side, W, H, seed=seed, target="screen")
+    rng = np.random.default_rng(seed)
+    vel = rng.uniform(-0.01, 0.01, scene["instances"].shape).astype(np.float32)
+    pos = scene["instances"].copy()
+
+    shutil.rmtree(out, ignore_errors=True)
+    r = Renderer(W, H, hip_ordinal=hip_ordinal)
+    hs = scenes.HipScene(scene, renderer=r)
+    comp = Compressor(r, out, n_streams=streams)
+    t_compress = [0.0]
+
+    def sink(frame):
+        t = time.perf_counter()
+        comp.compress_to_disk(frame)
+        t_compress[0] += time.perf_counter() - t
+
+    # budget: all streams' frames may be queued on the device at once (33 MB each at 4K)
+    r.start_recording([hs.pipeline], Renderer.clear_color(0., 0., 0., 1.), float((streams + 2) * W * H * 4), sink,
+                      keep_on_device=True)
+    r.flush()
+
+    def step():
+        nonlocal pos, vel
+        pos = (pos + vel).astype(np.float32)                       # the example's bounce rule, vectorised in f32
+        outside = (pos > np.float32(0.9)) | (pos < np.float32(-0.9))
+        vel = np.where(outside, -vel, vel).astype(np.float32)
+        r.set_instanced(hs.pipeline, (0, 0), pos)
+        r.render(hs.pipeline, hs.clear, hs.viewport, hs.count)
+        r.finish_frame()
+
+    for _ in range(2):
+        step()
+    comp.flush()
+    r.synchronize()
+    t_compress[0] = 0.0
+    raw0, packed0 = comp.raw_video_size, comp.compressed_size
+
+    if before_timing:
+        before_timing()
+    t0 = time.perf_counter()
+    for _ in range(frames):
+        step()
+    comp.flush()
+    r.synchronize()
+    if after_timing:
+        after_timing()
+    elapsed = time.perf_counter() - t0
+    raw = comp.raw_video_size - raw0
+    packed = comp.compressed_size - packed0
+    last = hs.read_recording()
+    r.stop_recording([hs.pipeline])
+    comp.finish()
+    hs.close()
+    r.close()
+    shutil.rmtree(out, ignore_errors=True)
+    info = {"frames": frames, "streams": streams,
+            "workload": f"{quads} animated quads {side}x{side} px, {W}x{H}, recording attachment, GPU LZ4F level 0 into "
+                        f"{streams} stream files per GPU",
+            "compress_ms_per_frame": t_compress[0] / frames * 1e3,
+            "raw_MB_per_frame": raw / frames / 1e6, "compressed_MB_per_frame": packed / frames / 1e6}
+    return elapsed, info, last
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=128)
@@ -31,67 +103,12 @@ def main():
     args = ap.parse_args()
 
     import numpy as np
-    import scenes
-    from renderer_amd import Compressor, Renderer
-
-    W, H = args.width, args.height
-    scene = scenes.random_quads_scene(args.quads, args.side, W, H, seed=4, target="screen")
-    rng = np.random.default_rng(4)
-    vel = rng.uniform(-0.01, 0.01, scene["instances"].shape).astype(np.float32)
-    pos = scene["instances"].copy()
-
-    shutil.rmtree(args.out, ignore_errors=True)
-    r = Renderer(W, H)
-    hs = scenes.HipScene(scene, renderer=r)
-    comp = Compressor(r, args.out, n_streams=args.streams)
-    t_compress = [0.0]
-
-    def sink(frame):
-        t = time.perf_counter()
-        comp.compress_to_disk(frame)
-        t_compress[0] += time.perf_counter() - t
-
-    # budget: all streams' frames may be queued on the device at once (33 MB each at 4K)
-    r.start_recording([hs.pipeline], Renderer.clear_color(0., 0., 0., 1.), float((args.streams + 2) * W * H * 4), sink,
-                      keep_on_device=True)
-    r.flush()
-
-    def step():
-        nonlocal pos, vel
-        pos = (pos + vel).astype(np.float32)                       # the example's bounce rule, vectorised in f32
-        out = (pos > np.float32(0.9)) | (pos < np.float32(-0.9))
-        vel = np.where(out, -vel, vel).astype(np.float32)
-        r.set_instanced(hs.pipeline, (0, 0), pos)
-        r.render(hs.pipeline, hs.clear, hs.viewport, hs.count)
-        r.finish_frame()
-
-    for _ in range(2):
-        step()
-    comp.flush()
-    r.synchronize()
-    t_compress[0] = 0.0
-    raw0, packed0 = comp.raw_video_size, comp.compressed_size
-
-    t0 = time.perf_counter()
-    for _ in range(args.frames):
-        step()
-    comp.flush()
-    r.synchronize()
-    elapsed = time.perf_counter() - t0
-    raw = comp.raw_video_size - raw0
-    packed = comp.compressed_size - packed0
-    last = hs.read_recording()
-    r.stop_recording([hs.pipeline])
-    comp.finish()
-
+    elapsed, info, last = run_capture(args.frames, args.streams, args.quads, args.side, args.width, args.height, args.out)
     out = {"metric": "recorded frames/s", "value": args.frames / elapsed, "unit": "frames/s", "n_gpus": 1,
-           "frames": args.frames, "streams": args.streams,
-           "config": {"workload": f"{args.quads} animated quads {args.side}x{args.side} px, {W}x{H}, recording attachment, "
-                                  f"GPU LZ4F level 0 into {args.streams} streams, .sz files in {args.out}"},
-           "ms_per_frame": elapsed / args.frames * 1e3,
-           "compress_ms_per_frame": t_compress[0] / args.frames * 1e3,
-           "raw_MB_per_frame": raw / args.frames / 1e6, "compressed_MB_per_frame": packed / args.frames / 1e6,
-           "raw_GBps": raw / elapsed / 1e9}
+           "frames": args.frames, "streams": args.streams, "config": {"workload": info["workload"]},
+           "ms_per_frame": elapsed / args.frames * 1e3, "compress_ms_per_frame": info["compress_ms_per_frame"],
+           "raw_MB_per_frame": info["raw_MB_per_frame"], "compressed_MB_per_frame": info["compressed_MB_per_frame"],
+           "raw_GBps": info["raw_MB_per_frame"] * args.frames / elapsed / 1e3}
 
     # CPU baseline: liblz4 1.9.3 level 0, one stream on one core, the last recorded frame repeated
     from oracle import loader as O
@@ -112,9 +129,6 @@ def main():
                            "sample": f"liblz4 1.9.3 level 0, {args.cpu_frames} frames of {len(img)} B on one core "
                                      f"(compress only, no rendering), {cpu_s:.2f} s"}
     print(json.dumps(out), flush=True)
-    hs.close()
-    r.close()
-    shutil.rmtree(args.out, ignore_errors=True)
 
 
 if __name__ == "__main__":

@@ -142,3 +142,65 @@ def test_general_and_specialised_kernel_bodies_agree(oracle):
         got = hs.read_color()
         hs.close()
         assert_same(got, want, f"general={general}")
+
+
+@pytest.mark.parametrize("fmt", ["r_u8", "bgra_u8"])
+@pytest.mark.parametrize("filter", ["linear", "nearest"])
+def test_other_texture_formats(oracle, fmt, filter):
+    """R8 and BGRA8 textures take the general kernel body (format read at run time)."""
+    rng = np.random.default_rng(21)
+    tex = rng.integers(0, 256, (37, 53) if fmt == "r_u8" else (37, 53, 4), dtype=np.uint8)
+    scene = scenes.random_quads_scene(3000, 20, 400, 300, seed=21, filter=filter, texture=tex)
+    scene["texture_format"] = fmt
+    orc = scenes.draw_oracle(scene)
+    hip = scenes.draw_hip(scene)
+    assert_same(hip["color"], orc["color"], f"{fmt}/{filter}")
+
+
+def test_one_texel_texture(oracle):
+    tex = np.array([[[200, 100, 50, 255]]], dtype=np.uint8)
+    for filter in ("linear", "nearest"):
+        scene = scenes.random_quads_scene(500, 12, 256, 128, seed=22, filter=filter, texture=tex, blend="additive")
+        assert_same(scenes.draw_hip(scene)["color"], scenes.draw_oracle(scene)["color"], f"1x1/{filter}")
+
+
+def test_viewport_clip_switch(oracle):
+    """Quads poking out of a letterboxed viewport: clipped to it by default, to the attachment with the option off."""
+    scene = scenes.example_scene(1, width=640, height=360)
+    scene["instances"] = np.array([[0.95, 0.0], [-1.0, 0.9]], dtype=np.float32)
+    for clip in (True, False):
+        orc = scenes.draw_oracle(scene, clip_to_viewport=clip)
+        hip = scenes.draw_hip(scene, clip_to_viewport=clip)
+        assert_same(hip["color"], orc["color"], f"clip={clip}")
+    assert not np.array_equal(scenes.draw_oracle(scene, clip_to_viewport=True)["color"],
+                              scenes.draw_oracle(scene, clip_to_viewport=False)["color"])
+
+
+def test_huge_and_far_away_quads(oracle):
+    """Edges longer than the f32-exact limit (integer edge path), vertices far outside the guard band, quads fully off
+    screen, zero-area quads and a NaN position."""
+    f32 = np.float32
+    scene = scenes.tiny_quads_scene(12, 700, 500, seed=23)
+    inst = scene["instances"]
+    inst[0] = [0.0, 0.0, 3.0, 3.0]            # covers everything, edges of 2100 px
+    inst[1] = [0.5, -0.5, 40.0, 0.02]         # 28000 px wide sliver: clamped by the guard band
+    inst[2] = [5.0, 5.0, 0.5, 0.5]            # off screen
+    inst[3] = [0.1, 0.1, 0.0, 0.3]            # zero width
+    inst[4] = [np.nan, 0.0, 0.1, 0.1]         # dropped
+    inst[5] = [-0.3, 0.4, 1.7, 0.9]           # large, partly outside
+    inst[6] = [0.2, 0.2, -0.6, 0.4]           # mirrored (negative extent): winding flips, still drawn
+    scene["instances"] = inst.astype(f32)
+    scene["blend"] = "premultiplied"
+    orc = scenes.draw_oracle(scene)
+    hip = scenes.draw_hip(scene)
+    assert_same(hip["color"], orc["color"], "huge")
+    assert orc["fragments"] > 700 * 500
+
+
+def test_no_instances_only_clears(oracle):
+    scene = scenes.random_quads_scene(4, 16, 200, 100, seed=24, clear=(0.2, 0.4, 0.6, 1.0))
+    scene["instances"] = np.zeros((0, 2), dtype=np.float32)
+    orc = scenes.draw_oracle(scene)
+    hip = scenes.draw_hip(scene)
+    assert_same(hip["color"], orc["color"], "empty")
+    assert orc["fragments"] == 0 and (hip["color"] == hip["color"][0, 0]).all()

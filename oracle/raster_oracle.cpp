@@ -41,6 +41,7 @@ enum {
     ORC_SHADER_HELLO = 0,        // reference examples/quads/hello.vert:5-15 + hello.frag:7-17
     ORC_SHADER_SIZED = 1,        // hello with a vec4 {x, y, half_w, half_h} instance record
     ORC_SHADER_HELLO_NEAREST_LAYER = 2, // hello sampling layer `uniform[0]` of a 2D-array texture
+    ORC_SHADER_TILTED = 3,       // projective quads: per-vertex w, a third varying, a uniform read by both stages
 };
 
 struct orc_texture {
@@ -181,10 +182,30 @@ void layer_fs(const orc_draw& d, const float* var, float out[][4]) {
     for (uint32_t a = 0; a < 2; a++) for (int k = 0; k < 4; k++) out[a][k] = c[k];
 }
 
+// Projective quads.  Storage record vec4 {cx, cy, half, tilt}; uniform floats {tint r, g, b, a, scale_x, scale_y}:
+//   w = a_position.x * tilt + 1;  gl_Position = vec4((a_position.x*scale_x*half + cx) * w, (a_position.y*scale_y*half + cy) * w, 0, w)
+//   varyings: tex_coord, shade = a_position.y * 0.25 + 0.75;  colour = (texture * tint) * shade
+void tilted_vs(const orc_draw& d, uint32_t v, uint32_t inst, VsOut& o) {
+    const float* pos = d.attr[0] + (size_t)v * d.attr_size[0];
+    const float* uv = d.attr[1] + (size_t)v * d.attr_size[1];
+    const float* r = d.storage[0] + (size_t)inst * 4;
+    const float* u = d.uniform[0];
+    const float w = fmaf(pos[0], r[3], 1.0f);
+    const float x = fmaf(pos[0] * u[4], r[2], r[0]), y = fmaf(pos[1] * u[5], r[2], r[1]);
+    o.pos[0] = x * w; o.pos[1] = y * w; o.pos[2] = 0.0f; o.pos[3] = w;
+    o.var[0] = uv[0]; o.var[1] = uv[1]; o.var[2] = fmaf(pos[1], 0.25f, 0.75f);
+}
+void tilted_fs(const orc_draw& d, const float* var, float out[][4]) {
+    const float* u = d.uniform[0];
+    float c[4]; sample_2d(d.tex[0], var[0], var[1], 0, c);
+    for (uint32_t a = 0; a < 2; a++) for (int k = 0; k < 4; k++) out[a][k] = (c[k] * u[k]) * var[2];
+}
+
 const Shader SHADERS[] = {
     { 2, 2, hello_vs, hello_fs },
     { 2, 2, sized_vs, hello_fs },
     { 2, 2, hello_vs, layer_fs },
+    { 3, 2, tilted_vs, tilted_fs },
 };
 
 // ---- triangle setup ----------------------------------------------------------------------------------------------

@@ -2,7 +2,7 @@
 both by the HIP renderer (through renderer_amd, i.e. the C ABI) and by the CPU oracle.
 
 Scene keys
-  shader        'hello' | 'sized'
+  shader        'hello' | 'sized' | 'tilted' (projective quads; needs 'uniform': float32 [6])
   width,height  window / target size
   target        'screen' (BGRA8 offscreen screen) | 'texture' (RGBA8 texture target)
   position,uv   per-vertex attributes (location 0 and 1), float32 [V, 2]
@@ -110,7 +110,8 @@ def draw_oracle(scene, threads=0, clip_to_viewport=True, initial=None):
     layers = scene.get("texture_layers", 1)
     th, tw = (tex.shape[0] // layers, tex.shape[1])
     blend = {"premultiplied": (O.BF_ONE, O.BF_ONE_MINUS_SRC_ALPHA), "additive": (O.BF_ONE, O.BF_ONE)}[scene["blend"]]
-    n = O.render(shader={"hello": O.SHADER_HELLO, "sized": O.SHADER_SIZED}[scene["shader"]],
+    n = O.render(shader={"hello": O.SHADER_HELLO, "sized": O.SHADER_SIZED, "tilted": O.SHADER_TILTED}[scene["shader"]],
+                 uniforms=[scene["uniform"]] if "uniform" in scene else (),
                  topology=O.TOPO_TRIANGLE_STRIP if scene["topology"] == "strip" else O.TOPO_TRIANGLE_LIST,
                  vertex_count=len(scene["position"]), instance_count=len(scene["instances"]),
                  attrs=[(scene["position"], 2), (scene["uv"], 2)], storage=[scene["instances"]],
@@ -154,8 +155,13 @@ class HipScene:
         a_tex_coord = r.attribute(1, 2)
         i_offset = r.instanced()
         t_texture = r.texture(tw, th, layers, flt, fmt, False, False, True)
-        program = r.program(vert, frag, [a_position, a_tex_coord], [i_offset], [],
+        uniforms = []
+        if "uniform" in scene:
+            self.u_params = r.uniform()
+            uniforms = [(self.u_params, Renderer.visible_to_both_shaders())]
+        program = r.program(vert, frag, [a_position, a_tex_coord], [i_offset], uniforms,
                             [(t_texture, Renderer.visible_to_fragment_shader())])
+        texture_slot = (0, 1 + len(uniforms))
         blend = Renderer.pre_multiplied_blend() if scene["blend"] == "premultiplied" else Renderer.additive_blend()
         primitive = Renderer.triangle_strip_primitive() if scene["topology"] == "strip" else Renderer.triangle_primitive()
         if scene["target"] == "screen":
@@ -168,7 +174,9 @@ class HipScene:
         r.set_attribute(self.pipeline, 0, scene["position"])
         r.set_attribute(self.pipeline, 1, scene["uv"])
         layer_px = tex.reshape(layers, -1)
-        r.set_texture(self.pipeline, (0, 1), [layer_px[i] for i in range(layers)])
+        r.set_texture(self.pipeline, texture_slot, [layer_px[i] for i in range(layers)])
+        if uniforms:
+            r.set_uniform(self.pipeline, (0, 1), scene["uniform"])
         r.set_instanced(self.pipeline, (0, 0), scene["instances"])
         self.clear = Renderer.clear_color(*scene["clear"]) if scene["clear"] is not None else None
         self.viewport = r.viewport(*scene["viewport"]) if scene["viewport"] is not None else None
@@ -216,3 +224,19 @@ def draw_hip(scene, clip_to_viewport=True, initial=None):
         return out
     finally:
         hs.close()
+
+
+def tilted_quads_scene(n, width, height, seed, blend="premultiplied", filter="linear"):
+    """Projective quads: per-vertex w (perspective-correct interpolation), three varyings, a uniform read by both
+    stages."""
+    rng = np.random.default_rng(seed)
+    cx = rng.uniform(-0.9, 0.9, n).astype(f32); cy = rng.uniform(-0.9, 0.9, n).astype(f32)
+    half = rng.uniform(0.02, 0.25, n).astype(f32)
+    tilt = rng.uniform(-0.8, 0.8, n).astype(f32)
+    tilt[::7] = 0.0                                   # some quads stay affine (w = 1 at every vertex)
+    scene = dict(shader="tilted", width=width, height=height, target="texture", position=UNIT_POSITION, uv=QUAD_UV,
+                 instances=np.stack([cx, cy, half, tilt], axis=1).astype(f32), texture=load_letter_f(),
+                 texture_format="rgba_u8", filter=filter, blend=blend, topology="strip", clear=(0.1, 0.1, 0.1, 1.0),
+                 viewport=None, record=False)
+    scene["uniform"] = np.array([1.0, 0.8, 0.6, 0.9, 1.0, 0.75], dtype=f32)
+    return scene

@@ -204,3 +204,12 @@ def test_no_instances_only_clears(oracle):
     hip = scenes.draw_hip(scene)
     assert_same(hip["color"], orc["color"], "empty")
     assert orc["fragments"] == 0 and (hip["color"] == hip["color"][0, 0]).all()
+
+
+@pytest.mark.parametrize("filter", ["linear", "nearest"])
+def test_projective_quads_uniforms_three_varyings(oracle, filter):
+    """Per-vertex w: perspective-correct interpolation (division by the interpolated 1/w), mixed with affine quads."""
+    scene = scenes.tilted_quads_scene(1500, 600, 400, seed=31, filter=filter)
+    orc = scenes.draw_oracle(scene)
+    hip = scenes.draw_hip(scene)
+    assert_same(hip["color"], orc["color"], f"tilted/{filter}")

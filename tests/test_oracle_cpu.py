@@ -248,3 +248,48 @@ def test_lz4_truncated_tail_is_tolerated(oracle):
     stream = s.finish()
     dec, consumed, complete = oracle.lz4_decompress_frame(stream[:-9], 200000)
     assert not complete and (b"abcdefgh" * 4000 + b"x" * 70000).startswith(dec) and len(dec) >= 32000
+
+
+def test_perspective_correct_interpolation_against_float64(oracle):
+    """One projective quad (per-vertex w) textured with a ramp: the texel the oracle samples at every covered pixel must
+    be the one perspective-correct interpolation gives in float64 (screen-space barycentrics divided by w)."""
+    W, H = 96, 64
+    ramp = np.zeros((1, 256, 4), dtype=np.uint8)
+    ramp[0, :, 0] = np.arange(256); ramp[0, :, 3] = 255
+    scene = scenes.tilted_quads_scene(1, W, H, seed=0, blend="additive", filter="nearest")
+    cx, cy, half, tilt = 0.05, -0.1, 0.7, 0.6
+    scene["instances"] = np.array([[cx, cy, half, tilt]], dtype=f32)
+    scene["uniform"] = np.array([1, 1, 1, 1, 1, 1], dtype=f32)
+    scene["texture"] = ramp
+    scene["clear"] = (0., 0., 0., 0.)
+    out = scenes.draw_oracle(scene)["color"]
+    corners = scenes.UNIT_POSITION.astype(np.float64)
+    w = 1.0 + corners[:, 0] * tilt
+    ndc = np.stack([corners[:, 0] * half + cx, corners[:, 1] * half + cy], axis=1)
+    sx = (ndc[:, 0] * 0.5 + 0.5) * W; sy = (0.5 - ndc[:, 1] * 0.5) * H
+    u_attr = scenes.QUAD_UV[:, 0].astype(np.float64)
+    shade_attr = corners[:, 1] * 0.25 + 0.75
+    checked = 0
+    for j in range(H):
+        for i in range(W):
+            if out[j, i, 3] == 0:
+                continue
+            px, py = i + 0.5, j + 0.5
+            ok = False
+            for tri in ((0, 1, 2), (1, 3, 2)):
+                (x0, y0), (x1, y1), (x2, y2) = [(sx[k], sy[k]) for k in tri]
+                den = (y1 - y2) * (x0 - x2) + (x2 - x1) * (y0 - y2)
+                m0 = ((y1 - y2) * (px - x2) + (x2 - x1) * (py - y2)) / den
+                m1 = ((y2 - y0) * (px - x2) + (x0 - x2) * (py - y2)) / den
+                m = np.array([m0, m1, 1 - m0 - m1])
+                if (m < -1e-6).any():
+                    continue
+                lam = m / w[list(tri)]; lam /= lam.sum()
+                u = float((lam * u_attr[list(tri)]).sum()); shade = float((lam * shade_attr[list(tri)]).sum())
+                texel = min(255, max(0, int(np.floor(u * 256))))
+                want_r = texel * shade            # (texel/255 * 1) * shade * 255
+                if abs(float(out[j, i, 0]) - want_r) <= 1.0 + 1.0 * shade:       # one texel either way + rounding
+                    ok = True
+            assert ok, f"pixel ({i}, {j}) = {out[j, i]}"
+            checked += 1
+    assert checked > 1500

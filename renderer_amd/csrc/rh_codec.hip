@@ -26,7 +26,7 @@ namespace {
 
 constexpr uint32_t KB64 = 65536u;
 constexpr int MINMATCH = 4, LASTLITERALS = 5, MFLIMIT = 12, LZ4_MINLENGTH = MFLIMIT + 1;
-constexpr int HASHLOG = 12, SKIP_TRIGGER = 6;
+constexpr int HASHLOG = 12;
 constexpr uint32_t DISTANCE_MAX = 65535u, ML_MASK = 15u, RUN_MASK = 15u;
 constexpr uint32_t BLOCK_UNCOMPRESSED_FLAG = 0x80000000u;
 constexpr uint32_t CUR = KB64;                // virtual offset of the current block
@@ -64,8 +64,6 @@ struct Ring {
     }
 };
 
-__device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
-
 // Number of equal bytes of ring[ip..] and ring[match..], stopping at `limit` (a virtual offset bounding ip).  256 bytes
 // per step.
 __device__ __forceinline__ uint32_t count_match(const Ring& R, uint32_t ip, uint32_t match, uint32_t limit, int lane) {
@@ -91,6 +89,10 @@ __device__ __forceinline__ uint32_t count_match(const Ring& R, uint32_t ip, uint
 // Cooperative copy of n bytes from the ring (virtual offset v) to global memory: bytes up to the first 4-byte boundary
 // of dst, then whole dwords, then the tail.
 __device__ __forceinline__ void copy_out(uint8_t* dst, const Ring& R, uint32_t v, uint32_t n, int lane) {
+    if (n <= 64u) {                                   // the usual literal run: one byte per lane
+        if ((uint32_t)lane < n) dst[lane] = (uint8_t)R.byte(v + (uint32_t)lane);
+        return;
+    }
     uint32_t head = (uint32_t)((4u - ((uintptr_t)dst & 3u)) & 3u);
     if (head > n) head = n;
     if ((uint32_t)lane < head) dst[lane] = (uint8_t)R.byte(v + (uint32_t)lane);
@@ -161,10 +163,10 @@ __device__ uint32_t compress_block(Lds& L, const Ring& R, Stream& st, uint32_t n
                     tests = (pre == 2u && idx == 1u);
                 } else {
                     const uint32_t k = idx - pre;
-                    p = w0 + walk(k);
                     // the sequential walk leaves for the last literals when the position after this one passes the
                     // limit, before it inserts or tests this one
-                    valid = w0 + walk(k + 1u) <= mflimit_plus_one;
+                    if (r0 == 0u) { p = w0 + k; valid = p + 1u <= mflimit_plus_one; }      // the first 65 steps advance by one
+                    else { p = w0 + walk(k); valid = w0 + walk(k + 1u) <= mflimit_plus_one; }
                 }
                 const unsigned long long vm = __ballot(valid);
                 uint32_t h = 0, seq = 0;
@@ -177,9 +179,13 @@ __device__ uint32_t compress_block(Lds& L, const Ring& R, Stream& st, uint32_t n
                 // candidate: the table entry, unless an earlier lane of this round has the same hash.  All valid lanes
                 // insert tentatively; a lane that does not read its own value back shares its hash with another lane.
                 uint32_t mi = 0, old = 0, back = 0;
-                // (volatile: other lanes write the same table, so a lane's own store must not be forwarded to its load)
-                volatile uint32_t* const table = L.hash;
-                if (valid) { old = table[h]; table[h] = mine; back = table[h]; }
+                // (other lanes write the same table, so a lane's own store must not be forwarded to its load: the
+                // compiler barrier makes the read-back a real LDS load; a volatile pointer would lose the LDS address
+                // space and turn these into flat accesses)
+                uint32_t* const table = L.hash;
+                if (valid) { old = table[h]; table[h] = mine; }
+                asm volatile("" ::: "memory");
+                if (valid) back = table[h];
                 mi = old;
                 unsigned long long same = 1ull << lane;                     // lanes of this round with the same hash
                 const bool collisions = __ballot(valid && back != mine) != 0ull;

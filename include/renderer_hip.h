@@ -255,6 +255,14 @@ int rh_compressor_peek(rh_compressor* c, uint32_t stream, const uint8_t** ptr, s
 int rh_compressor_consume(rh_compressor* c, uint32_t stream, size_t n);
 /* Flushes and appends the LZ4F end mark to `stream` (LZ4F_compressEnd, when the reference drops the writer). */
 int rh_compressor_finish_stream(rh_compressor* c, uint32_t stream);
+/* PngEncoder::encode_to_bytes (src/png_encoder.rs:6-38) on the device: encodes the captured frame held in `image`
+ * (RGBA8 rows `padded_bytes_per_row` apart, `width` x `height`, as src/video_recorder.rs:66-128 lays it out) as an 8-bit
+ * RGBA PNG and writes the complete file to `out` (host memory, `cap` bytes; *len = file size).  Only the finished PNG
+ * bytes cross PCIe.  The deflate stream differs from the `png` crate's; the decoded pixels are identical.  Fails when
+ * `cap` is too small: rh_png_bound gives a sufficient size. */
+size_t rh_png_bound(uint32_t width, uint32_t height);
+int rh_png_encode(rh_device* dev, rh_buffer* image, uint32_t width, uint32_t height, uint32_t padded_bytes_per_row,
+                  void* out, size_t cap, size_t* len);
 /* Host-side LZ4 frame decoder.  Tolerates a truncated tail (src/decompressor.rs:216-235 stops at an unclean end):
  * decoding stops after the last complete block; *complete is 1 when the end mark was reached. */
 int rh_lz4f_decompress(const void* src, size_t src_len, void* dst, size_t dst_cap, size_t* produced, size_t* consumed, int* complete);

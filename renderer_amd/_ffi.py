@@ -129,6 +129,8 @@ SIGNATURES = {
     "rh_compressor_pending": (C.c_size_t, [_P, C.c_uint32]),
     "rh_compressor_read": (C.c_int, [_P, C.c_uint32, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "rh_compressor_finish_stream": (C.c_int, [_P, C.c_uint32]),
+    "rh_png_bound": (C.c_size_t, [C.c_uint32, C.c_uint32]),
+    "rh_png_encode": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "rh_lz4f_decompress": (C.c_int, [_P, C.c_size_t, _P, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
 }
 

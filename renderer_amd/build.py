@@ -9,7 +9,7 @@ from .compiler import HIPCC, Compiler
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librenderer_hip.so")
-SOURCES = ["rh_api.cpp", "rh_kernels.hip", "rh_codec.hip"]
+SOURCES = ["rh_api.cpp", "rh_kernels.hip", "rh_codec.hip", "rh_png.hip"]
 
 
 def build_library(force=False):

@@ -35,6 +35,17 @@ struct PngEncoder {
         const auto pixels = frame.bytes();
         return encode_rows(pixels.first, frame.width, frame.height, frame.unpadded_bytes_per_row, frame.padded_bytes_per_row);
     }
+    // the frame's device buffer encoded on the GPU (rh_png_encode): only the finished PNG bytes are read back
+    static std::vector<uint8_t> encode_on_device(Renderer& renderer, const VideoFrame& frame, const char** error = nullptr) {
+        std::vector<uint8_t> out;
+        if (!frame.image_data) { if (error) *error = "VideoFrame could not be written because image_data is None."; return out; }
+        if (error) *error = nullptr;
+        out.resize(rh_png_bound(frame.width, frame.height));
+        size_t n = 0;
+        check(rh_png_encode(renderer.device, frame.image_data, frame.width, frame.height, frame.padded_bytes_per_row, out.data(), out.size(), &n));
+        out.resize(n);
+        return out;
+    }
     static std::vector<uint8_t> encode_rows(const uint8_t* rows, uint32_t width, uint32_t height, size_t unpadded, size_t padded) {
         using namespace png_detail;
         std::vector<uint8_t> out = { 0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a };

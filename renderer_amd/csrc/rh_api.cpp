@@ -71,6 +71,8 @@ struct rh_device {
     std::string name;
     // scratch for binning
     Scratch ranges, block_sums, chunk_tmp, keys_a, vals_a, keys_b, vals_b, hist, tile_start, tile_end;
+    Scratch png_slots, png_rows, png_out;          // GPU PNG encoder scratch
+    void* png_host = nullptr; size_t png_host_cap = 0;   // pinned
     unsigned long long* d_total = nullptr;
     unsigned long long* h_total = nullptr;      // pinned
     // allocation caches (exact-size reuse; capture buffers come and go every frame)
@@ -238,7 +240,7 @@ void device_release(rh_device* dev) {
     (void)hipSetDevice(dev->ordinal);
     (void)hipStreamSynchronize(dev->stream);
     Scratch* all[] = { &dev->ranges, &dev->block_sums, &dev->chunk_tmp, &dev->keys_a, &dev->vals_a, &dev->keys_b, &dev->vals_b,
-                       &dev->hist, &dev->tile_start, &dev->tile_end };
+                       &dev->hist, &dev->tile_start, &dev->tile_end, &dev->png_slots, &dev->png_rows, &dev->png_out };
     for (Scratch* s : all) s->release();
     for (hipEvent_t e : dev->event_pool) (void)hipEventDestroy(e);
     for (hipEvent_t e : dev->timing_events) (void)hipEventDestroy(e);
@@ -246,6 +248,7 @@ void device_release(rh_device* dev) {
     for (auto& kv : dev->free_pinned) (void)hipHostFree(kv.second);
     if (dev->d_total) (void)hipFree(dev->d_total);
     if (dev->h_total) (void)hipHostFree(dev->h_total);
+    if (dev->png_host) (void)hipHostFree(dev->png_host);
     (void)hipStreamDestroy(dev->stream);
     delete dev;
 }
@@ -850,6 +853,7 @@ int rh_device_last_pass_stats(rh_device* dev, rh_pass_stats* out) {
 
 // ---- capture codec --------------------------------------------------------------------------------------------------------
 #include "rh_codec.h"
+#include "rh_png.h"
 #include <deque>
 
 // Compressed bytes wait for the reader in segments: either a small owned vector (frame header, end mark) or a slice
@@ -1139,6 +1143,92 @@ int rh_compressor_finish_stream(rh_compressor* c, uint32_t stream) {
     if (rh_compressor_flush(c)) return 1;
     static const uint8_t end_mark[4] = { 0, 0, 0, 0 };
     push_owned(c, stream, end_mark, 4);
+    return 0;
+}
+
+// ---- GPU PNG encoder ------------------------------------------------------------------------------------------------------
+namespace {
+uint32_t png_slot_dwords(uint32_t width) { return (width * 36u + 160u) / 32u + 2u; }      // worst case: every pixel four 9-bit literals
+const uint32_t PNG_HEAD = 8 + 25, PNG_TAIL = 12;                                          // signature + IHDR, IEND
+
+uint32_t host_crc32(const uint8_t* p, size_t n) {
+    uint32_t c = 0xffffffffu;
+    for (size_t i = 0; i < n; i++) { c ^= p[i]; for (int k = 0; k < 8; k++) c = (c & 1u) ? (c >> 1) ^ 0xedb88320u : c >> 1; }
+    return c ^ 0xffffffffu;
+}
+} // namespace
+
+size_t rh_png_bound(uint32_t width, uint32_t height) {
+    return (size_t)PNG_HEAD + (size_t)height * (12u + (size_t)png_slot_dwords(width) * 4u) + 16u + PNG_TAIL;
+}
+
+int rh_png_encode(rh_device* dev, rh_buffer* image, uint32_t width, uint32_t height, uint32_t padded_bytes_per_row,
+                  void* out, size_t cap, size_t* len) {
+    if (!dev || !image || !out || !len) return fail("rh_png_encode: bad argument");
+    if (width == 0 || height == 0) return fail("rh_png_encode: empty image");
+    if ((uint64_t)width * 4u > padded_bytes_per_row || (padded_bytes_per_row & 3u)) return fail("rh_png_encode: row pitch %u does not hold %u RGBA8 pixels", padded_bytes_per_row, width);
+    if ((uint64_t)padded_bytes_per_row * height > image->size) return fail("rh_png_encode: the buffer holds %zu bytes, %u rows of %u are needed", image->size, height, padded_bytes_per_row);
+    if (width > (1u << 24)) return fail("rh_png_encode: image too wide");
+    if (set_device(dev)) return 1;
+    const uint32_t slot = png_slot_dwords(width);
+    const size_t out_dev = (size_t)height * (12u + (size_t)slot * 4u) + 16u;
+    const size_t rows_bytes = (size_t)height * (3 * 4 + 8) + 8;
+    if (dev->png_slots.ensure((size_t)height * slot * 4u) || dev->png_rows.ensure(rows_bytes) || dev->png_out.ensure(out_dev)) return 1;
+    if (dev->png_host_cap < out_dev) {
+        if (dev->png_host) (void)hipHostFree(dev->png_host);
+        dev->png_host = nullptr; dev->png_host_cap = 0;
+        RH_HIP(hipHostMalloc(&dev->png_host, out_dev + out_dev / 4, hipHostMallocDefault));
+        dev->png_host_cap = out_dev + out_dev / 4;
+    }
+    rh_png_args a;
+    memset(&a, 0, sizeof a);
+    a.image = (const uint8_t*)image->dptr; a.width = width; a.height = height; a.padded_bytes_per_row = padded_bytes_per_row;
+    const uint32_t stride = width * 4u + 1u;
+    a.up_ok = stride <= 32768u ? 1u : 0u;
+    if (a.up_ok) {
+        // fixed Huffman distance code (5 bits, sent most significant bit first) followed by its extra bits
+        const uint32_t d = stride - 1u;
+        uint32_t code, e;
+        if (d < 4u) { code = d; e = 0; }
+        else { e = (31u - (uint32_t)__builtin_clz(d)) - 1u; code = 2u * e + 2u + ((d >> e) & 1u); }
+        uint32_t rev = 0;
+        for (int k = 0; k < 5; k++) rev |= ((code >> k) & 1u) << (4 - k);
+        a.up_code = rev | ((d & ((1u << e) - 1u)) << 5);
+        a.up_code_bits = 5u + e;
+    }
+    a.slot_dwords = slot;
+    a.slots = dev->png_slots.as<uint32_t>();
+    uint8_t* rows = dev->png_rows.as<uint8_t>();
+    a.row_offset = (unsigned long long*)rows;
+    a.total_bytes = (unsigned long long*)(rows + (size_t)height * 8);
+    a.row_bytes = (uint32_t*)(rows + (size_t)height * 8 + 8);
+    a.row_s1 = a.row_bytes + height;
+    a.row_s2 = a.row_s1 + height;
+    a.out = dev->png_out.as<uint8_t>();
+    hipStream_t s = dev->stream;
+    rhk::png_encode_launch(a, s);
+    RH_HIP(hipGetLastError());
+    RH_HIP(hipMemcpyAsync(dev->h_total, a.total_bytes, 8, hipMemcpyDeviceToHost, s));
+    RH_HIP(hipStreamSynchronize(s));
+    const size_t idat = (size_t)*dev->h_total;
+    if (idat > out_dev) return fail("rh_png_encode: the encoder overran its output area");
+    const size_t total = (size_t)PNG_HEAD + idat + PNG_TAIL;
+    *len = total;
+    if (total > cap) return fail("rh_png_encode: %zu bytes are needed, the output holds %zu", total, cap);
+    RH_HIP(hipMemcpyAsync(dev->png_host, a.out, idat, hipMemcpyDeviceToHost, s));
+    RH_HIP(hipStreamSynchronize(s));
+    uint8_t* o = (uint8_t*)out;
+    static const uint8_t sig[8] = { 0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a };
+    memcpy(o, sig, 8);
+    uint8_t ihdr[25] = { 0, 0, 0, 13, 'I', 'H', 'D', 'R' };
+    for (int i = 0; i < 4; i++) { ihdr[8 + i] = (uint8_t)(width >> (24 - 8 * i)); ihdr[12 + i] = (uint8_t)(height >> (24 - 8 * i)); }
+    ihdr[16] = 8; ihdr[17] = 6; ihdr[18] = 0; ihdr[19] = 0; ihdr[20] = 0;       // 8 bit, RGBA, deflate, adaptive filtering, no interlace
+    const uint32_t c1 = host_crc32(ihdr + 4, 17);
+    for (int i = 0; i < 4; i++) ihdr[21 + i] = (uint8_t)(c1 >> (24 - 8 * i));
+    memcpy(o + 8, ihdr, 25);
+    memcpy(o + PNG_HEAD, dev->png_host, idat);
+    static const uint8_t iend[12] = { 0, 0, 0, 0, 'I', 'E', 'N', 'D', 0xae, 0x42, 0x60, 0x82 };
+    memcpy(o + PNG_HEAD + idat, iend, 12);
     return 0;
 }
 

@@ -28,6 +28,23 @@ class PngEncoder:
         return ("ok", b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", ihdr) + chunk(b"IDAT", idat) + chunk(b"IEND", b""))
 
     @staticmethod
+    def encode_on_device(renderer, video_frame):
+        """The same result type as encode_to_bytes for a frame whose image is a device buffer, encoded on the GPU
+        (librenderer_hip.so rh_png_encode): only the finished PNG bytes are read back.  The deflate stream differs
+        from zlib's; the decoded pixels are the same."""
+        import ctypes as C
+        from . import _ffi
+        if video_frame.image_data is None:
+            return ("err", "VideoFrame could not be written because image_data is None.")
+        L = _ffi.lib()
+        cap = L.rh_png_bound(video_frame.width, video_frame.height)
+        out = (C.c_uint8 * cap)()
+        n = C.c_size_t()
+        _ffi.check(L.rh_png_encode(renderer.device, video_frame.image_data.buffer(), video_frame.width, video_frame.height,
+                                   video_frame.padded_bytes_per_row, out, cap, C.byref(n)))
+        return ("ok", bytes(memoryview(out)[:n.value]))
+
+    @staticmethod
     def encode(video_frame, writer):
         status, value = PngEncoder.encode_to_bytes(video_frame)
         if status == "ok":

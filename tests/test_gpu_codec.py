@@ -178,3 +178,65 @@ def test_record_compress_decompress_roundtrip(oracle, tmp_path):
         assert np.array_equal(np.array(Image.open(io.BytesIO(png[1])).convert("RGBA")), want)
     assert os.listdir(tmp_path) == []          # removed after successful decompression
     hs.close(); r.close()
+
+
+def png_idat_stream(png):
+    """Concatenated IDAT payloads, checking every chunk's CRC on the way."""
+    import struct
+    import zlib
+    assert png[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, kinds = 8, b"", []
+    while pos < len(png):
+        n, tag = struct.unpack(">I4s", png[pos:pos + 8])
+        body = png[pos + 8:pos + 8 + n]
+        crc, = struct.unpack(">I", png[pos + 8 + n:pos + 12 + n])
+        assert zlib.crc32(tag + body) & 0xffffffff == crc, f"bad CRC in {tag} chunk at {pos}"
+        kinds.append(tag)
+        if tag == b"IDAT":
+            idat += body
+        pos += 12 + n
+    assert kinds[0] == b"IHDR" and kinds[-1] == b"IEND" and pos == len(png)
+    return idat
+
+
+@pytest.mark.parametrize("kind", ["scene", "noise", "flat", "stripes"])
+@pytest.mark.parametrize("size", [(640, 360), (67, 5), (1, 1)])
+def test_png_encoded_on_the_device_decodes_to_the_pixels(oracle, kind, size):
+    """GPU PNG encoder: a valid PNG (chunk CRCs, zlib stream with Adler-32) whose decoded pixels are the input's."""
+    import io
+    import zlib
+    from PIL import Image
+    from renderer_amd import PngEncoder, Renderer, _ffi
+    from renderer_amd.video_frame import FrameStatus, ImageData, VideoFrame
+    from renderer_amd.video_recorder import capture_layout
+    W, H = size
+    rng = np.random.default_rng(W * 1000 + H)
+    if kind == "scene":
+        pix = scenes.draw_oracle(scenes.random_quads_scene(60, 40, W, H, seed=5, clear=(0., 0., 0., 1.)) if W > 100
+                                 else scenes.random_quads_scene(2, 2, max(W, 2), max(H, 2), seed=5))["color"][:H, :W]
+        pix = np.ascontiguousarray(pix)
+    elif kind == "noise":
+        pix = rng.integers(0, 256, (H, W, 4), dtype=np.uint8)
+    elif kind == "flat":
+        pix = np.full((H, W, 4), 200, dtype=np.uint8)
+    else:
+        pix = np.zeros((H, W, 4), dtype=np.uint8)
+        pix[:, ::3] = [255, 0, 0, 255]; pix[::2] //= 2
+    unpadded, padded, frame_size = capture_layout(W, H, 4)
+    rows = np.zeros((H, padded), dtype=np.uint8)
+    rows[:, :unpadded] = pix.reshape(H, unpadded)
+    rows[:, unpadded:] = 0xee                         # the padding must not leak into the image
+    r = Renderer(64, 64)
+    L = _ffi.lib()
+    buf = C.c_void_p()
+    _ffi.check(L.rh_buffer_create(r.device, frame_size, _ffi.BUFFER_COPY_DST | _ffi.BUFFER_MAP_READ, rows.ctypes.data, rows.nbytes, C.byref(buf)))
+    frame = VideoFrame(FrameStatus.Captured, ImageData.Buffer(buf), W, H, 2, unpadded, padded, 1, frame_size)
+    status, png = PngEncoder.encode_on_device(r, frame)
+    assert status == "ok"
+    raw = zlib.decompress(png_idat_stream(png))
+    assert len(raw) == H * (1 + W * 4)
+    got = np.array(Image.open(io.BytesIO(png)).convert("RGBA"))
+    assert np.array_equal(got, pix)
+    if kind == "flat" and W * H > 100000:
+        assert len(png) < pix.nbytes // 20            # runs really are encoded as matches
+    frame.drop(); r.close()

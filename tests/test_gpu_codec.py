@@ -240,3 +240,23 @@ def test_png_encoded_on_the_device_decodes_to_the_pixels(oracle, kind, size):
     if kind == "flat" and W * H > 100000:
         assert len(png) < pix.nbytes // 20            # runs really are encoded as matches
     frame.drop(); r.close()
+
+
+def test_frame_parallel_recording_to_one_ordered_png_stream(oracle):
+    """tools/record_frame_parallel.py at world size 1: frames rendered, recorded, PNG-encoded on the GPU and written in
+    frame order as the concatenated PNG stream ffmpeg's image2pipe reads; every PNG decodes to the oracle's frame."""
+    import io
+    import sys
+    from PIL import Image
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import record_frame_parallel
+    W, H, n = 320, 180, 5
+    got = []
+    rendered = record_frame_parallel.record(n, W, H, lambda f, png: got.append((f, png)))
+    assert rendered == n and [f for f, _ in got] == list(range(1, n + 1))
+    from renderer_amd.viewport import Viewport
+    vp = Viewport(1.0, 1.0, float(W), float(H))
+    x0, y0, w, h = int(np.ceil(vp.margin_x)), int(np.ceil(vp.margin_y)), int(vp.width), int(vp.height)
+    for f, png in got:
+        want = scenes.draw_oracle(scenes.example_scene(f, width=W, height=H, record=True))["recording"][y0:y0 + h, x0:x0 + w]
+        assert np.array_equal(np.array(Image.open(io.BytesIO(png)).convert("RGBA")), want), f"frame {f}"

@@ -110,21 +110,38 @@ def main():
            "raw_MB_per_frame": info["raw_MB_per_frame"], "compressed_MB_per_frame": info["compressed_MB_per_frame"],
            "raw_GBps": info["raw_MB_per_frame"] * args.frames / elapsed / 1e3}
 
-    # CPU baseline: liblz4 1.9.3 level 0, one stream on one core, the last recorded frame repeated
-    from oracle import loader as O
+    # CPU baseline: the system's liblz4 (what the reference links through lzzzz) with the reference's preferences
+    # (level 0, auto-flush; reference src/compressor.rs:138-144), one stream on one core, the last recorded frame repeated
     import ctypes as C
-    s = O.LibLz4Stream(0)
+
+    class Prefs(C.Structure):              # LZ4F_preferences_t of lz4frame.h 1.9.x
+        _fields_ = [("blockSizeID", C.c_uint32), ("blockMode", C.c_uint32), ("contentChecksumFlag", C.c_uint32),
+                    ("frameType", C.c_uint32), ("contentSize", C.c_uint64), ("dictID", C.c_uint32),
+                    ("blockChecksumFlag", C.c_uint32), ("compressionLevel", C.c_int32), ("autoFlush", C.c_uint32),
+                    ("favorDecSpeed", C.c_uint32), ("reserved", C.c_uint32 * 3)]
+
+    L = C.CDLL("liblz4.so.1")
+    L.LZ4F_createCompressionContext.argtypes = [C.POINTER(C.c_void_p), C.c_uint]; L.LZ4F_createCompressionContext.restype = C.c_size_t
+    L.LZ4F_compressBegin.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]; L.LZ4F_compressBegin.restype = C.c_size_t
+    L.LZ4F_compressBound.argtypes = [C.c_size_t, C.c_void_p]; L.LZ4F_compressBound.restype = C.c_size_t
+    L.LZ4F_compressUpdate.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.LZ4F_compressUpdate.restype = C.c_size_t
+    L.LZ4F_isError.argtypes = [C.c_size_t]; L.LZ4F_isError.restype = C.c_uint
+    ctx, prefs = C.c_void_p(), Prefs()
+    prefs.autoFlush = 1
+    assert not L.LZ4F_isError(L.LZ4F_createCompressionContext(C.byref(ctx), 100))
+    head = (C.c_uint8 * 32)()
+    assert not L.LZ4F_isError(L.LZ4F_compressBegin(ctx, head, 32, C.byref(prefs)))
     img = np.ascontiguousarray(last).tobytes()
     src = (C.c_uint8 * len(img)).from_buffer_copy(img)
-    cap = s.L.LZ4F_compressBound(len(img), C.byref(s.prefs))
+    cap = L.LZ4F_compressBound(len(img), C.byref(prefs))
     dst = (C.c_uint8 * cap)()
-    s.write((16 + 23 + len(img)).to_bytes(8, "big")); s.write((23).to_bytes(8, "big")); s.write(bytes(23))
     cpu_s = 0.0
     for _ in range(args.cpu_frames):                           # only the library call on the image is timed
         t1 = time.perf_counter()
-        n = s.L.LZ4F_compressUpdate(s.ctx, dst, cap, src, len(img), None)
+        n = L.LZ4F_compressUpdate(ctx, dst, cap, src, len(img), None)
         cpu_s += time.perf_counter() - t1
-        assert not s.L.LZ4F_isError(n)
+        assert not L.LZ4F_isError(n)
     out["cpu_baseline"] = {"value": args.cpu_frames / cpu_s, "unit": "frames/s", "cores": 1, "kind": "reference-library",
                            "sample": f"liblz4 1.9.3 level 0, {args.cpu_frames} frames of {len(img)} B on one core "
                                      f"(compress only, no rendering), {cpu_s:.2f} s"}

@@ -96,7 +96,9 @@ def render(shader, topology, vertex_count, instance_count, attrs, storage, textu
         u = np.ascontiguousarray(u, dtype=np.float32); keep.append(u)
         d.uniform[i] = u.ctypes.data
     for i, (data, w, h, layers, fmt, flt) in enumerate(textures):
-        data = np.ascontiguousarray(data, dtype=np.uint8); keep.append(data)
+        data = np.ascontiguousarray(data)
+        data = data.view(np.uint8) if data.dtype != np.uint8 else data      # float texels travel as raw bytes
+        keep.append(data)
         d.tex[i] = OrcTexture(data.ctypes.data, w, h, layers, fmt, flt)
     if viewport is not None:
         d.has_viewport = 1

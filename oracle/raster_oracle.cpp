@@ -107,11 +107,25 @@ struct Shader {
 // ClampToEdge on every axis, mag = min = filter, one mip level (reference src/texture.rs:141-158).
 inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+// IEEE binary16 -> binary32, exact (subnormals, infinities and NaNs included)
+inline float half_to_float(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, exp = (h >> 10) & 0x1fu, man = h & 0x3ffu;
+    uint32_t bits;
+    if (exp == 0) {
+        if (man == 0) bits = sign;
+        else { int e = -1; uint32_t m = man; do { e++; m <<= 1; } while (!(m & 0x400u)); bits = sign | ((uint32_t)(127 - 15 - e) << 23) | ((m & 0x3ffu) << 13); }
+    } else if (exp == 31) bits = sign | 0x7f800000u | (man << 13);
+    else bits = sign | ((exp + 112u) << 23) | (man << 13);
+    float f; std::memcpy(&f, &bits, 4); return f;
+}
+
 inline void fetch_texel(const orc_texture& t, int x, int y, uint32_t layer, float out[4]) {
     size_t idx = ((size_t)layer * t.height + (size_t)y) * t.width + (size_t)x;
     switch (t.format) {
     case ORC_FMT_R_U8: out[0] = (float)t.data[idx]; out[1] = 0.0f; out[2] = 0.0f; out[3] = 255.0f; break;
     case ORC_FMT_BGRA_U8: { const uint8_t* p = t.data + idx * 4; out[0] = p[2]; out[1] = p[1]; out[2] = p[0]; out[3] = p[3]; break; }
+    case ORC_FMT_RGBA_F32: { float f[4]; std::memcpy(f, t.data + idx * 16, 16); for (int k = 0; k < 4; k++) out[k] = f[k]; break; }
+    case ORC_FMT_RGBA_F16: { uint16_t h[4]; std::memcpy(h, t.data + idx * 8, 8); for (int k = 0; k < 4; k++) out[k] = half_to_float(h[k]); break; }
     default: { const uint8_t* p = t.data + idx * 4; out[0] = p[0]; out[1] = p[1]; out[2] = p[2]; out[3] = p[3]; break; }
     }
 }
@@ -127,12 +141,14 @@ inline void fetch_texel(const orc_texture& t, int x, int y, uint32_t layer, floa
 void sample_2d(const orc_texture& t, float s, float tc, uint32_t layer, float out[4]) {
     const int W = (int)t.width, H = (int)t.height;
     if (layer >= t.layers) layer = t.layers - 1;
+    // 8-bit texels are filtered on the 0..255 scale and normalised once at the end; float texels are not scaled
+    const float scale = (t.format == ORC_FMT_RGBA_F16 || t.format == ORC_FMT_RGBA_F32) ? 1.0f : INV_255;
     if (t.filter == ORC_FILTER_NEAREST) {
         float u = floorf(s * (float)W), v = floorf(tc * (float)H);
         u = fminf(fmaxf(u, -1.0f), (float)W); v = fminf(fmaxf(v, -1.0f), (float)H);
         int i = clampi((int)u, 0, W - 1), j = clampi((int)v, 0, H - 1);
         float c[4]; fetch_texel(t, i, j, layer, c);
-        for (int k = 0; k < 4; k++) out[k] = c[k] * INV_255;
+        for (int k = 0; k < 4; k++) out[k] = c[k] * scale;
         return;
     }
     const float u = fmaf(s, (float)W, -0.5f), v = fmaf(tc, (float)H, -0.5f);
@@ -148,7 +164,7 @@ void sample_2d(const orc_texture& t, float s, float tc, uint32_t layer, float ou
         float top = fmaf(a, t10[k] - t00[k], t00[k]);
         float bot = fmaf(a, t11[k] - t01[k], t01[k]);
         float c = fmaf(b, bot, fmaf(-b, top, top));
-        out[k] = c * INV_255;
+        out[k] = c * scale;
     }
 }
 

@@ -543,7 +543,7 @@ int rh_pipeline_create(rh_device* dev, const rh_pipeline_desc* d, rh_pipeline** 
         case RH_SLOT_STORAGE: case RH_SLOT_UNIFORM: r.buf = (rh_buffer*)s.resource; break;
         case RH_SLOT_TEXTURE: {
             r.tex = (rh_texture*)s.resource;
-            if (r.tex->format != RH_FORMAT_RGBA_U8 && r.tex->format != RH_FORMAT_BGRA_U8 && r.tex->format != RH_FORMAT_R_U8) { delete p; return fail("rh_pipeline_create: sampling format %u is not implemented", r.tex->format); }
+            if (r.tex->format > RH_FORMAT_RGBA_F32) { delete p; return fail("rh_pipeline_create: sampling format %u is not implemented", r.tex->format); }
             break;
         }
         case RH_SLOT_SAMPLER: r.filter = ((rh_sampler*)s.resource)->filter; break;

@@ -21,7 +21,7 @@ namespace rh {
 
 constexpr float INV_255 = 1.0f / 255.0f;
 
-enum : uint32_t { FORMAT_R_U8 = 0, FORMAT_BGRA_U8 = 1, FORMAT_RGBA_U8 = 2 };
+enum : uint32_t { FORMAT_R_U8 = 0, FORMAT_BGRA_U8 = 1, FORMAT_RGBA_U8 = 2, FORMAT_RGBA_F16 = 3, FORMAT_RGBA_F32 = 4 };
 enum : uint32_t { FILTER_LINEAR = 0, FILTER_NEAREST = 1 };
 
 // `static_*` members are compile-time constants in the specialised kernel bodies (0 = decide at run time): after
@@ -37,11 +37,17 @@ struct Texture2D {
     const uint8_t* data; uint32_t width, height, layers, format;
     uint32_t static_rgba8;      // 1: known to be RGBA8 and at least 2x2
 
-    // Texel (x, y) of `layer`, channels on the 0..255 scale (generic path, any supported format).
+    // Texel (x, y) of `layer` (generic path, any supported format): 8-bit channels on the 0..255 scale, float channels
+    // as they are (a half converts to float exactly).
     RH_DEVICE float4 fetch(int x, int y, uint32_t layer) const {
         const uint32_t format = static_rgba8 ? (uint32_t)FORMAT_RGBA_U8 : this->format;
         const uint32_t idx = (layer * height + (uint32_t)y) * width + (uint32_t)x;
         if (format == FORMAT_R_U8) return make_float4((float)data[idx], 0.0f, 0.0f, 255.0f);
+        if (format == FORMAT_RGBA_F32) return *reinterpret_cast<const float4*>(data + ((size_t)idx << 4));
+        if (format == FORMAT_RGBA_F16) {
+            const _Float16* h = reinterpret_cast<const _Float16*>(data + ((size_t)idx << 3));
+            return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+        }
         const uint32_t t = *reinterpret_cast<const uint32_t*>(data + (idx << 2));
         const float c0 = (float)(t & 0xffu), c1 = (float)((t >> 8) & 0xffu), c2 = (float)((t >> 16) & 0xffu), c3 = (float)(t >> 24);
         if (format == FORMAT_BGRA_U8) return make_float4(c2, c1, c0, c3);
@@ -60,12 +66,14 @@ struct Texture2D {
         const uint32_t format = static_rgba8 ? (uint32_t)FORMAT_RGBA_U8 : this->format;
         const uint32_t filter = s.static_filter ? s.static_filter - 1u : s.filter;
         if (layer >= layers) layer = layers - 1;
+        // 8-bit texels are filtered on the 0..255 scale and normalised once at the end; float texels are not scaled
+        const float scale = (format == FORMAT_RGBA_F16 || format == FORMAT_RGBA_F32) ? 1.0f : INV_255;
         if (filter == FILTER_NEAREST) {
             float u = floorf(uv.x * (float)W), v = floorf(uv.y * (float)H);
             u = fminf(fmaxf(u, -1.0f), (float)W); v = fminf(fmaxf(v, -1.0f), (float)H);
             int i = min(max((int)u, 0), W - 1), j = min(max((int)v, 0), H - 1);
             float4 c = fetch(i, j, layer);
-            return make_float4(c.x * INV_255, c.y * INV_255, c.z * INV_255, c.w * INV_255);
+            return make_float4(c.x * scale, c.y * scale, c.z * scale, c.w * scale);
         }
         const float u = __builtin_fmaf(uv.x, (float)W, -0.5f), v = __builtin_fmaf(uv.y, (float)H, -0.5f);
         const float ibf = floorf(fminf(fmaxf(u, 0.0f), (float)(W >= 2 ? W - 2 : 0)));
@@ -73,7 +81,7 @@ struct Texture2D {
         const float a = fminf(fmaxf(u - ibf, 0.0f), 1.0f), b = fminf(fmaxf(v - jbf, 0.0f), 1.0f);
         const int ib = (int)ibf, jb = (int)jbf;
         float4 t00, t10, t01, t11;
-        if (static_rgba8 || (format != FORMAT_R_U8 && W >= 2 && H >= 2)) {
+        if (static_rgba8 || ((format == FORMAT_RGBA_U8 || format == FORMAT_BGRA_U8) && W >= 2 && H >= 2)) {
             // 4-byte texels: the taps of a row are adjacent and the rows are one pitch apart: two 8-byte loads
             const uint32_t off = (__umul24(layer * height + (uint32_t)jb, width) + (uint32_t)ib) << 2;
             const u32x2_a4 r0 = *reinterpret_cast<const u32x2_a4*>(data + off);
@@ -93,7 +101,7 @@ struct Texture2D {
         float4 r;
 #define RH_LERP2(ch) { const float top = __builtin_fmaf(a, t10.ch - t00.ch, t00.ch); \
                        const float bot = __builtin_fmaf(a, t11.ch - t01.ch, t01.ch); \
-                       r.ch = __builtin_fmaf(b, bot, __builtin_fmaf(-b, top, top)) * INV_255; }
+                       r.ch = __builtin_fmaf(b, bot, __builtin_fmaf(-b, top, top)) * scale; }
         RH_LERP2(x) RH_LERP2(y) RH_LERP2(z) RH_LERP2(w)
 #undef RH_LERP2
         if (format == FORMAT_BGRA_U8) return make_float4(r.z, r.y, r.x, r.w);

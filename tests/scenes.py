@@ -2,7 +2,8 @@
 both by the HIP renderer (through renderer_amd, i.e. the C ABI) and by the CPU oracle.
 
 Scene keys
-  shader        'hello' | 'sized' | 'tilted' (projective quads; needs 'uniform': float32 [6])
+  shader        'hello' | 'sized' | 'tilted' (projective quads; needs 'uniform': float32 [6]) |
+                'layered' (hello sampling layer uniform[0] of a 2D-array texture; needs 'uniform' and 'texture_layers')
   width,height  window / target size
   target        'screen' (BGRA8 offscreen screen) | 'texture' (RGBA8 texture target)
   position,uv   per-vertex attributes (location 0 and 1), float32 [V, 2]
@@ -106,11 +107,13 @@ def draw_oracle(scene, threads=0, clip_to_viewport=True, initial=None):
         v = Viewport(scene["viewport"][0], scene["viewport"][1], float(W), float(H))
         viewport = (v.margin_x, v.margin_y, v.width, v.height)
     tex = scene["texture"]
-    tfmt = {"rgba_u8": O.FMT_RGBA_U8, "bgra_u8": O.FMT_BGRA_U8, "r_u8": O.FMT_R_U8}[scene["texture_format"]]
+    tfmt = {"rgba_u8": O.FMT_RGBA_U8, "bgra_u8": O.FMT_BGRA_U8, "r_u8": O.FMT_R_U8, "rgba_f16": O.FMT_RGBA_F16,
+            "rgba_f32": O.FMT_RGBA_F32}[scene["texture_format"]]
     layers = scene.get("texture_layers", 1)
     th, tw = (tex.shape[0] // layers, tex.shape[1])
     blend = {"premultiplied": (O.BF_ONE, O.BF_ONE_MINUS_SRC_ALPHA), "additive": (O.BF_ONE, O.BF_ONE)}[scene["blend"]]
-    n = O.render(shader={"hello": O.SHADER_HELLO, "sized": O.SHADER_SIZED, "tilted": O.SHADER_TILTED}[scene["shader"]],
+    n = O.render(shader={"hello": O.SHADER_HELLO, "sized": O.SHADER_SIZED, "tilted": O.SHADER_TILTED,
+                         "layered": O.SHADER_HELLO_LAYER}[scene["shader"]],
                  uniforms=[scene["uniform"]] if "uniform" in scene else (),
                  topology=O.TOPO_TRIANGLE_STRIP if scene["topology"] == "strip" else O.TOPO_TRIANGLE_LIST,
                  vertex_count=len(scene["position"]), instance_count=len(scene["instances"]),
@@ -149,7 +152,8 @@ class HipScene:
         tex = scene["texture"]
         layers = scene.get("texture_layers", 1)
         th, tw = tex.shape[0] // layers, tex.shape[1]
-        fmt = {"rgba_u8": Renderer.rgba_u8(), "bgra_u8": Renderer.bgra_u8(), "r_u8": Renderer.red_u8()}[scene["texture_format"]]
+        fmt = {"rgba_u8": Renderer.rgba_u8(), "bgra_u8": Renderer.bgra_u8(), "r_u8": Renderer.red_u8(),
+               "rgba_f16": Renderer.rgba_f16(), "rgba_f32": Renderer.rgba_f32()}[scene["texture_format"]]
         flt = Renderer.linear_filtering() if scene["filter"] == "linear" else Renderer.nearest_filtering()
         a_position = r.attribute(0, 2)
         a_tex_coord = r.attribute(1, 2)

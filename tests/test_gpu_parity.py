@@ -213,3 +213,44 @@ def test_projective_quads_uniforms_three_varyings(oracle, filter):
     orc = scenes.draw_oracle(scene)
     hip = scenes.draw_hip(scene)
     assert_same(hip["color"], orc["color"], f"tilted/{filter}")
+
+
+@pytest.mark.parametrize("fmt", ["rgba_f16", "rgba_f32"])
+@pytest.mark.parametrize("filter", ["linear", "nearest"])
+def test_float_textures(oracle, fmt, filter):
+    """RGBA16F / RGBA32F textures: texels are used as they are (no 1/255), values above 1 saturate in the ROP."""
+    rng = np.random.default_rng(41)
+    tex = rng.uniform(-0.2, 1.3, (19, 23, 4)).astype(np.float16 if fmt == "rgba_f16" else np.float32)
+    tex[0, 0] = [np.inf, -np.inf, 0.0, 1.0]
+    if fmt == "rgba_f16":
+        tex[1, 1] = np.array([6e-8, 6e-5, 65504.0, 0.5], dtype=np.float16)        # subnormal, smallest normal, largest
+    scene = scenes.random_quads_scene(2500, 20, 400, 300, seed=41, filter=filter, texture=tex)
+    scene["texture_format"] = fmt
+    orc = scenes.draw_oracle(scene)
+    hip = scenes.draw_hip(scene)
+    assert_same(hip["color"], orc["color"], f"{fmt}/{filter}")
+
+
+def test_texture_array_layers_and_sub_rectangle_upload(oracle):
+    """A 3-layer texture, the sampled layer chosen by a uniform; then part of that layer replaced with
+    set_part_of_texture (reference src/renderer.rs:156-162, src/texture.rs:45-56)."""
+    rng = np.random.default_rng(42)
+    layers, th, tw = 3, 16, 24
+    tex = rng.integers(0, 256, (layers * th, tw, 4), dtype=np.uint8)
+    tex[..., 3] = 255
+    for layer in range(layers):
+        scene = scenes.random_quads_scene(800, 30, 320, 200, seed=42, texture=tex)
+        scene.update(shader="layered", texture_layers=layers, uniform=np.array([float(layer)], dtype=np.float32))
+        assert_same(scenes.draw_hip(scene)["color"], scenes.draw_oracle(scene)["color"], f"layer {layer}")
+    # sub-rectangle upload into layer 1
+    scene = scenes.random_quads_scene(800, 30, 320, 200, seed=43, texture=tex)
+    scene.update(shader="layered", texture_layers=layers, uniform=np.array([1.0], dtype=np.float32))
+    patch = rng.integers(0, 256, (5, 7, 4), dtype=np.uint8)
+    hs = scenes.HipScene(scene)
+    hs.renderer.set_part_of_texture(hs.pipeline, (0, 2), (3, 4, 1), (7, 5), patch)
+    hs.draw()
+    got = hs.read_color(); hs.close()
+    tex2 = tex.copy()
+    tex2[th + 4:th + 9, 3:10] = patch
+    want = scenes.draw_oracle(dict(scene, texture=tex2))["color"]
+    assert_same(got, want, "sub-rectangle")

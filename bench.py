@@ -42,6 +42,11 @@ def pmc_traffic_bytes():
 
 
 def main():
+    # Libraries underneath (RCCL prints a version banner at start-up) write to stdout: keep the real stdout for the one
+    # JSON line and send everything else to stderr.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
@@ -65,7 +70,9 @@ def main():
     n_gpus = max(args.gpus, world)
 
     dist = None
-    if world > 1:
+    if world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ):
+        # launched by torch.distributed.run: one rank per GPU.  torch is imported before the renderer's library on
+        # purpose: it bundles a HIP runtime of its own and the two must share one (see renderer_amd/partition.py).
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -192,7 +199,8 @@ def main():
                                              f"on {cores} threads, {cpu_s:.2f} s wall; CPU restatement, not lavapipe"}
         if capture is not None:
             out["capture"] = capture
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
 
     if dist is not None:
         dist.destroy_process_group()

@@ -144,6 +144,11 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RendererError(f"{LIB_PATH} is missing: run `python -m renderer_amd.build` (needs hipcc) first; "
                                 "there is no CPU fallback")
+        # PyTorch bundles a HIP runtime with the system runtime's soname.  When torch is going to touch the GPU in this
+        # process (torch.distributed over RCCL, tensors aliasing renderer memory) it has to be loaded before this library,
+        # so that both share the one runtime; RH_HIP_RUNTIME=torch asks for that explicitly.
+        if os.environ.get("RH_HIP_RUNTIME") == "torch":
+            import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         for name, (restype, argtypes) in SIGNATURES.items():
             fn = getattr(L, name)

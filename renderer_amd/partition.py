@@ -9,6 +9,9 @@
 
 The only exchange steps are gathers of finished results to rank 0 (encoded frames for a single ordered sink such as the
 ffmpeg pipe; strips of a target that a later pass samples), done with torch.distributed (RCCL on GPUs, gloo on CPU).
+
+PyTorch bundles its own HIP runtime: a process that uses torch on the GPU together with the renderer must import torch
+before the renderer's library is loaded (or set RH_HIP_RUNTIME=torch), so that both share one runtime.
 """
 TILE = 32
 
@@ -79,3 +82,38 @@ def all_gather_strips(strip, height, device="cpu", group=None):
     parts = [torch.empty_like(padded) for _ in range(world)]
     dist.all_gather(parts, padded, group=group)
     return torch.cat([parts[r][:rows[r][1] - rows[r][0]] for r in range(world)], dim=0)
+
+
+class _DeviceArray:
+    """Exposes a device allocation of the renderer to torch through __cuda_array_interface__ (no copy)."""
+
+    def __init__(self, ptr, shape, typestr="|u1"):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+def texture_as_tensor(texture, device):
+    """The texels of an RGBA8/BGRA8 texture (layer 0) as a torch uint8 tensor [height, width, 4] that aliases the
+    texture's device memory: what the strip all-gather sends and receives."""
+    import torch
+    from . import _ffi
+    w, h, _ = texture.size
+    ptr = _ffi.lib().rh_texture_device_ptr(texture.handle)
+    return torch.as_tensor(_DeviceArray(ptr, (h, w, 4)), device=device)
+
+
+def exchange_strips(renderer, texture, rank, world, device, group=None):
+    """After every rank has rendered its strip of `texture` (Renderer.set_strip(*strip_for_rank(...))), makes the whole
+    image present on every rank: the strips are all-gathered (RCCL over xGMI between GPUs) straight out of and into the
+    texture's device memory, so that a following pass can sample the complete target."""
+    import torch.distributed as dist
+    renderer.synchronize()                       # the strip is rendered on the renderer's own HIP stream
+    if world == 1:
+        return
+    image = texture_as_tensor(texture, device)
+    height = image.shape[0]
+    r0, r1 = strip_for_rank(height, rank, world)
+    full = all_gather_strips(image[r0:r1], height, device=device, group=group)
+    image.copy_(full)
+    import torch
+    torch.cuda.synchronize()
+    del dist

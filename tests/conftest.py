@@ -8,6 +8,15 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# PyTorch ships its own HIP runtime with the same soname as the system's.  A process that uses both torch's GPU side and
+# librenderer_hip.so must load torch first, so that the renderer binds to the runtime torch already loaded; the other
+# order leaves two runtimes in the process and the second one finds no GPU.  Some GPU tests use torch (strip exchange).
+try:
+    import torch  # noqa: F401,E402
+except ImportError:
+    pass
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

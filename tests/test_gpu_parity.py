@@ -254,3 +254,36 @@ def test_texture_array_layers_and_sub_rectangle_upload(oracle):
     tex2[th + 4:th + 9, 3:10] = patch
     want = scenes.draw_oracle(dict(scene, texture=tex2))["color"]
     assert_same(got, want, "sub-rectangle")
+
+
+def test_two_pass_with_target_bound_as_texture(oracle):
+    """tools/render_strips.py at world size 1: pass 2 samples the texture pass 1 rendered into, bound directly (no copy);
+    the torch view of the texture's device memory used by the strip exchange aliases the real texels."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import render_strips
+    S = 160
+    image, _ = render_strips.render_two_pass(S, 300, 24, seed=3)
+    s1 = scenes.random_quads_scene(300, 24, S, S, seed=3)
+    a_img = scenes.draw_oracle(s1)["color"]
+    s2 = dict(shader="hello", width=S, height=S, target="texture", position=scenes.UNIT_POSITION, uv=scenes.QUAD_UV,
+              instances=np.zeros((1, 2), dtype=np.float32), texture=a_img, texture_format="rgba_u8", filter="linear",
+              blend="premultiplied", topology="strip", clear=(0., 0., 0., 1.), viewport=None, record=False)
+    assert_same(image, scenes.draw_oracle(s2)["color"], "two-pass")
+
+
+def test_texture_memory_as_torch_tensor(oracle):
+    import torch
+    from renderer_amd import Renderer, partition
+    r = Renderer(64, 64)
+    tex = r.texture(40, 24, 1, Renderer.nearest_filtering(), Renderer.rgba_u8(), True, True, False)
+    pixels = np.random.default_rng(1).integers(0, 256, (24, 40, 4), dtype=np.uint8)
+    tex.set_data((0, 0, 0), (0, 0), pixels)
+    r.synchronize()
+    t = partition.texture_as_tensor(tex, "cuda:0")
+    assert t.shape == (24, 40, 4) and np.array_equal(t.cpu().numpy(), pixels)
+    t[3:5] = 7                                   # writes land in the texture
+    torch.cuda.synchronize()
+    assert (tex.read()[3:5] == 7).all()
+    r.close()

@@ -70,6 +70,8 @@ def main():
     args = ap.parse_args()
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch  # noqa: F401  (before the renderer's library: one shared HIP runtime)
     dist, device = None, "cpu"
     if world > 1:
         import torch

@@ -19,6 +19,7 @@ from .pipeline import BINDINGS_PER_GROUP, Pipeline, RecordingPosition
 from .primitive import Primitive
 from .program import Program
 from .render_pass import RenderPass
+from .render_thread import RenderThread
 from .renderer import Renderer
 from .target import Target
 from .texture import Texture

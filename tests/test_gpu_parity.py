@@ -287,3 +287,47 @@ def test_texture_memory_as_torch_tensor(oracle):
     torch.cuda.synchronize()
     assert (tex.read()[3:5] == 7).all()
     r.close()
+
+
+def test_render_thread_proxy_runs_the_quads_example(oracle):
+    """reference examples/quads_render_thread.rs shape: every call goes through the RenderThread proxy (index handles,
+    messages executed in order on a worker thread that owns the Renderer); recorded frames equal the oracle's."""
+    from renderer_amd import RenderThread, Renderer
+    W, H = 320, 180
+    rt = RenderThread(W, H)
+    vert, frag = scenes.shader_code("hello")
+    a_position, a_tex_coord, i_offset = rt.attribute(0, 2), rt.attribute(1, 2), rt.instanced()
+    t_texture = rt.texture(256, 256, 1, Renderer.linear_filtering(), Renderer.rgba_u8(), False, False, True)
+    program = rt.program(vert, frag, [a_position, a_tex_coord], [i_offset], [], [(t_texture, Renderer.visible_to_fragment_shader())])
+    pipeline = rt.pipeline(program, Renderer.pre_multiplied_blend(), Renderer.triangle_strip_primitive(), 1, [RenderThread.screen_target()])
+    clear = Renderer.clear_color(0., 0., 0., 1.)
+    rt.set_attribute(pipeline, 0, scenes.QUAD_POSITION)
+    rt.set_attribute(pipeline, 1, scenes.QUAD_UV)
+    rt.set_texture(pipeline, (0, 1), [scenes.load_letter_f().reshape(-1)])
+    frames = []
+
+    def on_frame(video_frame):                   # runs on the render thread
+        got = []
+        video_frame.image_data.bytes_fn(lambda b: got.append(np.array(b, copy=True)))
+        frames.append((video_frame.frame_number, video_frame.width, video_frame.height, video_frame.padded_bytes_per_row, got[0]))
+        video_frame.drop()
+
+    rt.start_recording([pipeline], clear, 100., on_frame)
+    rt.flush()
+    n = 4
+    for k in range(1, n + 1):
+        rt.set_instanced(pipeline, (0, 0), scenes.example_positions(k))
+        rt.render(pipeline, clear, rt.viewport(1., 1.), (2, 4))
+        rt.finish_frame()
+    rt.render(pipeline, clear, rt.viewport(1., 1.), (2, 4)); rt.finish_frame()       # frames are delivered a frame later at the earliest
+    rt.synchronize()
+    assert "gfx" in rt.adapter_info()
+    rt.stop_recording([pipeline])
+    rt.join()
+    assert [f[0] for f in frames[:n]] == list(range(1, n + 1))
+    vp = rt.viewport(1., 1.)
+    x0, y0 = int(np.ceil(vp.margin_x)), int(np.ceil(vp.margin_y))
+    for number, w, h, pitch, data in frames[:n]:
+        want = scenes.draw_oracle(scenes.example_scene(number, width=W, height=H, record=True))["recording"][y0:y0 + h, x0:x0 + w]
+        got = data.reshape(h, pitch)[:, :w * 4].reshape(h, w, 4)
+        assert np.array_equal(got, want), f"frame {number}"

@@ -44,7 +44,7 @@ extern "C" __device__ const rh_module_info_t rh_module_info = {
 #ifndef RH_TILE_MIN_WAVES
 #define RH_TILE_MIN_WAVES 8
 #endif
-static_assert(RH_BATCH_CLUSTERS % 64 == 0, "a batch is walked in rounds of 64 clusters");
+static_assert(RH_BATCH_CLUSTERS % 64 == 0 && RH_BATCH_CLUSTERS <= 256, "a batch is walked in rounds of 64 clusters; a cluster index fits 8 bits");
 
 namespace rh {
 
@@ -238,6 +238,8 @@ RH_DEVICE bool edges_inside_i32(const TriData& t, int lx, int ly) {
 }
 
 constexpr int TRI_FLOATS = (int)(sizeof(TriData) / sizeof(float));
+constexpr int REC_FLOATS = (int)(sizeof(ClusterRecord) / sizeof(float));
+constexpr int PACK_MAX = 4;               // boxes that may share one shading pass
 // float offsets inside TriData of the values a fragment reads from the triangle that covers it
 constexpr int OFF_XR = 9, OFF_YR = 10, OFF_V0 = 11, OFF_DVDX = OFF_V0 + NV, OFF_DVDY = OFF_DVDX + NV, OFF_Q0 = OFF_DVDY + NV;
 static_assert(offsetof(TriData, XR) == OFF_XR * 4 && offsetof(TriData, v0) == OFF_V0 * 4 && offsetof(TriData, q0) == OFF_Q0 * 4,
@@ -258,7 +260,8 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA>& lds) {
     uint32_t (* const tile_px)[4 * REGION_STRIDE] = lds.tile_px;
 
     const rh_draw_params& p = a.p;
-    const int tid = (int)threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = (int)threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: everything derived from it is wave-uniform
     const uint32_t tile = blockIdx.x + p.tile_first;
     const int ox = (int)(tile % p.tiles_x) * RH_TILE_W, oy = (int)(tile / p.tiles_x) * RH_TILE_H;
     const uint32_t start = a.tile_start[tile], end = a.tile_end[tile];
@@ -309,87 +312,152 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA>& lds) {
         if (!region_live) continue;
 
         for (int round = 0; round < RH_BATCH_CLUSTERS / 64; round++) {
+            // lane = cluster of this round: its box clipped to the region (all wave-parallel)
             const uint32_t bb = rec_bbox[round * 64 + lane];
-            const int cx0 = (int)(bb & 0xffu), cy0 = (int)((bb >> 8) & 0xffu), cx1 = (int)((bb >> 16) & 0xffu), cy1 = (int)(bb >> 24);
-            const bool hit = cx0 <= sx1 && cx1 >= sx0 && cy0 <= sy1 && cy1 >= sy0;
-            unsigned long long mask = __ballot(hit);
-            while (mask) {
-                const int tl = __builtin_ctzll(mask);
-                mask &= mask - 1;
-                const int ci = round * 64 + tl;
-                const ClusterRecord& r = rec[ci];
-                const float* const rf = reinterpret_cast<const float*>(&r);          // t[0] at 0, t[1] at TRI_FLOATS
-                // wave-uniform values are pulled into scalar registers so that the per-hit bookkeeping runs on the scalar unit
-                const uint32_t flags = __builtin_amdgcn_readfirstlane(r.flags);
-                const uint32_t hb = __builtin_amdgcn_readfirstlane(rec_bbox[ci]);
+            const uint32_t fl = rec[round * 64 + lane].flags;            // (stale for an empty slot: never a hit)
+            const int hx0 = max((int)(bb & 0xffu), sx0), hy0 = max((int)((bb >> 8) & 0xffu), sy0);
+            const int hx1 = min((int)((bb >> 16) & 0xffu), sx1), hy1 = min((int)(bb >> 24), sy1);
+            const bool hit = hx0 <= hx1 && hy0 <= hy1;
+            const int npx = (hx1 - hx0 + 1) * (hy1 - hy0 + 1);
+            const unsigned long long mask = __ballot(hit);
+            const int nh = __popcll(mask);
+            if (nh == 0) continue;
+            // Small axis-aligned quads may share one pass (see below); anything else runs alone, 64 pixels per pass.
+            const bool small = (fl & (FLAG_RECT | FLAG_PERSP_A | FLAG_PERSP_B)) == FLAG_RECT && npx <= 64;
+            // Compact the hits, in submission order, into the first nh lanes (a lane permutation, no memory):
+            //   box = clipped box, info = cluster | flags << 8 | pixels << 16 | small << 31
+            uint32_t box_v, info_v;
+            {
+                const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                const int dest = hit ? below : nh + lane - below;
+                const uint32_t box = (uint32_t)hx0 | ((uint32_t)hy0 << 8) | ((uint32_t)hx1 << 16) | ((uint32_t)hy1 << 24);
+                const uint32_t info = (uint32_t)(round * 64 + lane) | (fl << 8) | ((uint32_t)npx << 16) | (small ? 0x80000000u : 0u);
+                box_v = (uint32_t)__builtin_amdgcn_ds_permute(dest << 2, (int)box);
+                info_v = (uint32_t)__builtin_amdgcn_ds_permute(dest << 2, (int)(hit ? info : 0u));
+            }
+            // A pack = up to PACK_MAX consecutive small hits whose boxes are pairwise disjoint and whose pixels fit
+            // the 64 lanes of ONE pass (disjoint boxes cannot touch the same pixel, so their relative order is
+            // immaterial).  Every lane works out the pack that would start at its hit:
+            //   run = length | pixels << 3 | lane at which member 1, 2, 3 starts << 10, 17, 24 (127 = no such member)
+            uint32_t run_v;
+            {
+                const uint32_t n0 = (info_v >> 16) & 0x3ffu;
+                uint32_t len = 1u, total = n0, c1 = 127u, c2 = 127u, c3 = 127u;
+                const unsigned long long sm = __ballot((info_v >> 31) != 0u);
+                if (sm & (sm >> 1)) {
+                    static_assert(PACK_MAX == 4, "written for four members");
+                    // the three hits after this one (lanes past the end wrap around: excluded by the bound checks)
+                    auto after = [&](int d) { const int src = ((lane + d) & 63) << 2;
+                                              return make_uint2((uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)box_v), (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)info_v)); };
+                    const uint2 m1 = after(1), m2 = after(2), m3 = after(3);
+                    auto apart = [](uint32_t p, uint32_t q) {
+                        return (p & 0xffu) > ((q >> 16) & 0xffu) || ((p >> 16) & 0xffu) < (q & 0xffu) ||
+                               ((p >> 8) & 0xffu) > (q >> 24) || (p >> 24) < ((q >> 8) & 0xffu);
+                    };
+                    const uint32_t n1 = (m1.y >> 16) & 0x3ffu, n2 = (m2.y >> 16) & 0x3ffu, n3 = (m3.y >> 16) & 0x3ffu;
+                    const bool ok1 = (info_v >> 31) != 0u && lane + 1 < nh && (m1.y >> 31) != 0u && n0 + n1 <= 64u && apart(box_v, m1.x);
+                    const bool ok2 = ok1 && lane + 2 < nh && (m2.y >> 31) != 0u && n0 + n1 + n2 <= 64u && apart(box_v, m2.x) && apart(m1.x, m2.x);
+                    const bool ok3 = ok2 && lane + 3 < nh && (m3.y >> 31) != 0u && n0 + n1 + n2 + n3 <= 64u &&
+                                     apart(box_v, m3.x) && apart(m1.x, m3.x) && apart(m2.x, m3.x);
+                    len = 1u + (ok1 ? 1u : 0u) + (ok2 ? 1u : 0u) + (ok3 ? 1u : 0u);
+                    c1 = ok1 ? n0 : 127u; c2 = ok2 ? n0 + n1 : 127u; c3 = ok3 ? n0 + n1 + n2 : 127u;
+                    total = n0 + (ok1 ? n1 : 0u) + (ok2 ? n2 : 0u) + (ok3 ? n3 : 0u);
+                }
+                run_v = len | (total << 3) | (c1 << 10) | (c2 << 17) | (c3 << 24);
+            }
+            // Hits in order; k and everything read with readlane is wave-uniform and lives on the scalar unit.
+            int k = 0, s_first = 0;
+            while (k < nh) {
+                const uint32_t info = __builtin_amdgcn_readlane(info_v, k);
+                // per-lane inputs of this pass: cluster record, pixel, liveness
+                uint32_t flags;
+                const float* rf;
+                float hx0f, hy0f, wf, idx_f;
+                bool live;
+                if (info >> 31) {
+                    const uint32_t run = __builtin_amdgcn_readlane(run_v, k);
+                    const int c1 = (int)((run >> 10) & 127u), c2 = (int)((run >> 17) & 127u), c3 = (int)(run >> 24);
+                    const bool g1 = lane >= c1, g2 = lane >= c2, g3 = lane >= c3;
+                    const int slot = (g1 ? 1 : 0) + (g2 ? 1 : 0) + (g3 ? 1 : 0);
+                    const int st = g3 ? c3 : (g2 ? c2 : (g1 ? c1 : 0));
+                    const int src = (k + slot) << 2;
+                    const uint2 m = make_uint2((uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)box_v), (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)info_v));
+                    hx0f = (float)(m.x & 0xffu); hy0f = (float)((m.x >> 8) & 0xffu);
+                    wf = (float)(int)(((m.x >> 16) & 0xffu) - (m.x & 0xffu) + 1u);
+                    idx_f = (float)(lane - st);
+                    live = lane < (int)((run >> 3) & 127u);
+                    rf = reinterpret_cast<const float*>(rec) + (int)(m.y & 0xffu) * REC_FLOATS;
+                    flags = FLAG_RECT | FLAG_HAS_A | FLAG_HAS_B;
+                    k += (int)(run & 7u);
+                } else {
+                    const uint32_t box = __builtin_amdgcn_readlane(box_v, k);
+                    const int w = (int)((box >> 16) & 0xffu) - (int)(box & 0xffu) + 1, n = (int)((info >> 16) & 0x3ffu);
+                    hx0f = (float)(box & 0xffu); hy0f = (float)((box >> 8) & 0xffu); wf = (float)w;
+                    idx_f = lane_f + (float)s_first;
+                    live = idx_f < (float)n;
+                    rf = reinterpret_cast<const float*>(rec) + (int)(info & 0xffu) * REC_FLOATS;
+                    flags = (info >> 8) & 0x3fu;
+                    s_first += 64;
+                    if (s_first >= n) { s_first = 0; k++; }
+                }
+                const float invw = __builtin_amdgcn_rcpf(wf);
                 const bool has_a = (flags & FLAG_HAS_A) != 0u, has_b = (flags & FLAG_HAS_B) != 0u;
                 const bool any_persp = (flags & (FLAG_PERSP_A | FLAG_PERSP_B)) != 0u;
-                // pixels of (cluster bbox intersected with the region), packed linearly: idx -> (idx % w, idx / w)
-                const int hx0 = max((int)(hb & 0xffu), sx0), hy0 = max((int)((hb >> 8) & 0xffu), sy0);
-                const int hx1 = min((int)((hb >> 16) & 0xffu), sx1), hy1 = min((int)(hb >> 24), sy1);
-                const int w = hx1 - hx0 + 1, npx = w * (hy1 - hy0 + 1);
-                const float wf = (float)w, invw = __builtin_amdgcn_rcpf(wf);
-                const float hx0f = (float)hx0, hy0f = (float)hy0, npxf = (float)npx;
-                const float half_invw = 0.5f * invw;
-                for (int first = 0; first < npx; first += 64) {
-                    const float idx_f = lane_f + (float)first;
-                    // floor((idx + 0.5) / w): the half keeps the quotient at least 1/32 away from an integer
-                    const float row_f = floorf(__builtin_fmaf(idx_f, invw, half_invw));
-                    const float col_f = __builtin_fmaf(-row_f, wf, idx_f);
-                    const float lxf = hx0f + col_f, lyf = hy0f + row_f;          // tile-relative pixel, exact small integers
-                    const bool live = idx_f < npxf;
-                    // region-relative LDS index of the pixel
-                    const int pidx = (int)__builtin_fmaf(lyf, (float)REGION_W, lxf - region_bias);
-                    // coverage of both triangles (a missing triangle's record holds stale values: masked by has_*)
-                    bool cov_a, cov_b, overlap = false;
-                    if (flags & FLAG_RECT) {
-                        // every pixel of the box is covered; the shared diagonal (edge 1 of A) says by which triangle
-                        const TriData& ta = r.t[0];
-                        const bool in_a = __float_as_int(__builtin_fmaf(ta.A[1], lxf, __builtin_fmaf(ta.B[1], lyf, ta.T[1]))) >= 0;
-                        cov_a = live && in_a; cov_b = live && !in_a;
+                const TriData& tri_a = *reinterpret_cast<const TriData*>(rf);
+                const TriData& tri_b = *reinterpret_cast<const TriData*>(rf + TRI_FLOATS);
+                // floor((idx + 0.5) / w): the half keeps the quotient at least 1/128 away from an integer
+                const float row_f = floorf(__builtin_fmaf(idx_f, invw, 0.5f * invw));
+                const float col_f = __builtin_fmaf(-row_f, wf, idx_f);
+                const float lxf = hx0f + col_f, lyf = hy0f + row_f;          // tile-relative pixel, exact small integers
+                // region-relative LDS index of the pixel
+                const int pidx = (int)__builtin_fmaf(lyf, (float)REGION_W, lxf - region_bias);
+                bool cov_a, cov_b, overlap = false;
+                if (flags & FLAG_RECT) {
+                    // every pixel of the box is covered; the shared diagonal (edge 1 of A) says by which triangle
+                    const bool in_a = __float_as_int(__builtin_fmaf(tri_a.A[1], lxf, __builtin_fmaf(tri_a.B[1], lyf, tri_a.T[1]))) >= 0;
+                    cov_a = live && in_a; cov_b = live && !in_a;
+                } else {
+                    // (a missing triangle's record holds stale values: masked by has_*)
+                    bool in_a, in_b;
+                    if (flags & FLAG_BIG) {
+                        const int lx = (int)lxf, ly = (int)lyf;
+                        in_a = edges_inside_i32(tri_a, lx, ly); in_b = edges_inside_i32(tri_b, lx, ly);
                     } else {
-                        // (a missing triangle's record holds stale values: masked by has_*)
-                        bool in_a, in_b;
-                        if (flags & FLAG_BIG) {
-                            const int lx = (int)lxf, ly = (int)lyf;
-                            in_a = edges_inside_i32(r.t[0], lx, ly); in_b = edges_inside_i32(r.t[1], lx, ly);
-                        } else {
-                            in_a = edges_inside_f32(r.t[0], lxf, lyf); in_b = edges_inside_f32(r.t[1], lxf, lyf);
-                        }
-                        cov_a = live && has_a && in_a; cov_b = live && has_b && in_b;
-                        overlap = __any(cov_a && cov_b);
+                        in_a = edges_inside_f32(tri_a, lxf, lyf); in_b = edges_inside_f32(tri_b, lxf, lyf);
                     }
-                    // One shading pass when no pixel is covered by both triangles (the usual case): every lane takes
-                    // the plane equations of the triangle that covers it.  Otherwise A's fragments, then B's.
-                    auto shade = [&](bool cov, bool use_b) {
-                        // per-lane choice of the triangle = per-lane LDS address (one copy of the shading code)
-                        const float* const tp = rf + (use_b ? TRI_FLOATS : 0);
-                        const float dx = __builtin_fmaf(lxf, 256.0f, -tp[OFF_XR]), dy = __builtin_fmaf(lyf, 256.0f, -tp[OFF_YR]);   // exact
-                        Varyings var; float* vf = reinterpret_cast<float*>(&var);
+                    cov_a = live && has_a && in_a; cov_b = live && has_b && in_b;
+                    overlap = __any(cov_a && cov_b);
+                }
+                // One shading pass when no pixel is covered by both triangles (the usual case): every lane takes
+                // the plane equations of the triangle that covers it.  Otherwise A's fragments, then B's.
+                auto shade = [&](bool cov, bool use_b) {
+                    // per-lane choice of the triangle = per-lane LDS address (one copy of the shading code)
+                    const float* const tp = rf + (use_b ? TRI_FLOATS : 0);
+                    const float dx = __builtin_fmaf(lxf, 256.0f, -tp[OFF_XR]), dy = __builtin_fmaf(lyf, 256.0f, -tp[OFF_YR]);   // exact
+                    Varyings var; float* vf = reinterpret_cast<float*>(&var);
 #pragma unroll
-                        for (int v = 0; v < NV; v++) vf[v] = __builtin_fmaf(tp[OFF_DVDY + v], dy, __builtin_fmaf(tp[OFF_DVDX + v], dx, tp[OFF_V0 + v]));
-                        if (any_persp) {
-                            const bool persp = use_b ? (flags & FLAG_PERSP_B) != 0u : (flags & FLAG_PERSP_A) != 0u;
-                            const float q = __builtin_fmaf(tp[OFF_Q0 + 2], dy, __builtin_fmaf(tp[OFF_Q0 + 1], dx, tp[OFF_Q0]));
+                    for (int v = 0; v < NV; v++) vf[v] = __builtin_fmaf(tp[OFF_DVDY + v], dy, __builtin_fmaf(tp[OFF_DVDX + v], dx, tp[OFF_V0 + v]));
+                    if (any_persp) {
+                        const bool persp = use_b ? (flags & FLAG_PERSP_B) != 0u : (flags & FLAG_PERSP_A) != 0u;
+                        const float q = __builtin_fmaf(tp[OFF_Q0 + 2], dy, __builtin_fmaf(tp[OFF_Q0 + 1], dx, tp[OFF_Q0]));
 #pragma unroll
-                            for (int v = 0; v < NV; v++) vf[v] = persp ? vf[v] / q : vf[v];
+                        for (int v = 0; v < NV; v++) vf[v] = persp ? vf[v] / q : vf[v];
+                    }
+                    if (cov) {
+                        Outputs out;
+                        fragment_main(fctx, var, out);
+#pragma unroll
+                        for (int n = 0; n < NA; n++) {
+                            uint32_t* px = region_px + n * (4 * REGION_STRIDE) + pidx;
+                            *px = blend<BLEND>(*px, out.color[n < RH_FRAGMENT_OUTPUTS ? n : RH_FRAGMENT_OUTPUTS - 1], a.src_factor, a.dst_factor);
                         }
-                        if (cov) {
-                            Outputs out;
-                            fragment_main(fctx, var, out);
-#pragma unroll
-                            for (int n = 0; n < NA; n++) {
-                                uint32_t* px = region_px + n * (4 * REGION_STRIDE) + pidx;
-                                *px = blend<BLEND>(*px, out.color[n < RH_FRAGMENT_OUTPUTS ? n : RH_FRAGMENT_OUTPUTS - 1], a.src_factor, a.dst_factor);
-                            }
-                        }
-                    };
-                    if (__builtin_expect(!overlap, 1)) shade(cov_a || cov_b, cov_b);
-                    else {
-                        // overlapping triangles inside the cluster (bow-tie, folded quads): strictly A before B
+                    }
+                };
+                if (__builtin_expect(!overlap, 1)) shade(cov_a || cov_b, cov_b);
+                else {
+                    // overlapping triangles inside the cluster (bow-tie, folded quads): strictly A before B
 #pragma nounroll
-                        for (int phase = 0; phase < 2; phase++) shade(phase ? cov_b : cov_a, phase != 0);
-                    }
+                    for (int phase = 0; phase < 2; phase++) shade(phase ? cov_b : cov_a, phase != 0);
                 }
             }
         }

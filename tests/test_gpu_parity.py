@@ -50,6 +50,17 @@ def test_tiny_quads_additive(oracle):
     assert_same(hip["color"], orc["color"], "tiny")
 
 
+@pytest.mark.parametrize("lo,hi", [(1, 3), (2, 8), (5, 12)])
+def test_tiny_quads_order_sensitive_blend(oracle, lo, hi):
+    """Small axis-aligned quads share shading passes when their boxes are disjoint; with pre-multiplied alpha the
+    result depends on the submission order of every overlapping pair, ~10 layers deep here."""
+    scene = scenes.tiny_quads_scene(60000, 320, 200, seed=11 + lo, lo=lo, hi=hi)
+    scene["blend"] = "premultiplied"
+    orc = scenes.draw_oracle(scene)
+    hip = scenes.draw_hip(scene)
+    assert_same(hip["color"], orc["color"], f"tiny premultiplied {lo}..{hi}")
+
+
 def test_large_quads_and_odd_size(oracle):
     # target size not a multiple of the tile size; quads larger than a tile; quads poking outside the target
     scene = scenes.random_quads_scene(300, 150, 333, 217, seed=3)

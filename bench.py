@@ -28,12 +28,12 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
 
 
-def pmc_traffic_bytes():
+def pmc_traffic_bytes(tag="c1"):
     """HBM bytes per rh_tile_1 launch from the committed counter passes of this same command (tools/prof.sh: one
     rocprofv3 --pmc run for FETCH_SIZE, one for WRITE_SIZE; both counters are in KiB).  FETCH_SIZE is doubled, the
     gfx950 correction for its 64-B tally of 128-B read requests; counters cannot be collected from inside this
     process, so the figure is the profiled one and is None when no profile of the default workload is present."""
-    path = os.path.join(ROOT, "profiles", "r01", "bench_c1_v5_pmc_avg_per_launch.json")
+    path = os.path.join(ROOT, "profiles", "r01", "bench_%s_v6_pmc_avg_per_launch.json" % tag)
     try:
         k = json.load(open(path))["rh_tile_1"]
         return (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0
@@ -169,7 +169,8 @@ def main():
         tile_ms = timings["tile_ms"] / max(1, timings["passes"])
         bin_ms = timings["bin_ms"] / max(1, timings["passes"])
         achieved = b_alg / (tile_ms * 1e-3) / 1e9 if tile_ms > 0 else 0.0
-        traffic = pmc_traffic_bytes() if default_workload else None
+        c2_profiled = (args.workload == "c2" and args.quads == 10_000_000 and (args.width, args.height) == (3840, 2160))
+        traffic = pmc_traffic_bytes("c1") if default_workload else (pmc_traffic_bytes("c2") if c2_profiled else None)
         out = {
             "metric": "instanced quads/s at 4K alpha-blend" if args.workload == "c1" else "instanced quads/s at 4K additive tiny quads", "value": value, "unit": "quads/s",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,

@@ -36,10 +36,13 @@ static void premultiply_alpha(std::vector<uint8_t>& buffer) {
 }
 
 int main(int argc, char** argv) {
-    if (argc < 4) { fprintf(stderr, "usage: %s <shader dir> <letter_f.png> <out dir> [frames] [width] [height]\n", argv[0]); return 2; }
+    if (argc < 4) { fprintf(stderr, "usage: %s <shader dir> <letter_f.png> <out dir> [frames] [width] [height] [msaa samples]\n", argv[0]); return 2; }
     const std::string shader_dir = argv[1], image_path = argv[2], out_dir = argv[3];
     const int frames = argc > 4 ? atoi(argv[4]) : 60;
     const uint32_t win_w = argc > 5 ? (uint32_t)atoi(argv[5]) : 1920, win_h = argc > 6 ? (uint32_t)atoi(argv[6]) : 1080;
+    // (not in the reference's example) more than one sample: a multisampled pass cannot carry the single-sampled
+    // recording attachment, so nothing is recorded and the PNG is the final screen instead of the last captured frame
+    const uint32_t msaa_arg = argc > 7 ? (uint32_t)atoi(argv[7]) : 1;
     try {
         Renderer renderer(win_w, win_h);
 
@@ -61,7 +64,7 @@ int main(int argc, char** argv) {
                                         { { t_texture, Renderer::visible_to_fragment_shader() } });
         const auto blend_mode = Renderer::pre_multiplied_blend();
         const auto primitive = Renderer::triangle_strip_primitive();
-        const uint32_t msaa_samples = 1;
+        const uint32_t msaa_samples = msaa_arg;
         const auto target = Renderer::screen_target();
         auto pipeline = renderer.pipeline(program, blend_mode, primitive, msaa_samples, { target });
         const auto clear_color = Renderer::clear_color(0., 0., 0., 1.);
@@ -74,7 +77,7 @@ int main(int argc, char** argv) {
         //    the last frame is also kept mapped on the host to write it out as a PNG below
         renderer::Compressor compressor(renderer, out_dir, "1970-01-01T00_00_00.000Z", 0, 4);
         std::vector<uint8_t> last_png;
-        renderer.start_recording({ &pipeline }, &clear_color, 500.f, [&](renderer::VideoFrame video_frame) {
+        if (msaa_samples == 1) renderer.start_recording({ &pipeline }, &clear_color, 500.f, [&](renderer::VideoFrame video_frame) {
             if ((int)video_frame.frame_number == frames) last_png = renderer::PngEncoder::encode_to_bytes(video_frame);
             compressor.compress_to_disk(std::move(video_frame));
         });
@@ -94,8 +97,14 @@ int main(int argc, char** argv) {
         }
         // frames are delivered during a later finish_frame at the earliest: drain what is still in flight
         renderer.synchronize();
-        renderer.recorder->process_mapped_buffers();
-        renderer.stop_recording({ &pipeline });
+        if (msaa_samples == 1) {
+            renderer.recorder->process_mapped_buffers();
+            renderer.stop_recording({ &pipeline });
+        } else {
+            std::vector<uint8_t> screen = renderer.read_screen();                    // BGRA
+            for (size_t i = 0; i + 3 < screen.size(); i += 4) std::swap(screen[i], screen[i + 2]);
+            last_png = renderer::PngEncoder::encode_rows(screen.data(), win_w, win_h, (size_t)win_w * 4, (size_t)win_w * 4);
+        }
         compressor.finish();
 
         const std::string png_path = out_dir + "/frame_" + std::to_string(frames) + ".png";

@@ -162,7 +162,8 @@ typedef struct rh_pipeline_desc {
     uint32_t n_slots;
     const rh_slot_desc* slots;             /* flat slot i = (set i/4, binding i%4) (src/pipeline.rs:90-131) */
     uint32_t topology;                     /* RH_TOPOLOGY_*; no culling, no depth/stencil (src/pipeline.rs:150-159,197-207) */
-    uint32_t samples;                      /* only 1 is implemented */
+    uint32_t samples;                      /* MultisampleState.count (src/pipeline.rs:209-211): 1, 2, 4 or 8; mask !0,
+                                              no alpha-to-coverage; a multisampled pass takes one attachment */
     uint32_t n_targets;
     const rh_color_target_desc* targets;   /* incl. the extra RGBA8 recording target (src/pipeline.rs:133-142) */
 } rh_pipeline_desc;
@@ -177,6 +178,9 @@ typedef struct rh_attachment_desc {
     rh_texture* texture;
     uint32_t load_op;       /* RH_LOAD_OP_* ; store op is always Store (src/render_pass.rs:73) */
     double clear[4];        /* wgpu::Color (src/clear_color.rs:7-16) */
+    rh_texture* resolve_target;   /* NULL, or for a multisampled `texture` the single-sampled texture that receives the
+                                     averaged samples when the pass ends (src/render_pass.rs:76-81: view = the pipeline's
+                                     MSAA texture, resolve_target = the target's view).  Load/clear act on `texture`. */
 } rh_attachment_desc;
 
 typedef struct rh_pass_desc {

@@ -51,7 +51,8 @@ class OrcDraw(C.Structure):
                 ("storage", C.c_void_p * 4), ("uniform", C.c_void_p * 4), ("tex", OrcTexture * 4),
                 ("has_viewport", C.c_int32), ("viewport", C.c_float * 4), ("clip_to_viewport", C.c_int32),
                 ("src_factor", C.c_uint32), ("dst_factor", C.c_uint32), ("n_targets", C.c_uint32),
-                ("targets", OrcTarget * 4), ("threads", C.c_int32), ("fragments_out", C.c_uint64)]
+                ("targets", OrcTarget * 4), ("threads", C.c_int32), ("fragments_out", C.c_uint64),
+                ("samples", C.c_uint32), ("msaa", C.c_void_p)]
 
 
 _raster = None
@@ -73,7 +74,7 @@ def raster_lib():
 
 
 def render(shader, topology, vertex_count, instance_count, attrs, storage, textures, targets, blend,
-           viewport=None, clip_to_viewport=True, uniforms=(), threads=0):
+           viewport=None, clip_to_viewport=True, uniforms=(), threads=0, samples=1, msaa=None):
     """Run the oracle.
 
     attrs:    list of (np.float32 array, size)
@@ -81,6 +82,8 @@ def render(shader, topology, vertex_count, instance_count, attrs, storage, textu
     textures: list of (np.uint8 array [layers*H*W*C], width, height, layers, format, filter)
     targets:  list of dicts {data: np.uint8 [H, W, 4] (modified in place), format, clear: None | (r, g, b, a)}
     blend:    (src_factor, dst_factor)
+    samples:  1, or 2/4/8 with msaa = np.uint8 [H, W, samples, 4] (the pipeline's multisampled texture, modified in
+              place and resolved into the single target)
     Returns the number of fragments blended per attachment.
     """
     d = OrcDraw()
@@ -118,6 +121,10 @@ def render(shader, topology, vertex_count, instance_count, attrs, storage, textu
             # reference src/clear_color.rs:10: f32 components widened to f64
             d.targets[i].clear_rgba[:] = [float(np.float32(c)) for c in clear]
     d.threads = threads
+    if samples > 1:
+        assert msaa is not None and msaa.dtype == np.uint8 and msaa.flags["C_CONTIGUOUS"]
+        assert msaa.shape == (targets[0]["data"].shape[0], targets[0]["data"].shape[1], samples, 4)
+        d.samples, d.msaa = samples, msaa.ctypes.data
     rc = raster_lib().orc_render(C.byref(d))
     if rc != 0:
         raise RuntimeError(f"orc_render failed: {rc}")

@@ -77,6 +77,10 @@ struct orc_draw {
     orc_target targets[4];
     int32_t  threads;                // <=0: hardware concurrency
     uint64_t fragments_out;          // out: number of blended fragments per attachment
+    uint32_t samples;                // 0 or 1: single-sampled.  2, 4, 8: the pass renders into `msaa` and resolves into
+                                     // targets[0] (reference src/render_pass.rs:76-81, src/pipeline.rs:164-176, 209-211)
+    uint8_t* msaa;                   // width*height*samples*4 bytes, the samples of a pixel adjacent, bytes in the order
+                                     // of targets[0].format; persists between passes (LoadOp::Load reads it back)
 };
 
 int orc_render(orc_draw* d);
@@ -229,6 +233,7 @@ struct Vert { int32_t X, Y; float rw; bool ok; float var[MAX_VARYINGS]; };
 
 struct Tri {
     int32_t A[3], B[3]; int64_t Cq[3];   // inside <=> A*i + B*j + Cq >= 0 for all three edges (i, j = pixel indices)
+    int64_t Cf[3];                       // inside at a sub-pixel position P (1/256 px) <=> A*Px + B*Py + Cf >= 0
     int32_t X0, Y0;
     int x0, y0, x1, y1;                  // inclusive pixel bbox, already intersected with the scissor
     float v0[MAX_VARYINGS], dvdx[MAX_VARYINGS], dvdy[MAX_VARYINGS];
@@ -264,7 +269,16 @@ Vert run_vertex(const orc_draw& d, const Shader& sh, const ViewXf& xf, uint32_t 
 
 inline int64_t asr8(int64_t v) { return v >> SUBPIXEL_BITS; }   // floor division by 256
 
-bool setup_tri(const Shader& sh, Vert a, Vert b, Vert c, const Scissor& sc, Tri& t) {
+// Standard sample locations (Vulkan 1.3 section 25.3, "Multisampling"), as offsets from the pixel centre in 1/256 px.
+const int8_t SAMPLE_OFFSETS_2[2][2] = { { 64, 64 }, { -64, -64 } };
+const int8_t SAMPLE_OFFSETS_4[4][2] = { { -32, -96 }, { 96, -32 }, { -96, 32 }, { 32, 96 } };
+const int8_t SAMPLE_OFFSETS_8[8][2] = { { 16, -48 }, { -16, 48 }, { 80, 16 }, { -48, -80 }, { -80, 80 }, { -112, -16 }, { 48, 112 }, { 112, -112 } };
+inline const int8_t (*sample_offsets(uint32_t samples))[2] {
+    return samples == 2 ? SAMPLE_OFFSETS_2 : (samples == 4 ? SAMPLE_OFFSETS_4 : SAMPLE_OFFSETS_8);
+}
+
+// `pad`: 0 for single-sampled passes; 128 (half a pixel) when samples away from the centre can be covered.
+bool setup_tri(const Shader& sh, Vert a, Vert b, Vert c, const Scissor& sc, int pad, Tri& t) {
     if (!a.ok || !b.ok || !c.ok) return false;
     int64_t area2 = (int64_t)(b.X - a.X) * (c.Y - a.Y) - (int64_t)(c.X - a.X) * (b.Y - a.Y);
     if (area2 == 0) return false;
@@ -275,12 +289,12 @@ bool setup_tri(const Shader& sh, Vert a, Vert b, Vert c, const Scissor& sc, Tri&
         int32_t A = p.Y - q.Y, B = q.X - p.X;
         int64_t C = -((int64_t)A * p.X + (int64_t)B * p.Y);
         bool top_left = (A > 0) || (A == 0 && B > 0);
-        t.A[e] = A; t.B[e] = B; t.Cq[e] = asr8(C + (top_left ? 0 : -1));
+        t.A[e] = A; t.B[e] = B; t.Cf[e] = C + (top_left ? 0 : -1); t.Cq[e] = asr8(t.Cf[e]);
     }
     int32_t minX = std::min(a.X, std::min(b.X, c.X)), maxX = std::max(a.X, std::max(b.X, c.X));
     int32_t minY = std::min(a.Y, std::min(b.Y, c.Y)), maxY = std::max(a.Y, std::max(b.Y, c.Y));
-    t.x0 = std::max(sc.x0, (int)((minX + 255) >> 8)); t.x1 = std::min(sc.x1 - 1, (int)(maxX >> 8));
-    t.y0 = std::max(sc.y0, (int)((minY + 255) >> 8)); t.y1 = std::min(sc.y1 - 1, (int)(maxY >> 8));
+    t.x0 = std::max(sc.x0, (int)((minX - pad + 255) >> 8)); t.x1 = std::min(sc.x1 - 1, (int)((maxX + pad) >> 8));
+    t.y0 = std::max(sc.y0, (int)((minY - pad + 255) >> 8)); t.y1 = std::min(sc.y1 - 1, (int)((maxY + pad) >> 8));
     if (t.x0 > t.x1 || t.y0 > t.y1) return false;
     t.X0 = a.X; t.Y0 = a.Y;
     float e1x = (float)(b.X - a.X) * INV_SUBPIXEL, e1y = (float)(b.Y - a.Y) * INV_SUBPIXEL;
@@ -337,16 +351,31 @@ inline void blend_store(const orc_draw& d, const orc_target& tg, size_t pix, con
     else { p[0] = q[0]; p[1] = q[1]; p[2] = q[2]; p[3] = q[3]; }
 }
 
-void clear_rows(const orc_target& tg, int y0, int y1) {
+void clear_rows(const orc_target& tg, int y0, int y1, uint8_t* msaa = nullptr, uint32_t samples = 1) {
     if (!tg.clear) return;
     uint8_t q[4];
     for (int k = 0; k < 4; k++) q[k] = to_unorm8((float)tg.clear_rgba[k]);
     uint8_t px[4] = { q[0], q[1], q[2], q[3] };
     if (tg.format == ORC_FMT_BGRA_U8) { px[0] = q[2]; px[2] = q[0]; }
+    if (msaa) {
+        for (size_t k = (size_t)y0 * tg.width * samples; k < (size_t)y1 * tg.width * samples; k++) std::memcpy(msaa + k * 4, px, 4);
+        return;
+    }
     for (int y = y0; y < y1; y++) {
         uint8_t* row = tg.data + (size_t)y * tg.width * 4;
         for (uint32_t x = 0; x < tg.width; x++) std::memcpy(row + (size_t)x * 4, px, 4);
     }
+}
+
+// Multisample resolve: per channel the mean of the samples, rounded to nearest, ties to even (the sum is exact).
+void resolve_rows(const orc_target& tg, const uint8_t* msaa, uint32_t samples, int y0, int y1) {
+    const float inv = 1.0f / (float)samples;
+    for (size_t pix = (size_t)y0 * tg.width; pix < (size_t)y1 * tg.width; pix++)
+        for (int k = 0; k < 4; k++) {
+            uint32_t sum = 0;
+            for (uint32_t sidx = 0; sidx < samples; sidx++) sum += msaa[(pix * samples + sidx) * 4 + k];
+            tg.data[pix * 4 + k] = (uint8_t)rintf((float)sum * inv);
+        }
 }
 
 // Triangles of instance `inst`, in primitive order.  Strip triangle i uses vertices (i, i+1, i+2) for even i and
@@ -363,12 +392,28 @@ inline void tri_vertices(const orc_draw& d, uint32_t i, uint32_t idx[3]) {
 
 void shade_tri(const orc_draw& d, const Shader& sh, const Tri& t, int band_y0, int band_y1, uint64_t& frags) {
     int y0 = std::max(t.y0, band_y0), y1 = std::min(t.y1, band_y1 - 1);
+    const uint32_t S = d.samples > 1 ? d.samples : 1;
+    const int8_t (*offs)[2] = sample_offsets(S);
     for (int j = y0; j <= y1; j++) {
         for (int i = t.x0; i <= t.x1; i++) {
-            bool in = true;
-            for (int e = 0; e < 3; e++)
-                in = in && ((int64_t)t.A[e] * i + (int64_t)t.B[e] * j + t.Cq[e] >= 0);
-            if (!in) continue;
+            uint32_t covered = 0;           // sample mask
+            if (S == 1) {
+                bool in = true;
+                for (int e = 0; e < 3; e++)
+                    in = in && ((int64_t)t.A[e] * i + (int64_t)t.B[e] * j + t.Cq[e] >= 0);
+                covered = in ? 1u : 0u;
+            } else {
+                // the same edge functions and top-left rule, evaluated at every sample position
+                for (uint32_t sidx = 0; sidx < S; sidx++) {
+                    const int64_t px = (int64_t)i * 256 + offs[sidx][0], py = (int64_t)j * 256 + offs[sidx][1];
+                    bool in = true;
+                    for (int e = 0; e < 3; e++) in = in && (t.A[e] * px + t.B[e] * py + t.Cf[e] >= 0);
+                    if (in) covered |= 1u << sidx;
+                }
+            }
+            if (!covered) continue;
+            // one fragment shader invocation per pixel, inputs interpolated at the pixel centre (no centroid qualifier
+            // in the reference's shaders), its colour blended into every covered sample
             float dx = (float)(i * 256 - t.X0), dy = (float)(j * 256 - t.Y0);     // exact: |delta| < 2^24
             float var[MAX_VARYINGS];
             for (int k = 0; k < sh.n_varyings; k++) var[k] = fmaf(t.dvdy[k], dy, fmaf(t.dvdx[k], dx, t.v0[k]));
@@ -378,9 +423,15 @@ void shade_tri(const orc_draw& d, const Shader& sh, const Tri& t, int band_y0, i
             }
             float out[4][4];
             sh.fs(d, var, out);
-            for (uint32_t a = 0; a < d.n_targets; a++) {
-                const orc_target& tg = d.targets[a];
-                blend_store(d, tg, (size_t)j * tg.width + (size_t)i, out[a < (uint32_t)sh.n_outputs ? a : sh.n_outputs - 1]);
+            if (S > 1) {
+                orc_target ms = d.targets[0]; ms.data = d.msaa;
+                for (uint32_t sidx = 0; sidx < S; sidx++)
+                    if (covered & (1u << sidx)) blend_store(d, ms, ((size_t)j * ms.width + (size_t)i) * S + sidx, out[0]);
+            } else {
+                for (uint32_t a = 0; a < d.n_targets; a++) {
+                    const orc_target& tg = d.targets[a];
+                    blend_store(d, tg, (size_t)j * tg.width + (size_t)i, out[a < (uint32_t)sh.n_outputs ? a : sh.n_outputs - 1]);
+                }
             }
             frags++;
         }
@@ -394,6 +445,8 @@ extern "C" int orc_render(orc_draw* d) {
     if (d->n_targets == 0) return 0;            // reference src/render_pass.rs:26: no targets, empty command buffer
     if (d->n_targets > 4) return -2;
     const Shader& sh = SHADERS[d->shader];
+    const uint32_t S = d->samples > 1 ? d->samples : 1;
+    if (S > 1 && ((S != 2 && S != 4 && S != 8) || d->n_targets != 1 || !d->msaa)) return -4;
     const int W = (int)d->targets[0].width, H = (int)d->targets[0].height;
     for (uint32_t a = 1; a < d->n_targets; a++)
         if ((int)d->targets[a].width != W || (int)d->targets[a].height != H) return -3;
@@ -426,7 +479,7 @@ extern "C" int orc_render(orc_draw* d) {
             for (uint32_t i = 0; i < tpi; i++) {
                 uint32_t idx[3]; tri_vertices(*d, i, idx);
                 Tri t;
-                if (setup_tri(sh, verts[idx[0]], verts[idx[1]], verts[idx[2]], sc, t)) tris.push_back(t);
+                if (setup_tri(sh, verts[idx[0]], verts[idx[1]], verts[idx[2]], sc, S > 1 ? 128 : 0, t)) tris.push_back(t);
             }
         }
     }
@@ -436,12 +489,14 @@ extern "C" int orc_render(orc_draw* d) {
     std::vector<uint64_t> frags(nthreads, 0);
     auto work = [&](int tid) {
         int by0 = (int)((int64_t)H * tid / nthreads), by1 = (int)((int64_t)H * (tid + 1) / nthreads);
-        for (uint32_t a = 0; a < d->n_targets; a++) clear_rows(d->targets[a], by0, by1);
+        if (S > 1) clear_rows(d->targets[0], by0, by1, d->msaa, S);
+        else for (uint32_t a = 0; a < d->n_targets; a++) clear_rows(d->targets[a], by0, by1);
         uint64_t n = 0;
         for (const Tri& t : tris) {
             if (t.y1 < by0 || t.y0 >= by1) continue;
             shade_tri(*d, sh, t, by0, by1, n);
         }
+        if (S > 1) resolve_rows(d->targets[0], d->msaa, S, by0, by1);      // the resolve overwrites the whole target
         frags[tid] = n;
     };
     if (nthreads == 1) work(0);
@@ -455,4 +510,4 @@ extern "C" int orc_render(orc_draw* d) {
     return 0;
 }
 
-extern "C" int orc_abi_version(void) { return 1; }
+extern "C" int orc_abi_version(void) { return 2; }

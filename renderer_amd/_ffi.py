@@ -51,7 +51,7 @@ class PipelineDesc(C.Structure):
 
 
 class AttachmentDesc(C.Structure):
-    _fields_ = [("texture", C.c_void_p), ("load_op", C.c_uint32), ("clear", C.c_double * 4)]
+    _fields_ = [("texture", C.c_void_p), ("load_op", C.c_uint32), ("clear", C.c_double * 4), ("resolve_target", C.c_void_p)]
 
 
 class PassDesc(C.Structure):

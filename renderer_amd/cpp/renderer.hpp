@@ -213,7 +213,23 @@ public:
         rh_device* device; Program program; BlendMode blend_mode; Primitive primitive; uint32_t msaa_samples;
         RecordingPosition position_in_recording = RecordingPosition::None; std::vector<Target> targets;
         std::vector<uint32_t> seen_generations; rh_pipeline* handle = nullptr;
+        uint32_t window_width = 0, window_height = 0;
+        Texture msaa_texture;                                 // Some(..) <=> msaa_samples > 1 (src/pipeline.rs:31)
         ~Inner() { if (handle) rh_pipeline_release(handle); }
+
+        // One multisampled texture per pipeline, shaped after the FIRST target (src/pipeline.rs:164-176); every pass of the
+        // pipeline renders into it (clear and load act on it) and resolves into the target.
+        void create_msaa_texture() {
+            if (msaa_samples <= 1) { msaa_texture = Texture(); return; }
+            const Target& t = targets.at(0);
+            const uint32_t w = t.screen ? window_width : t.texture.inner->width, h = t.screen ? window_height : t.texture.inner->height;
+            msaa_texture = Texture(device, w, h, 1, FilterMode::Nearest, t.format(), msaa_samples, true, false, false);
+        }
+        void resize_msaa_texture(uint32_t ww, uint32_t wh, const std::vector<Target>& to) {        // src/pipeline.rs:178-187
+            if (!msaa_texture.inner || to.empty()) return;
+            const Target& t = to[0];
+            msaa_texture.resize(t.screen ? ww : t.texture.inner->width, t.screen ? wh : t.texture.inner->height, 1);
+        }
 
         // flat slot list: instanced..., uniforms..., then per texture: texture [, sampler]; slot i = (set i / 4, binding i % 4)
         std::vector<rh_slot_desc> create_bind_groups() const {
@@ -234,7 +250,6 @@ public:
             return states;
         }
         void rebuild() {
-            if (msaa_samples > 1) throw Panic("MSAA samples > 1 requested; multisampling is not implemented");
             auto slots = create_bind_groups();
             auto states = create_color_target_states();
             std::vector<rh_attribute_desc> attrs;
@@ -254,20 +269,24 @@ public:
     std::shared_ptr<Inner> inner;
 
     Pipeline() = default;
-    Pipeline(rh_device* device, Program program, BlendMode blend_mode, Primitive primitive, uint32_t msaa_samples, std::vector<Target> targets)
-        : inner(std::make_shared<Inner>()) {
+    Pipeline(rh_device* device, uint32_t window_width, uint32_t window_height, Program program, BlendMode blend_mode, Primitive primitive,
+             uint32_t msaa_samples, std::vector<Target> targets) : inner(std::make_shared<Inner>()) {
         inner->device = device; inner->program = std::move(program); inner->blend_mode = blend_mode; inner->primitive = primitive;
         inner->msaa_samples = msaa_samples; inner->targets = std::move(targets);
+        inner->window_width = window_width; inner->window_height = window_height;
+        inner->create_msaa_texture();
         inner->rebuild();
         inner->seen_generations = inner->program.latest_generations();
     }
-    void recreate_on_buffer_or_texture_resize() const {       // src/pipeline.rs:44-62
+    void recreate_on_buffer_or_texture_resize(uint32_t window_width, uint32_t window_height, const std::vector<Target>& targets) const {   // src/pipeline.rs:44-62
+        inner->resize_msaa_texture(window_width, window_height, targets);
         auto actual = inner->program.latest_generations();
         if (actual == inner->seen_generations) return;
         inner->rebuild();
+        inner->window_width = window_width; inner->window_height = window_height;
         inner->seen_generations = std::move(actual);
     }
-    void set_msaa_samples(uint32_t n) const { inner->msaa_samples = n; inner->rebuild(); }             // src/pipeline.rs:64-76
+    void set_msaa_samples(uint32_t n) const { inner->msaa_samples = n; inner->create_msaa_texture(); inner->rebuild(); }   // src/pipeline.rs:64-76
     void set_stream_position(RecordingPosition p) const { inner->position_in_recording = p; inner->rebuild(); }   // src/pipeline.rs:78-88
 };
 
@@ -508,7 +527,7 @@ public:
 
     // factories (src/renderer.rs:203-298)
     Pipeline pipeline(Program program, BlendMode blend_mode, Primitive primitive, uint32_t msaa_samples, std::vector<Target> targets) {
-        return Pipeline(device, std::move(program), blend_mode, primitive, msaa_samples, std::move(targets));
+        return Pipeline(device, window_width, window_height, std::move(program), blend_mode, primitive, msaa_samples, std::move(targets));
     }
     Attribute attribute(uint32_t location, uint32_t size) { return Attribute(device, location, size); }
     Instanced instanced() { return Instanced(device); }
@@ -544,7 +563,7 @@ private:
     rh_cmdbuf* render_pass(const std::vector<Target>& targets, const Pipeline& pipeline, const ClearColor* clear, const Viewport* viewport,
                            std::pair<uint32_t, uint32_t> count) {
         Pipeline::Inner& pl = *pipeline.inner;
-        pipeline.recreate_on_buffer_or_texture_resize();
+        pipeline.recreate_on_buffer_or_texture_resize(window_width, window_height, targets);
         if (recorder) recorder->recording_texture.resize(window_width, window_height, 1);
         rh_cmd* encoder = nullptr;
         check(rh_cmd_begin(device, &encoder));
@@ -552,7 +571,10 @@ private:
             std::vector<rh_attachment_desc> attachments;
             for (auto& t : targets) {
                 rh_attachment_desc a{};
-                a.texture = t.screen ? screen_handle() : t.texture.inner->handle;
+                rh_texture* view = t.screen ? screen_handle() : t.texture.inner->handle;
+                // src/render_pass.rs:76-79: render into the pipeline's multisampled texture, resolve into the target
+                if (pl.msaa_samples != 1) { a.texture = pl.msaa_texture.inner->handle; a.resolve_target = view; }
+                else a.texture = view;
                 if (clear) { a.load_op = RH_LOAD_OP_CLEAR; memcpy(a.clear, clear->inner, sizeof a.clear); } else a.load_op = RH_LOAD_OP_LOAD;
                 attachments.push_back(a);
             }

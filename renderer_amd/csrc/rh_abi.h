@@ -4,7 +4,7 @@
 #pragma once
 #include <stdint.h>
 
-#define RH_DEVICE_ABI_VERSION 6u
+#define RH_DEVICE_ABI_VERSION 7u
 #define RH_MODULE_MAGIC 0x52484d4fu   // "RHMO"
 
 #define RH_DEV_MAX_ATTRIBUTES 8
@@ -55,6 +55,9 @@ struct rh_draw_params {
     uint32_t tpi;                                    // triangles per instance
     uint32_t cpi;                                    // clusters (pairs of consecutive triangles) per instance
     uint32_t n_clusters;                             // instance_count * cpi
+    uint32_t samples;                                // 1, or 2 / 4 / 8 (multisampled pass)
+    int32_t bbox_pad;                                // growth of primitive bounding boxes in 1/256 px: 0, or 128 when
+                                                     // samples away from the pixel centre can be covered
 };
 
 // Packed tile rectangle of a cluster: x0 | y0 << 16, x1 | y1 << 16 (inclusive); x0 > x1 marks "touches nothing".
@@ -72,6 +75,11 @@ struct rh_attach_dev {
     uint32_t format;            // RH_FORMAT_RGBA_U8 or RH_FORMAT_BGRA_U8
     uint32_t load_op;           // RH_LOAD_OP_*
     uint32_t clear_rgba8;       // clear colour already converted to UNORM8, r in byte 0
+    // Multisampled passes: `ptr` is the multisampled texture (the samples of a pixel adjacent, pitch in pixels) and
+    // the averaged samples are written to the single-sampled resolve target (null: no resolve).
+    uint8_t* resolve_ptr;
+    uint32_t resolve_pitch_px;
+    uint32_t resolve_format;
 };
 
 struct rh_tile_args {

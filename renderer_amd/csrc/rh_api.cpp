@@ -115,6 +115,7 @@ struct rh_module {
     rh_module_info_t info{};
     hipFunction_t bin_count = nullptr;
     hipFunction_t tile[RH_MAX_COLOR_TARGETS] = {nullptr, nullptr, nullptr, nullptr};
+    hipFunction_t tile_ms[3] = {nullptr, nullptr, nullptr};        // 2, 4, 8 samples
 };
 
 struct SlotRef { uint32_t kind = 0, visibility = 0; rh_buffer* buf = nullptr; rh_texture* tex = nullptr; uint32_t filter = 0; };
@@ -399,11 +400,15 @@ int rh_texture_create(rh_device* dev, uint32_t width, uint32_t height, uint32_t 
     if (width == 0 || height == 0 || layers == 0) return fail("rh_texture_create: zero-sized texture");
     const uint32_t bpt = bytes_per_texel(format);
     if (bpt == 0) return fail("rh_texture_create: unknown format %u", format);
-    if (samples != 1) return fail("rh_texture_create: %u samples requested; multisampling is not implemented", samples);
+    if (samples != 1 && samples != 2 && samples != 4 && samples != 8) return fail("rh_texture_create: %u samples requested; 1, 2, 4 and 8 are implemented", samples);
+    if (samples > 1) {
+        if (layers != 1) return fail("rh_texture_create: a multisampled texture has one layer");
+        if (format != RH_FORMAT_RGBA_U8 && format != RH_FORMAT_BGRA_U8) return fail("rh_texture_create: multisampled format %u is not implemented (RGBA8/BGRA8 only)", format);
+    }
     if (set_device(dev)) return 1;
     rh_texture* t = new rh_texture();
     t->dev = dev; t->width = width; t->height = height; t->layers = layers; t->format = format; t->samples = samples; t->usage = usage;
-    t->bpt = bpt; t->bytes = (size_t)width * height * layers * bpt;
+    t->bpt = bpt; t->bytes = (size_t)width * height * layers * bpt * samples;      // the samples of a pixel are adjacent
     if (device_alloc(dev, t->bytes, &t->dptr)) { delete t; return 1; }
     device_retain(dev);
     // wgpu textures start zero-initialised
@@ -416,6 +421,7 @@ int rh_texture_create(rh_device* dev, uint32_t width, uint32_t height, uint32_t 
 int rh_texture_write(rh_texture* tex, uint32_t x, uint32_t y, uint32_t layer, uint32_t width, uint32_t height,
                      const void* data, size_t data_len, uint32_t bytes_per_row) {
     if (!tex || !data) return fail("rh_texture_write: bad argument");
+    if (tex->samples != 1) return fail("rh_texture_write: the texture is multisampled");
     if (layer >= tex->layers || x > tex->width || y > tex->height || width > tex->width - x || height > tex->height - y)
         return fail("rh_texture_write: region (%u,%u,%u)+(%u,%u) outside the %ux%ux%u texture", x, y, layer, width, height, tex->width, tex->height, tex->layers);
     if (width == 0 || height == 0) return 0;
@@ -431,7 +437,8 @@ int rh_texture_write(rh_texture* tex, uint32_t x, uint32_t y, uint32_t layer, ui
 int rh_texture_read(rh_texture* tex, uint32_t layer, void* out, size_t out_len) {
     if (!tex || !out) return fail("rh_texture_read: bad argument");
     if (layer >= tex->layers) return fail("rh_texture_read: layer %u out of range", layer);
-    const size_t layer_bytes = (size_t)tex->width * tex->height * tex->bpt;
+    // a multisampled texture reads back as width*height*samples texels, the samples of a pixel adjacent (for tests)
+    const size_t layer_bytes = (size_t)tex->width * tex->height * tex->bpt * tex->samples;
     if (out_len < layer_bytes) return fail("rh_texture_read: output too small (%zu < %zu)", out_len, layer_bytes);
     if (set_device(tex->dev)) return 1;
     RH_HIP(hipMemcpyAsync(out, (uint8_t*)tex->dptr + layer * layer_bytes, layer_bytes, hipMemcpyDeviceToHost, tex->dev->stream));
@@ -493,6 +500,9 @@ int rh_module_load(rh_device* dev, const void* code_object, size_t size, rh_modu
         const char* names[RH_MAX_COLOR_TARGETS] = { "rh_tile_1", "rh_tile_2", "rh_tile_3", "rh_tile_4" };
         for (int i = 0; i < RH_MAX_COLOR_TARGETS; i++)
             if (hipModuleGetFunction(&m->tile[i], m->module, names[i]) != hipSuccess) { (void)hipModuleUnload(m->module); delete m; return fail("rh_module_load: fragment code object lacks %s", names[i]); }
+        const char* ms_names[3] = { "rh_tile_ms2", "rh_tile_ms4", "rh_tile_ms8" };
+        for (int i = 0; i < 3; i++)
+            if (hipModuleGetFunction(&m->tile_ms[i], m->module, ms_names[i]) != hipSuccess) { (void)hipModuleUnload(m->module); delete m; return fail("rh_module_load: fragment code object lacks %s", ms_names[i]); }
     } else { (void)hipModuleUnload(m->module); delete m; return fail("rh_module_load: unknown stage"); }
     device_retain(dev);
     *out = m;
@@ -519,7 +529,7 @@ int rh_pipeline_create(rh_device* dev, const rh_pipeline_desc* d, rh_pipeline** 
     if (d->n_attributes > RH_MAX_ATTRIBUTES) return fail("rh_pipeline_create: %u attributes (max %d)", d->n_attributes, RH_MAX_ATTRIBUTES);
     if (d->n_slots > RH_DEV_MAX_SLOTS) return fail("rh_pipeline_create: %u binding slots (max %d implemented)", d->n_slots, RH_DEV_MAX_SLOTS);
     if (d->n_targets > RH_MAX_COLOR_TARGETS) return fail("rh_pipeline_create: %u colour targets (max %d)", d->n_targets, RH_MAX_COLOR_TARGETS);
-    if (d->samples != 1) return fail("rh_pipeline_create: %u samples requested; multisampling is not implemented", d->samples);
+    if (d->samples != 1 && d->samples != 2 && d->samples != 4 && d->samples != 8) return fail("rh_pipeline_create: %u samples requested; 1, 2, 4 and 8 are implemented", d->samples);
     if (d->topology != RH_TOPOLOGY_TRIANGLE_LIST && d->topology != RH_TOPOLOGY_TRIANGLE_STRIP) return fail("rh_pipeline_create: unknown topology %u", d->topology);
     rh_pipeline* p = new rh_pipeline();
     p->dev = dev; p->topology = d->topology; p->samples = d->samples;
@@ -544,6 +554,7 @@ int rh_pipeline_create(rh_device* dev, const rh_pipeline_desc* d, rh_pipeline** 
         case RH_SLOT_TEXTURE: {
             r.tex = (rh_texture*)s.resource;
             if (r.tex->format > RH_FORMAT_RGBA_F32) { delete p; return fail("rh_pipeline_create: sampling format %u is not implemented", r.tex->format); }
+            if (r.tex->samples != 1) { delete p; return fail("rh_pipeline_create: slot %u binds a multisampled texture; sampling those is not implemented", i); }
             break;
         }
         case RH_SLOT_SAMPLER: r.filter = ((rh_sampler*)s.resource)->filter; break;
@@ -580,7 +591,7 @@ static void release_cmds(std::vector<Cmd>& cmds) {
     for (Cmd& c : cmds) {
         if (c.kind == 0) {
             rh_pipeline_release(c.pass.pipeline);
-            for (auto& a : c.pass.attachments) rh_texture_release(a.texture);
+            for (auto& a : c.pass.attachments) { rh_texture_release(a.texture); rh_texture_release(a.resolve_target); }
             for (rh_buffer* b : c.pass.vertex_buffers) rh_buffer_release(b);
         } else { rh_texture_release(c.copy.tex); rh_buffer_release(c.copy.buf); }
     }
@@ -600,7 +611,18 @@ int rh_cmd_render_pass(rh_cmd* cmd, const rh_pass_desc* d) {
         if (t->format != p->targets[i].format) return fail("rh_cmd_render_pass: attachment %u has format %u but the pipeline expects %u", i, t->format, p->targets[i].format);
         if (t->width != t0->width || t->height != t0->height) return fail("rh_cmd_render_pass: attachment %u is %ux%u, attachment 0 is %ux%u", i, t->width, t->height, t0->width, t0->height);
         if (!(t->usage & RH_TEXTURE_RENDER_ATTACHMENT)) return fail("rh_cmd_render_pass: attachment %u was not created renderable", i);
+        if (t->samples != p->samples) return fail("rh_cmd_render_pass: attachment %u has %u samples but the pipeline was created for %u", i, t->samples, p->samples);
+        const rh_texture* rt = d->attachments[i].resolve_target;
+        if (rt) {
+            if (t->samples == 1) return fail("rh_cmd_render_pass: attachment %u has a resolve target but is not multisampled", i);
+            if (rt->samples != 1 || rt->format != t->format || rt->width != t->width || rt->height != t->height || rt->layers != 1)
+                return fail("rh_cmd_render_pass: the resolve target of attachment %u must be a single-sampled %ux%u texture of format %u", i, t->width, t->height, t->format);
+            if (!(rt->usage & RH_TEXTURE_RENDER_ATTACHMENT)) return fail("rh_cmd_render_pass: the resolve target of attachment %u was not created renderable", i);
+        }
     }
+    // The reference attaches its one multisampled texture to every target of the pipeline (src/render_pass.rs:76-79),
+    // which is only valid for a single attachment; the recording attachment is single-sampled and cannot join either.
+    if (p->samples > 1 && d->n_attachments != 1) return fail("rh_cmd_render_pass: a multisampled pass takes exactly one colour attachment, got %u", d->n_attachments);
     for (uint32_t i = 0; i < d->n_vertex_buffers; i++) {
         rh_buffer* b = d->vertex_buffers[i];
         if (!b) return fail("rh_cmd_render_pass: vertex buffer %u is null", i);
@@ -609,7 +631,7 @@ int rh_cmd_render_pass(rh_cmd* cmd, const rh_pass_desc* d) {
     }
     Cmd c; c.kind = 0;
     c.pass.pipeline = p; rh_pipeline_retain(p);
-    for (uint32_t i = 0; i < d->n_attachments; i++) { c.pass.attachments.push_back(d->attachments[i]); rh_texture_retain(d->attachments[i].texture); }
+    for (uint32_t i = 0; i < d->n_attachments; i++) { c.pass.attachments.push_back(d->attachments[i]); rh_texture_retain(d->attachments[i].texture); rh_texture_retain(d->attachments[i].resolve_target); }
     for (uint32_t i = 0; i < d->n_vertex_buffers; i++) { c.pass.vertex_buffers.push_back(d->vertex_buffers[i]); rh_buffer_retain(d->vertex_buffers[i]); }
     c.pass.has_viewport = d->has_viewport != 0;
     if (c.pass.has_viewport) memcpy(c.pass.viewport, d->viewport, sizeof c.pass.viewport);
@@ -719,6 +741,7 @@ int execute_pass(rh_device* dev, const PassCmd& c) {
     const uint64_t n_clusters64 = (uint64_t)p.cpi * c.instance_count;
     if (n_clusters64 >= 0xffffff00ull) return fail("render pass: %llu triangle pairs exceed the 32-bit cluster index", (unsigned long long)n_clusters64);
     p.n_clusters = (uint32_t)n_clusters64;
+    p.samples = pl->samples; p.bbox_pad = pl->samples > 1 ? 128 : 0;
     const bool empty_scissor = p.sc_x0 >= p.sc_x1 || p.sc_y0 >= p.sc_y1;
     const uint32_t n_clusters = empty_scissor ? 0u : p.n_clusters;
 
@@ -770,6 +793,7 @@ int execute_pass(rh_device* dev, const PassCmd& c) {
         rh_attach_dev& d = ta.att[i];
         d.ptr = (uint8_t*)a.texture->dptr; d.pitch_px = a.texture->width; d.format = a.texture->format; d.load_op = a.load_op;
         d.clear_rgba8 = unorm8(a.clear[0]) | (unorm8(a.clear[1]) << 8) | (unorm8(a.clear[2]) << 16) | (unorm8(a.clear[3]) << 24);
+        if (a.resolve_target) { d.resolve_ptr = (uint8_t*)a.resolve_target->dptr; d.resolve_pitch_px = a.resolve_target->width; d.resolve_format = a.resolve_target->format; }
         any_clear = any_clear || a.load_op == RH_LOAD_OP_CLEAR;
     }
     ta.src_factor = pl->targets[0].src_factor; ta.dst_factor = pl->targets[0].dst_factor;
@@ -786,7 +810,11 @@ int execute_pass(rh_device* dev, const PassCmd& c) {
         ta.variant = (blend_class && tex_class && !dev->general_kernels) ? 1 + (blend_class - 1) * 2 + (tex_class - 1) : 0;
     }
     if (timing_mark(dev)) return 1;
-    if ((total > 0 || any_clear) && n_launch_tiles > 0)
+    if (pl->samples > 1) {
+        // every tile runs: the resolve rewrites the whole target from the multisampled texture (Load included)
+        hipFunction_t fn = pl->fs->tile_ms[pl->samples == 2 ? 0 : (pl->samples == 4 ? 1 : 2)];
+        if (n_launch_tiles > 0 && launch_module_kernel(fn, n_launch_tiles, &ta, sizeof ta, s)) return 1;
+    } else if ((total > 0 || any_clear) && n_launch_tiles > 0)
         if (launch_module_kernel(pl->fs->tile[c.attachments.size() - 1], n_launch_tiles, &ta, sizeof ta, s)) return 1;
     if (timing_mark(dev)) return 1;
 

@@ -57,8 +57,9 @@ RH_DEVICE bool tri_pixel_bbox(const rh_draw_params& p, const SnappedVertex& a, c
     if (!(a.ok && b.ok && c.ok)) return false;
     int32_t minX = min(a.X, min(b.X, c.X)), maxX = max(a.X, max(b.X, c.X));
     int32_t minY = min(a.Y, min(b.Y, c.Y)), maxY = max(a.Y, max(b.Y, c.Y));
-    x0 = max(p.sc_x0, (minX + 255) >> 8); x1 = min(p.sc_x1 - 1, maxX >> 8);
-    y0 = max(p.sc_y0, (minY + 255) >> 8); y1 = min(p.sc_y1 - 1, maxY >> 8);
+    const int32_t pad = p.bbox_pad;
+    x0 = max(p.sc_x0, (minX - pad + 255) >> 8); x1 = min(p.sc_x1 - 1, (maxX + pad) >> 8);
+    y0 = max(p.sc_y0, (minY - pad + 255) >> 8); y1 = min(p.sc_y1 - 1, (maxY + pad) >> 8);
     return x0 <= x1 && y0 <= y1;
 }
 

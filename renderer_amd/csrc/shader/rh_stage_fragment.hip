@@ -107,8 +107,10 @@ RH_DEVICE int64_t clamp_i64(int64_t v, int64_t lim) { return v < -lim ? -lim : (
 // Triangle setup relative to tile origin (ox, oy).  Returns false when the triangle contributes nothing to this tile;
 // otherwise fills `t` and grows the tile-relative bbox.  `big` is set when an edge coefficient is too large for the
 // f32 coverage path.
+// `cf` receives, per edge, the constant of the edge function in 1/256 px with the top-left rule folded in
+// (inside at sub-pixel position P <=> A*Px + B*Py + cf >= 0); multisampled kernels derive per-sample constants from it.
 RH_DEVICE bool setup_triangle(const rh_draw_params& p, SnappedVertex a, SnappedVertex b, SnappedVertex c, int ox, int oy,
-                              TriData& t, int32_t ei[9], bool& persp, bool& big, int& bx0, int& by0, int& bx1, int& by1) {
+                              TriData& t, int32_t ei[9], int64_t cf[3], bool& persp, bool& big, int& bx0, int& by0, int& bx1, int& by1) {
     int x0, y0, x1, y1;
     if (!tri_pixel_bbox(p, a, b, c, x0, y0, x1, y1)) return false;
     x0 = max(x0, ox); y0 = max(y0, oy); x1 = min(x1, ox + RH_TILE_W - 1); y1 = min(y1, oy + RH_TILE_H - 1);
@@ -122,7 +124,8 @@ RH_DEVICE bool setup_triangle(const rh_draw_params& p, SnappedVertex a, SnappedV
         const int32_t A_ = P.Y - Q.Y, B_ = Q.X - P.X; \
         const int64_t C_ = -((int64_t)A_ * P.X + (int64_t)B_ * P.Y); \
         const bool tl_ = (A_ > 0) || (A_ == 0 && B_ > 0); \
-        const int64_t Cq_ = (C_ + (tl_ ? 0 : -1)) >> RH_SUBPIXEL_BITS; \
+        cf[K] = C_ + (tl_ ? 0 : -1); \
+        const int64_t Cq_ = cf[K] >> RH_SUBPIXEL_BITS; \
         ei[K] = A_; ei[3 + K] = B_; ei[6 + K] = (int32_t)clamp_i64(Cq_ + (int64_t)A_ * ox + (int64_t)B_ * oy, (int64_t)1 << 30); \
         if (A_ >= F32_EDGE_LIMIT || A_ <= -F32_EDGE_LIMIT || B_ >= F32_EDGE_LIMIT || B_ <= -F32_EDGE_LIMIT) big = true; }
     RH_EDGE(a, b, 0)
@@ -168,9 +171,44 @@ RH_DEVICE void store_edges(TriData& t, const int32_t ei[9], bool big) {
     }
 }
 
+// Standard sample locations (Vulkan 1.3, "Multisampling"), as offsets from the pixel centre in 1/256 px.
+template <int S> RH_DEVICE void sample_offset(int s, int& dx, int& dy) {
+    constexpr int8_t O2[2][2] = { { 64, 64 }, { -64, -64 } };
+    constexpr int8_t O4[4][2] = { { -32, -96 }, { 96, -32 }, { -96, 32 }, { 32, 96 } };
+    constexpr int8_t O8[8][2] = { { 16, -48 }, { -16, 48 }, { 80, 16 }, { -48, -80 }, { -80, 80 }, { -112, -16 }, { 48, 112 }, { 112, -112 } };
+    if (S == 2) { dx = O2[s & 1][0]; dy = O2[s & 1][1]; }
+    else if (S == 4) { dx = O4[s & 3][0]; dy = O4[s & 3][1]; }
+    else { dx = O8[s & 7][0]; dy = O8[s & 7][1]; }
+}
+
+// Integer edge functions of a cluster's two triangles for a multisampled pass: sample s of tile-relative pixel
+// (lx, ly) is inside edge e of triangle t <=> A[t][e]*lx + B[t][e]*ly + T[t][s][e] >= 0.  With the sample at
+// P = 256*pixel + offset_s the exact test A*Px + B*Py + cf >= 0 equals A*i + B*j + floor((cf + A*dx_s + B*dy_s) / 256) >= 0.
+template <int S>
+struct MsRecord {
+    int32_t A[2][3], B[2][3];
+    int32_t T[2][S][3];
+};
+
+template <int S>
+RH_DEVICE void store_ms_edges(MsRecord<S>& m, int t, const int32_t ei[9], const int64_t cf[3], int ox, int oy) {
+#pragma unroll
+    for (int e = 0; e < 3; e++) {
+        const int32_t A = ei[e], B = ei[3 + e];
+        m.A[t][e] = A; m.B[t][e] = B;
+#pragma unroll
+        for (int sidx = 0; sidx < S; sidx++) {
+            int dx, dy; sample_offset<S>(sidx, dx, dy);
+            const int64_t q = (cf[e] + (int64_t)A * dx + (int64_t)B * dy) >> RH_SUBPIXEL_BITS;
+            m.T[t][sidx][e] = (int32_t)clamp_i64(q + (int64_t)A * ox + (int64_t)B * oy, (int64_t)1 << 30);
+        }
+    }
+}
+
 // Sets up both triangles of `cluster`; returns the packed tile-relative bbox of their union (BBOX_EMPTY if neither
-// triangle touches the tile).
-RH_DEVICE uint32_t setup_cluster(const rh_draw_params& p, uint32_t cluster, int ox, int oy, ClusterRecord& r) {
+// triangle touches the tile).  S > 1 (multisampled pass) also fills `ms` and never takes the exact-box shortcut.
+template <int S = 1>
+RH_DEVICE uint32_t setup_cluster(const rh_draw_params& p, uint32_t cluster, int ox, int oy, ClusterRecord& r, MsRecord<S>* ms = nullptr) {
     const uint32_t instance = cluster / p.cpi, local = cluster - instance * p.cpi;
     const uint32_t tri0 = local * 2;
     const bool has_second = tri0 + 1 < p.tpi;
@@ -184,26 +222,32 @@ RH_DEVICE uint32_t setup_cluster(const rh_draw_params& p, uint32_t cluster, int 
     int bx0 = 255, by0 = 255, bx1 = -1, by1 = -1;
     bool persp_a = false, persp_b = false, big = false;
     int32_t ea[9], eb[9];
-    const bool has_a = setup_triangle(p, v0, v1, v2, ox, oy, r.t[0], ea, persp_a, big, bx0, by0, bx1, by1);
+    int64_t cfa[3], cfb[3];
+    const bool has_a = setup_triangle(p, v0, v1, v2, ox, oy, r.t[0], ea, cfa, persp_a, big, bx0, by0, bx1, by1);
     bool has_b = false, rect = false;
     int32_t rminX = 0, rmaxX = 0, rminY = 0, rmaxY = 0;
     if (has_second) {
         const SnappedVertex v3 = run_vertex(p, first + 3, instance);
         if (strip) {
-            has_b = setup_triangle(p, v1, v3, v2, ox, oy, r.t[1], eb, persp_b, big, bx0, by0, bx1, by1);
+            has_b = setup_triangle(p, v1, v3, v2, ox, oy, r.t[1], eb, cfb, persp_b, big, bx0, by0, bx1, by1);
             // a strip quad whose snapped corners form an axis-aligned rectangle split along v1-v2
             const bool columns = v0.X == v1.X && v2.X == v3.X && v0.Y == v2.Y && v1.Y == v3.Y;
             const bool rows = v0.Y == v1.Y && v2.Y == v3.Y && v0.X == v2.X && v1.X == v3.X;
-            rect = has_a && has_b && !big && (columns || rows) && v0.X != v3.X && v0.Y != v3.Y;
+            rect = S == 1 && has_a && has_b && !big && (columns || rows) && v0.X != v3.X && v0.Y != v3.Y;
             rminX = min(v0.X, v3.X); rmaxX = max(v0.X, v3.X); rminY = min(v0.Y, v3.Y); rmaxY = max(v0.Y, v3.Y);
         } else {
             const SnappedVertex v4 = run_vertex(p, first + 4, instance);
             const SnappedVertex v5 = run_vertex(p, first + 5, instance);
-            has_b = setup_triangle(p, v3, v4, v5, ox, oy, r.t[1], eb, persp_b, big, bx0, by0, bx1, by1);
+            has_b = setup_triangle(p, v3, v4, v5, ox, oy, r.t[1], eb, cfb, persp_b, big, bx0, by0, bx1, by1);
         }
     }
-    if (has_a) store_edges(r.t[0], ea, big);
-    if (has_b) store_edges(r.t[1], eb, big);
+    if (S == 1) {
+        if (has_a) store_edges(r.t[0], ea, big);
+        if (has_b) store_edges(r.t[1], eb, big);
+    } else {
+        if (has_a) store_ms_edges<S>(*ms, 0, ea, cfa, ox, oy);
+        if (has_b) store_ms_edges<S>(*ms, 1, eb, cfb, ox, oy);
+    }
     r.flags = (has_a ? FLAG_HAS_A : 0u) | (has_b ? FLAG_HAS_B : 0u) | (persp_a ? FLAG_PERSP_A : 0u) | (persp_b ? FLAG_PERSP_B : 0u) |
               (big ? FLAG_BIG : 0u) | (rect ? FLAG_RECT : 0u);
     if (!has_a && !has_b) return BBOX_EMPTY;
@@ -481,6 +525,169 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA>& lds) {
     }
 }
 
+// ---- multisampled passes -----------------------------------------------------------------------------------------
+// Same structure as tile_kernel (one workgroup per tile, one wave per region, LDS-resident tile, clusters in order),
+// with S colour samples per pixel: coverage is evaluated per sample at the standard sample locations with the same
+// integer edge functions and top-left rule, the fragment function runs once per pixel and triangle with its inputs
+// interpolated at the pixel centre, and its colour is blended into every covered sample.  The tile's samples go back to
+// the multisampled texture and their mean (round to nearest, ties to even; the sum is exact) to the resolve target.
+// One attachment; every state is read at run time.
+template <int S>
+struct TileLdsMs {
+    ClusterRecord rec[RH_BATCH_CLUSTERS];
+    MsRecord<S> ms[RH_BATCH_CLUSTERS];
+    uint32_t rec_bbox[RH_BATCH_CLUSTERS];
+    uint32_t px[S][4 * REGION_STRIDE];               // one plane per sample index
+};
+
+template <int S>
+RH_DEVICE void tile_kernel_ms(const rh_tile_args& a) {
+    __shared__ TileLdsMs<S> lds;
+    const rh_draw_params& p = a.p;
+    const rh_attach_dev& at = a.att[0];
+    const int tid = (int)threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t tile = blockIdx.x + p.tile_first;
+    const int ox = (int)(tile % p.tiles_x) * RH_TILE_W, oy = (int)(tile / p.tiles_x) * RH_TILE_H;
+    const uint32_t start = a.tile_start[tile], end = a.tile_end[tile];
+    auto lds_index = [](int lx, int ly) { return ((ly / REGION_H) * 2 + (lx / REGION_W)) * REGION_STRIDE + (ly % REGION_H) * REGION_W + (lx % REGION_W); };
+
+    // 1. the tile's samples into LDS (every tile: the resolve below rewrites the whole target)
+    for (int i = tid; i < RH_TILE_W * RH_TILE_H; i += RH_TILE_THREADS) {
+        const int lx = i & (RH_TILE_W - 1), ly = i / RH_TILE_W;
+        const uint32_t gx = (uint32_t)(ox + lx), gy = (uint32_t)(oy + ly);
+        const bool inside = gx < p.width && gy < p.height;
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(at.ptr) + ((size_t)gy * at.pitch_px + gx) * S;
+#pragma unroll
+        for (int sidx = 0; sidx < S; sidx++) {
+            uint32_t v = 0;
+            if (inside) {
+                if (at.load_op != 0u) v = at.clear_rgba8;
+                else { v = src[sidx]; if (at.format == FORMAT_BGRA_U8) v = swap_rb(v); }
+            }
+            lds.px[sidx][lds_index(lx, ly)] = v;
+        }
+    }
+
+    FragmentContext fctx; fctx.p = &p; fctx.static_rgba8 = 0u; fctx.static_filter = 0u;
+    const int rx0 = (wave & 1) * REGION_W, ry0 = (wave >> 1) * REGION_H;
+    const int sx0 = max(rx0, p.sc_x0 - ox), sy0 = max(ry0, p.sc_y0 - oy);
+    const int sx1 = min(rx0 + REGION_W - 1, p.sc_x1 - 1 - ox), sy1 = min(ry0 + REGION_H - 1, p.sc_y1 - 1 - oy);
+    const bool region_live = sx0 <= sx1 && sy0 <= sy1;
+    const float lane_f = (float)lane;
+
+    // 2. batches of clusters
+    for (uint32_t base = start; base < end; base += RH_BATCH_CLUSTERS) {
+        __syncthreads();
+        if (tid < RH_BATCH_CLUSTERS) {
+            const uint32_t ci = base + (uint32_t)tid;
+            uint32_t bb = BBOX_EMPTY;
+            if (ci < end) bb = setup_cluster<S>(p, a.list[ci], ox, oy, lds.rec[tid], &lds.ms[tid]);
+            lds.rec_bbox[tid] = bb;
+        }
+        __syncthreads();
+        if (!region_live) continue;
+        for (int round = 0; round < RH_BATCH_CLUSTERS / 64; round++) {
+            const uint32_t bb = lds.rec_bbox[round * 64 + lane];
+            const bool hit = (int)(bb & 0xffu) <= sx1 && (int)((bb >> 16) & 0xffu) >= sx0 && (int)((bb >> 8) & 0xffu) <= sy1 && (int)(bb >> 24) >= sy0;
+            unsigned long long mask = __ballot(hit);
+            while (mask) {
+                const int ci = round * 64 + __builtin_ctzll(mask);
+                mask &= mask - 1;
+                const ClusterRecord& r = lds.rec[ci];
+                const MsRecord<S>& m = lds.ms[ci];
+                const float* const rf = reinterpret_cast<const float*>(&r);
+                const uint32_t flags = __builtin_amdgcn_readfirstlane(r.flags);
+                const uint32_t hb = __builtin_amdgcn_readfirstlane(lds.rec_bbox[ci]);
+                const bool has_a = (flags & FLAG_HAS_A) != 0u, has_b = (flags & FLAG_HAS_B) != 0u;
+                const bool any_persp = (flags & (FLAG_PERSP_A | FLAG_PERSP_B)) != 0u;
+                const int hx0 = max((int)(hb & 0xffu), sx0), hy0 = max((int)((hb >> 8) & 0xffu), sy0);
+                const int hx1 = min((int)((hb >> 16) & 0xffu), sx1), hy1 = min((int)(hb >> 24), sy1);
+                const int w = hx1 - hx0 + 1, npx = w * (hy1 - hy0 + 1);
+                const float wf = (float)w, invw = __builtin_amdgcn_rcpf(wf);
+                for (int first = 0; first < npx; first += 64) {
+                    const float idx_f = lane_f + (float)first;
+                    const float row_f = floorf(__builtin_fmaf(idx_f, invw, 0.5f * invw));
+                    const float col_f = __builtin_fmaf(-row_f, wf, idx_f);
+                    const float lxf = (float)hx0 + col_f, lyf = (float)hy0 + row_f;
+                    const bool live = idx_f < (float)npx;
+                    const int lx = (int)lxf, ly = (int)lyf;
+                    const int pidx = live ? lds_index(lx, ly) : 0;
+                    // sample masks of the two triangles (a missing triangle's record holds stale values: masked by has_*)
+                    uint32_t mask_a = 0u, mask_b = 0u;
+#pragma unroll
+                    for (int sidx = 0; sidx < S; sidx++) {
+                        int ia = 0, ib = 0;
+#pragma unroll
+                        for (int e = 0; e < 3; e++) {
+                            ia |= __mul24(m.A[0][e], lx) + __mul24(m.B[0][e], ly) + m.T[0][sidx][e];
+                            ib |= __mul24(m.A[1][e], lx) + __mul24(m.B[1][e], ly) + m.T[1][sidx][e];
+                        }
+                        mask_a |= ia >= 0 ? 1u << sidx : 0u;
+                        mask_b |= ib >= 0 ? 1u << sidx : 0u;
+                    }
+                    if (!(live && has_a)) mask_a = 0u;
+                    if (!(live && has_b)) mask_b = 0u;
+                    auto shade = [&](uint32_t cov, bool use_b) {
+                        const float* const tp = rf + (use_b ? TRI_FLOATS : 0);
+                        const float dx = __builtin_fmaf(lxf, 256.0f, -tp[OFF_XR]), dy = __builtin_fmaf(lyf, 256.0f, -tp[OFF_YR]);
+                        Varyings var; float* vf = reinterpret_cast<float*>(&var);
+#pragma unroll
+                        for (int v = 0; v < NV; v++) vf[v] = __builtin_fmaf(tp[OFF_DVDY + v], dy, __builtin_fmaf(tp[OFF_DVDX + v], dx, tp[OFF_V0 + v]));
+                        if (any_persp) {
+                            const bool persp = use_b ? (flags & FLAG_PERSP_B) != 0u : (flags & FLAG_PERSP_A) != 0u;
+                            const float q = __builtin_fmaf(tp[OFF_Q0 + 2], dy, __builtin_fmaf(tp[OFF_Q0 + 1], dx, tp[OFF_Q0]));
+#pragma unroll
+                            for (int v = 0; v < NV; v++) vf[v] = persp ? vf[v] / q : vf[v];
+                        }
+                        if (cov) {
+                            Outputs out;
+                            fragment_main(fctx, var, out);
+#pragma unroll
+                            for (int sidx = 0; sidx < S; sidx++)
+                                if (cov & (1u << sidx)) {
+                                    uint32_t* px = &lds.px[sidx][pidx];
+                                    *px = blend<0>(*px, out.color[0], a.src_factor, a.dst_factor);
+                                }
+                        }
+                    };
+                    // triangle A's fragment first; a pixel with samples in both triangles gets a second invocation for B
+                    const bool first_is_b = mask_a == 0u;
+                    shade(first_is_b ? mask_b : mask_a, first_is_b);
+                    const uint32_t second = mask_a != 0u ? mask_b : 0u;
+                    if (__any(second != 0u)) shade(second, true);
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // 3. samples back to the multisampled texture, their mean to the resolve target
+    const float inv_s = 1.0f / (float)S;
+    for (int i = tid; i < RH_TILE_W * RH_TILE_H; i += RH_TILE_THREADS) {
+        const int lx = i & (RH_TILE_W - 1), ly = i / RH_TILE_W;
+        const uint32_t gx = (uint32_t)(ox + lx), gy = (uint32_t)(oy + ly);
+        if (!(gx < p.width && gy < p.height)) continue;
+        uint32_t* dst = reinterpret_cast<uint32_t*>(at.ptr) + ((size_t)gy * at.pitch_px + gx) * S;
+        uint32_t sum[4] = { 0u, 0u, 0u, 0u };
+#pragma unroll
+        for (int sidx = 0; sidx < S; sidx++) {
+            const uint32_t v = lds.px[sidx][lds_index(lx, ly)];
+            sum[0] += v & 0xffu; sum[1] += (v >> 8) & 0xffu; sum[2] += (v >> 16) & 0xffu; sum[3] += v >> 24;
+            if (at.load_op != 0u || start != end) dst[sidx] = at.format == FORMAT_BGRA_U8 ? swap_rb(v) : v;
+        }
+        if (at.resolve_ptr) {
+            uint32_t q = 0u;
+            q = __builtin_amdgcn_cvt_pk_u8_f32((float)sum[0] * inv_s, 0, q);
+            q = __builtin_amdgcn_cvt_pk_u8_f32((float)sum[1] * inv_s, 1, q);
+            q = __builtin_amdgcn_cvt_pk_u8_f32((float)sum[2] * inv_s, 2, q);
+            q = __builtin_amdgcn_cvt_pk_u8_f32((float)sum[3] * inv_s, 3, q);
+            if (at.resolve_format == FORMAT_BGRA_U8) q = swap_rb(q);
+            reinterpret_cast<uint32_t*>(at.resolve_ptr)[(size_t)gy * at.resolve_pitch_px + gx] = q;
+        }
+    }
+}
+
 // Runs the specialisation rh_tile_args::variant names; one and two attachments (plain and recorded rendering) have the
 // specialised bodies, more attachments use the general one.
 template <int NA>
@@ -504,3 +711,6 @@ extern "C" __global__ __launch_bounds__(RH_TILE_THREADS, RH_TILE_MIN_WAVES) void
 extern "C" __global__ __launch_bounds__(RH_TILE_THREADS, RH_TILE_MIN_WAVES) void rh_tile_2(rh_tile_args a) { rh::tile_dispatch<2>(a); }
 extern "C" __global__ __launch_bounds__(RH_TILE_THREADS, RH_TILE_MIN_WAVES) void rh_tile_3(rh_tile_args a) { rh::tile_dispatch<3>(a); }
 extern "C" __global__ __launch_bounds__(RH_TILE_THREADS, RH_TILE_MIN_WAVES) void rh_tile_4(rh_tile_args a) { rh::tile_dispatch<4>(a); }
+extern "C" __global__ __launch_bounds__(RH_TILE_THREADS) void rh_tile_ms2(rh_tile_args a) { rh::tile_kernel_ms<2>(a); }
+extern "C" __global__ __launch_bounds__(RH_TILE_THREADS) void rh_tile_ms4(rh_tile_args a) { rh::tile_kernel_ms<4>(a); }
+extern "C" __global__ __launch_bounds__(RH_TILE_THREADS) void rh_tile_ms8(rh_tile_args a) { rh::tile_kernel_ms<8>(a); }

@@ -33,9 +33,23 @@ class Pipeline:
         self.window_size = tuple(window_size)
         self.handle = None
         if msaa_samples > 1:
-            raise _ffi.RendererError(f"{msaa_samples} MSAA samples requested; multisampling is not implemented")
+            self.msaa_texture = self._create_msaa_texture(msaa_samples)
         self._rebuild()
         self.seen_generations = program.latest_generations()
+
+    # -- reference src/pipeline.rs:164-187 ---------------------------------------------------------------------------
+    def _create_msaa_texture(self, msaa_samples):
+        """One multisampled texture per pipeline, shaped after the FIRST target; every pass of the pipeline renders
+        into it (clear and load act on it) and resolves into the target."""
+        from .texture import Texture
+        from .filter_mode import FilterMode
+        target = self.targets[0]
+        return Texture(self.device, target.size(self.window_size), FilterMode.Nearest, target.format(), msaa_samples,
+                       True, False, False)
+
+    def _resize_msaa_texture(self, window_size, targets):
+        if self.msaa_texture is not None:
+            self.msaa_texture.resize(targets[0].size(window_size))
 
     # -- reference src/pipeline.rs:90-131 ---------------------------------------------------------------------------
     def create_bind_groups(self):
@@ -84,6 +98,8 @@ class Pipeline:
 
     def recreate_on_buffer_or_texture_resize(self, window_size, targets):
         """reference src/pipeline.rs:44-62"""
+        if targets:
+            self._resize_msaa_texture(window_size, targets)
         actual = self.program.latest_generations()
         if actual == self.seen_generations:
             return
@@ -93,8 +109,7 @@ class Pipeline:
 
     def set_msaa_samples(self, msaa_samples):
         """reference src/pipeline.rs:64-76"""
-        if msaa_samples > 1:
-            raise _ffi.RendererError(f"{msaa_samples} MSAA samples requested; multisampling is not implemented")
+        self.msaa_texture = self._create_msaa_texture(msaa_samples) if msaa_samples > 1 else None
         self.msaa_samples = msaa_samples
         self._rebuild()
 

@@ -44,15 +44,20 @@ class RenderPass:
         return cbuffer
 
     def color_attachments(self, targets, pipeline, clear):
-        attachments = [self.color_attachment(t.handle(self.renderer), clear) for t in targets]
+        attachments = [self.color_attachment(t.handle(self.renderer), clear, pipeline) for t in targets]
         if pipeline.position_in_recording is not RecordingPosition.NONE:
             attachments.append(self.renderer.recorder.color_attachment())
         return attachments
 
     @staticmethod
-    def color_attachment(texture_handle, clear):
+    def color_attachment(texture_handle, clear, pipeline=None):
         a = _ffi.AttachmentDesc()
-        a.texture = texture_handle
+        if pipeline is not None and pipeline.msaa_samples != 1:
+            # reference src/render_pass.rs:76-79: render into the pipeline's multisampled texture, resolve into the target
+            a.texture = pipeline.msaa_texture.handle
+            a.resolve_target = texture_handle
+        else:
+            a.texture = texture_handle
         if clear is not None:
             a.load_op = _ffi.LOAD_OP_CLEAR
             a.clear[:] = clear.inner

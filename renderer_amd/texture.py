@@ -65,9 +65,11 @@ class Texture:
                                                data.ctypes.data, data.nbytes, bytes_per_row))
 
     def read(self, layer=0):
-        """Synchronous read-back of one layer as an array [height, width, bytes_per_texel] of uint8."""
+        """Synchronous read-back of one layer as an array [height, width, bytes_per_texel] of uint8
+        ([height, width, samples, bytes_per_texel] for a multisampled texture)."""
         w, h, _ = self.size
-        out = np.empty((h, w, self.format.bytes_per_texel()), dtype=np.uint8)
+        shape = (h, w, self.format.bytes_per_texel()) if self.msaa_samples == 1 else (h, w, self.msaa_samples, self.format.bytes_per_texel())
+        out = np.empty(shape, dtype=np.uint8)
         _ffi.check(_ffi.lib().rh_texture_read(self.handle, layer, out.ctypes.data, out.nbytes))
         return out
 

@@ -90,8 +90,10 @@ def tiny_quads_scene(n, width, height, seed, lo=2, hi=8):
 
 
 # ---- drawing with the oracle -------------------------------------------------------------------------------------------------
-def draw_oracle(scene, threads=0, clip_to_viewport=True, initial=None):
-    """Returns {'color': uint8 [H, W, 4] in the target's byte order, 'recording': ... (if record), 'fragments': n}."""
+def draw_oracle(scene, threads=0, clip_to_viewport=True, initial=None, msaa=None):
+    """Returns {'color': uint8 [H, W, 4] in the target's byte order, 'recording': ... (if record), 'fragments': n}.
+    scene['samples'] > 1: multisampled; `msaa` is the pipeline's multisampled texture [H, W, S, 4] (zeros when None),
+    returned under 'msaa'."""
     from oracle import loader as O
     W, H = scene["width"], scene["height"]
     fmt = O.FMT_BGRA_U8 if scene["target"] == "screen" else O.FMT_RGBA_U8
@@ -112,6 +114,9 @@ def draw_oracle(scene, threads=0, clip_to_viewport=True, initial=None):
     layers = scene.get("texture_layers", 1)
     th, tw = (tex.shape[0] // layers, tex.shape[1])
     blend = {"premultiplied": (O.BF_ONE, O.BF_ONE_MINUS_SRC_ALPHA), "additive": (O.BF_ONE, O.BF_ONE)}[scene["blend"]]
+    samples = scene.get("samples", 1)
+    if samples > 1:
+        msaa = np.zeros((H, W, samples, 4), dtype=np.uint8) if msaa is None else msaa.copy()
     n = O.render(shader={"hello": O.SHADER_HELLO, "sized": O.SHADER_SIZED, "tilted": O.SHADER_TILTED,
                          "layered": O.SHADER_HELLO_LAYER}[scene["shader"]],
                  uniforms=[scene["uniform"]] if "uniform" in scene else (),
@@ -119,8 +124,11 @@ def draw_oracle(scene, threads=0, clip_to_viewport=True, initial=None):
                  vertex_count=len(scene["position"]), instance_count=len(scene["instances"]),
                  attrs=[(scene["position"], 2), (scene["uv"], 2)], storage=[scene["instances"]],
                  textures=[(tex, tw, th, layers, tfmt, O.FILTER_LINEAR if scene["filter"] == "linear" else O.FILTER_NEAREST)],
-                 targets=targets, blend=blend, viewport=viewport, clip_to_viewport=clip_to_viewport, threads=threads)
+                 targets=targets, blend=blend, viewport=viewport, clip_to_viewport=clip_to_viewport, threads=threads,
+                 samples=samples, msaa=msaa if samples > 1 else None)
     out = {"color": color, "fragments": n}
+    if samples > 1:
+        out["msaa"] = msaa
     if rec is not None:
         out["recording"] = rec
     return out
@@ -174,7 +182,7 @@ class HipScene:
         else:
             self.target_texture = r.texture(W, H, 1, Renderer.nearest_filtering(), Renderer.rgba_u8(), True, True, False)
             target = Renderer.texture_target(self.target_texture)
-        self.pipeline = r.pipeline(program, blend, primitive, 1, [target])
+        self.pipeline = r.pipeline(program, blend, primitive, scene.get("samples", 1), [target])
         r.set_attribute(self.pipeline, 0, scene["position"])
         r.set_attribute(self.pipeline, 1, scene["uv"])
         layer_px = tex.reshape(layers, -1)
@@ -223,6 +231,8 @@ def draw_hip(scene, clip_to_viewport=True, initial=None):
             hs.set_initial(initial)
         hs.draw()
         out = {"color": hs.read_color(), "stats": hs.renderer.last_pass_stats()}
+        if scene.get("samples", 1) > 1:
+            out["msaa"] = hs.pipeline.msaa_texture.read()
         if scene.get("record"):
             out["recording"] = hs.read_recording()
         return out

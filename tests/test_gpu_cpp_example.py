@@ -40,3 +40,18 @@ def test_cpp_quads_example_matches_oracle(oracle, tmp_path):
     last = seen[-1]
     rows = np.frombuffer(last.image_data.bytes(), dtype=np.uint8).reshape(last.height, last.padded_bytes_per_row)
     assert np.array_equal(rows[:, :last.unpadded_bytes_per_row].reshape(h, w, 4), got)
+
+
+def test_cpp_quads_example_multisampled(oracle, tmp_path):
+    """The same example with 4 samples (no recording: the recording attachment is single-sampled): the screen equals the
+    oracle's resolved image."""
+    from PIL import Image
+    W, H, frames = 480, 270, 30
+    out = subprocess.run([EXE, os.path.join(ROOT, "renderer_amd", "shaders"), os.path.join(ROOT, "tests", "golden", "letter_f.png"),
+                          str(tmp_path), str(frames), str(W), str(H), "4"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    scene = scenes.example_scene(frames, width=W, height=H)
+    scene["samples"] = 4
+    want = scenes.draw_oracle(scene)["color"][..., [2, 1, 0, 3]]          # the screen is BGRA
+    got = np.array(Image.open(os.path.join(tmp_path, f"frame_{frames}.png")).convert("RGBA"))
+    assert np.array_equal(got, want)

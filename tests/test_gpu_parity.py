@@ -342,3 +342,68 @@ def test_render_thread_proxy_runs_the_quads_example(oracle):
         want = scenes.draw_oracle(scenes.example_scene(number, width=W, height=H, record=True))["recording"][y0:y0 + h, x0:x0 + w]
         got = data.reshape(h, pitch)[:, :w * 4].reshape(h, w, 4)
         assert np.array_equal(got, want), f"frame {number}"
+
+
+# ---- multisampling (reference src/pipeline.rs:164-187, 209-211; src/render_pass.rs:76-81) --------------------------
+@pytest.mark.parametrize("samples", [2, 4, 8])
+@pytest.mark.parametrize("blend", ["premultiplied", "additive"])
+def test_multisampled_random_quads(oracle, samples, blend):
+    """Resolved target AND every stored sample equal the oracle's; quads at random sub-pixel offsets, deep overlap."""
+    scene = scenes.random_quads_scene(6000, 12, 333, 217, seed=40 + samples, blend=blend)
+    scene["samples"] = samples
+    orc = scenes.draw_oracle(scene)
+    hip = scenes.draw_hip(scene)
+    assert_same(hip["msaa"].reshape(217, 333 * samples, 4), orc["msaa"].reshape(217, 333 * samples, 4), f"samples {samples}x {blend}")
+    assert_same(hip["color"], orc["color"], f"resolve {samples}x {blend}")
+    # edges are antialiased: the resolved image has values the single-sampled one cannot have on a black/opaque scene
+    assert len(np.unique(hip["color"])) > 8
+
+
+def test_multisampled_projective_and_screen_target(oracle):
+    scene = scenes.tilted_quads_scene(800, 300, 200, seed=9)
+    scene["samples"] = 4
+    orc = scenes.draw_oracle(scene)
+    hip = scenes.draw_hip(scene)
+    assert_same(hip["color"], orc["color"], "tilted 4x")
+    scene = scenes.example_scene(60, 640, 360)           # BGRA8 screen target with a letterbox viewport
+    scene["samples"] = 4
+    orc = scenes.draw_oracle(scene)
+    hip = scenes.draw_hip(scene)
+    assert_same(hip["color"], orc["color"], "screen 4x")
+
+
+def test_multisampled_load_reads_the_pipelines_msaa_texture(oracle):
+    """LoadOp::Load on a multisampled pipeline continues from ITS multisampled texture, not from the target: the
+    target's previous contents are overwritten by the resolve."""
+    scene = scenes.random_quads_scene(500, 20, 256, 128, seed=5)
+    scene["samples"] = 4
+    first = scenes.draw_oracle(scene)
+    second_scene = dict(scene, clear=None, instances=scene["instances"][::-1].copy())
+    junk = np.full((128, 256, 4), 77, dtype=np.uint8)
+    second = scenes.draw_oracle(second_scene, msaa=first["msaa"], initial=junk)
+    hs = scenes.HipScene(scene)
+    try:
+        hs.draw()
+        assert_same(hs.read_color(), first["color"], "first pass")
+        hs.set_initial(junk)
+        hs.clear = None
+        hs.renderer.set_instanced(hs.pipeline, (0, 0), second_scene["instances"])
+        hs.draw()
+        assert_same(hs.read_color(), second["color"], "second pass (Load)")
+        assert_same(hs.pipeline.msaa_texture.read().reshape(128, 1024, 4), second["msaa"].reshape(128, 1024, 4), "samples after Load")
+        # dropping back to one sample renders straight into the target again
+        hs.renderer.set_msaa_samples(hs.pipeline, 1)
+        hs.clear = hs.renderer.clear_color(0., 0., 0., 1.)
+        hs.draw()
+        plain = scenes.draw_oracle(dict(second_scene, samples=1, clear=(0., 0., 0., 1.)))
+        assert_same(hs.read_color(), plain["color"], "back to single-sampled")
+    finally:
+        hs.close()
+
+
+def test_multisampled_pass_rejects_a_recording_attachment(oracle):
+    from renderer_amd import RendererError
+    scene = scenes.example_scene(1, 320, 180, record=True)
+    scene["samples"] = 4
+    with pytest.raises(RendererError, match="samples|exactly one colour attachment"):
+        scenes.draw_hip(scene)

@@ -293,3 +293,75 @@ def test_perspective_correct_interpolation_against_float64(oracle):
             assert ok, f"pixel ({i}, {j}) = {out[j, i]}"
             checked += 1
     assert checked > 1500
+
+
+# ---- multisampling ----------------------------------------------------------------------------------------------------------
+# Standard sample locations inside a pixel (Vulkan 1.3, "Multisampling"), x right, y down.
+STANDARD_SAMPLES = {
+    2: [(0.75, 0.75), (0.25, 0.25)],
+    4: [(0.375, 0.125), (0.875, 0.375), (0.125, 0.625), (0.625, 0.875)],
+    8: [(0.5625, 0.3125), (0.4375, 0.6875), (0.8125, 0.5625), (0.3125, 0.1875),
+        (0.1875, 0.8125), (0.0625, 0.4375), (0.6875, 0.9375), (0.9375, 0.0625)],
+}
+
+
+@pytest.mark.parametrize("samples", [2, 4, 8])
+def test_multisample_coverage_of_an_axis_aligned_quad_by_hand(oracle, samples):
+    """An opaque quad [x0, x1) x [y0, y1) with edges off the sample grid: every stored sample is set exactly when its
+    standard location lies inside the rectangle, each covered sample holds exactly one layer (the shared diagonal is
+    hit once per sample), and the resolve is the mean rounded to nearest, ties to even."""
+    x0, y0, x1, y1 = 2.2, 1.6, 6.2, 5.6
+    s = px_quad_scene(x0, y0, x1, y1, W=8, H=8, rgba=(255, 255, 255, 255), clear=(0., 0., 0., 0.))
+    s["samples"] = samples
+    o = scenes.draw_oracle(s, threads=1)
+    expect = np.zeros((8, 8, samples), dtype=np.uint8)
+    for j in range(8):
+        for i in range(8):
+            for k, (sx, sy) in enumerate(STANDARD_SAMPLES[samples]):
+                expect[j, i, k] = 255 if (x0 <= i + sx < x1 and y0 <= j + sy < y1) else 0
+    assert np.array_equal(o["msaa"][..., 0], expect)
+    assert np.array_equal(o["msaa"][..., 3], expect)
+    mean = expect.astype(np.float64).sum(axis=2) / samples
+    assert np.array_equal(o["color"][..., 0], np.rint(mean).astype(np.uint8))        # np.rint: ties to even
+    if samples == 4:
+        assert o["color"][3, 2, 0] == 191 and o["color"][3, 6, 0] == 64 and o["color"][1, 3, 0] == 128 and o["color"][1, 2, 0] == 64
+
+
+def test_multisample_edges_on_sample_positions_follow_the_top_left_rule(oracle):
+    # left edge exactly through sample 2 of 4x (x = 0.125): a left edge takes it; the right edge at x = 4.125 does not
+    s = px_quad_scene(2.125, 1.0, 4.125, 3.0, W=8, H=4, rgba=(255, 255, 255, 255))
+    s["samples"] = 4
+    o = scenes.draw_oracle(s, threads=1)
+    assert o["msaa"][1, 2, 2, 0] == 255 and o["msaa"][1, 4, 2, 0] == 0
+    assert o["color"][1, 2, 0] == 255 and o["color"][1, 4, 0] == 0 and o["color"][1, 3, 0] == 255
+
+
+def test_multisample_area_is_preserved(oracle):
+    """Size-independent property: an opaque quad of area A pixels adds 255*A to the resolved channel sum, up to the
+    sampling error of its four edges and 0.5 per edge pixel of rounding."""
+    for samples in (2, 4, 8):
+        s = px_quad_scene(3.3, 2.7, 27.9, 25.1, rgba=(255, 255, 255, 255))
+        s["samples"] = samples
+        o = scenes.draw_oracle(s, threads=1)
+        area = (27.9 - 3.3) * (25.1 - 2.7)
+        total = o["color"][..., 0].astype(np.float64).sum() / 255.0
+        assert abs(total - area) < 0.35 * (2 * (24.6 + 22.4)) , (samples, total, area)
+        single = scenes.draw_oracle(px_quad_scene(3.3, 2.7, 27.9, 25.1, rgba=(255, 255, 255, 255)), threads=1)
+        assert abs(total - area) <= abs(single["color"][..., 0].astype(np.float64).sum() / 255.0 - area) + 1e-9
+
+
+def test_multisample_load_continues_from_the_sample_buffer(oracle):
+    s = px_quad_scene(2.2, 1.6, 6.2, 5.6, W=8, H=8, blend="additive", rgba=(10, 20, 30, 40))
+    s["samples"] = 4
+    one = scenes.draw_oracle(s, threads=1)
+    two = scenes.draw_oracle(dict(s, clear=None), threads=1, msaa=one["msaa"], initial=np.full((8, 8, 4), 99, np.uint8))
+    assert np.array_equal(two["msaa"], one["msaa"] * 2)
+    assert two["color"][3, 3, 0] == 20 and two["color"][0, 0, 0] == 0        # the target's old contents are gone
+
+
+def test_multisample_thread_invariance(oracle):
+    s = scenes.random_quads_scene(400, 9, 96, 64, seed=3)
+    s["samples"] = 4
+    a = scenes.draw_oracle(s, threads=1)
+    b = scenes.draw_oracle(s, threads=5)
+    assert np.array_equal(a["color"], b["color"]) and np.array_equal(a["msaa"], b["msaa"]) and a["fragments"] == b["fragments"]

@@ -80,7 +80,7 @@ def render(shader, topology, vertex_count, instance_count, attrs, storage, textu
     attrs:    list of (np.float32 array, size)
     storage:  list of np.float32 arrays
     textures: list of (np.uint8 array [layers*H*W*C], width, height, layers, format, filter)
-    targets:  list of dicts {data: np.uint8 [H, W, 4] (modified in place), format, clear: None | (r, g, b, a)}
+    targets:  list of dicts {data: np.uint8 [H, W, bytes per texel] (modified in place), format, clear: None | (r, g, b, a)}
     blend:    (src_factor, dst_factor)
     samples:  1, or 2/4/8 with msaa = np.uint8 [H, W, samples, 4] (the pipeline's multisampled texture, modified in
               place and resolved into the single target)
@@ -111,7 +111,8 @@ def render(shader, topology, vertex_count, instance_count, attrs, storage, textu
     d.n_targets = len(targets)
     for i, t in enumerate(targets):
         buf = t["data"]
-        assert buf.dtype == np.uint8 and buf.flags["C_CONTIGUOUS"] and buf.ndim == 3 and buf.shape[2] == 4
+        bpt = {FMT_R_U8: 1, FMT_RGBA_F16: 8, FMT_RGBA_F32: 16}.get(t.get("format", FMT_RGBA_U8), 4)
+        assert buf.dtype == np.uint8 and buf.flags["C_CONTIGUOUS"] and buf.ndim == 3 and buf.shape[2] == bpt
         d.targets[i].data = buf.ctypes.data
         d.targets[i].height, d.targets[i].width = buf.shape[0], buf.shape[1]
         d.targets[i].format = t.get("format", FMT_RGBA_U8)

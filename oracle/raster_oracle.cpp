@@ -52,9 +52,9 @@ struct orc_texture {
 };
 
 struct orc_target {
-    uint8_t* data;         // width*height*4 bytes, row 0 = top
+    uint8_t* data;         // width*height texels of the format's size (1, 4, 8 or 16 bytes), row 0 = top
     uint32_t width, height;
-    uint32_t format;       // ORC_FMT_RGBA_U8 or ORC_FMT_BGRA_U8 (reference src/target.rs:8-13)
+    uint32_t format;       // any ORC_FMT_* (reference src/target.rs:8-13: the screen is BGRA8, a texture has its own format)
     int32_t  clear;        // 1 = LoadOp::Clear(clear_rgba), 0 = LoadOp::Load (reference src/render_pass.rs:71-74)
     double   clear_rgba[4];// reference src/clear_color.rs:7-16 (f32 -> f64)
 };
@@ -121,6 +121,24 @@ inline float half_to_float(uint16_t h) {
     } else if (exp == 31) bits = sign | 0x7f800000u | (man << 13);
     else bits = sign | ((exp + 112u) << 23) | (man << 13);
     float f; std::memcpy(&f, &bits, 4); return f;
+}
+
+// f32 -> f16, round to nearest even, overflow to infinity, denormals kept (IEEE 754 binary16)
+inline uint16_t float_to_half(float f) {
+    uint32_t x; std::memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7fffffffu;
+    if (x >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | (x > 0x7f800000u ? 0x200u | ((x >> 13) & 0x3ffu) : 0u));   // inf / NaN
+    if (x >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);                  // rounds to >= 2^16: infinity
+    if (x < 0x33000001u) return (uint16_t)sign;                               // <= 2^-25: rounds to zero
+    int e = (int)(x >> 23) - 127;
+    uint32_t m = (x & 0x7fffffu) | 0x800000u;                                 // 24-bit significand
+    int shift = e < -14 ? 13 + (-14 - e) : 13;                                // bits dropped (denormal results drop more)
+    uint32_t kept = m >> shift, rem = m & ((1u << shift) - 1u), halfway = 1u << (shift - 1);
+    if (rem > halfway || (rem == halfway && (kept & 1u))) kept++;
+    // kept carries the implicit bit for normal results: adding the exponent field absorbs a mantissa carry correctly
+    uint32_t h = e < -14 ? kept : (((uint32_t)(e + 15) << 10) + (kept - 0x400u));
+    return (uint16_t)(sign | h);
 }
 
 inline void fetch_texel(const orc_texture& t, int x, int y, uint32_t layer, float out[4]) {
@@ -335,10 +353,29 @@ inline uint8_t to_unorm8(float o) {
 // out = src*SF + dst*DF per channel, alpha included (reference src/blend_mode.rs:31-40), destination read back as
 // UNORM8 and the result re-quantised after every fragment.  Evaluated on the 0..255 scale:
 //   q = rint(clamp(fma(dst_byte, DF, (src*SF)*255), 0, 255)),  NaN -> 0, ties to even.
+// Float targets blend in f32 without clamping, out = fma(dst, DF, src*SF); an RGBA16F result is rounded to f16 (nearest
+// even) after every fragment.  An R8 target stores the red channel only.
 inline void blend_store(const orc_draw& d, const orc_target& tg, size_t pix, const float src[4]) {
+    const float sf = factor(d.src_factor, src[3]), df = factor(d.dst_factor, src[3]);
+    if (tg.format == ORC_FMT_RGBA_F32 || tg.format == ORC_FMT_RGBA_F16) {
+        for (int k = 0; k < 4; k++) {
+            float dst;
+            if (tg.format == ORC_FMT_RGBA_F32) std::memcpy(&dst, tg.data + (pix * 4 + k) * 4, 4);
+            else { uint16_t h; std::memcpy(&h, tg.data + (pix * 4 + k) * 2, 2); dst = half_to_float(h); }
+            const float o = fmaf(dst, df, src[k] * sf);
+            if (tg.format == ORC_FMT_RGBA_F32) std::memcpy(tg.data + (pix * 4 + k) * 4, &o, 4);
+            else { const uint16_t h = float_to_half(o); std::memcpy(tg.data + (pix * 4 + k) * 2, &h, 2); }
+        }
+        return;
+    }
+    if (tg.format == ORC_FMT_R_U8) {
+        float o = fmaf((float)tg.data[pix], df, (src[0] * sf) * 255.0f);
+        o = fminf(fmaxf(o, 0.0f), 255.0f);
+        tg.data[pix] = (uint8_t)rintf(o);
+        return;
+    }
     uint8_t* p = tg.data + pix * 4;
     const bool bgra = tg.format == ORC_FMT_BGRA_U8;
-    const float sf = factor(d.src_factor, src[3]), df = factor(d.dst_factor, src[3]);
     uint8_t q[4];
     for (int k = 0; k < 4; k++) {
         int byte = bgra ? (k == 0 ? 2 : (k == 2 ? 0 : k)) : k;
@@ -353,6 +390,17 @@ inline void blend_store(const orc_draw& d, const orc_target& tg, size_t pix, con
 
 void clear_rows(const orc_target& tg, int y0, int y1, uint8_t* msaa = nullptr, uint32_t samples = 1) {
     if (!tg.clear) return;
+    if (tg.format == ORC_FMT_RGBA_F32 || tg.format == ORC_FMT_RGBA_F16 || tg.format == ORC_FMT_R_U8) {
+        for (size_t pix = (size_t)y0 * tg.width; pix < (size_t)y1 * tg.width; pix++) {
+            if (tg.format == ORC_FMT_R_U8) { tg.data[pix] = to_unorm8((float)tg.clear_rgba[0]); continue; }
+            for (int k = 0; k < 4; k++) {
+                const float c = (float)tg.clear_rgba[k];
+                if (tg.format == ORC_FMT_RGBA_F32) std::memcpy(tg.data + (pix * 4 + k) * 4, &c, 4);
+                else { const uint16_t h = float_to_half(c); std::memcpy(tg.data + (pix * 4 + k) * 2, &h, 2); }
+            }
+        }
+        return;
+    }
     uint8_t q[4];
     for (int k = 0; k < 4; k++) q[k] = to_unorm8((float)tg.clear_rgba[k]);
     uint8_t px[4] = { q[0], q[1], q[2], q[3] };
@@ -447,6 +495,7 @@ extern "C" int orc_render(orc_draw* d) {
     const Shader& sh = SHADERS[d->shader];
     const uint32_t S = d->samples > 1 ? d->samples : 1;
     if (S > 1 && ((S != 2 && S != 4 && S != 8) || d->n_targets != 1 || !d->msaa)) return -4;
+    if (S > 1 && d->targets[0].format != ORC_FMT_RGBA_U8 && d->targets[0].format != ORC_FMT_BGRA_U8) return -5;
     const int W = (int)d->targets[0].width, H = (int)d->targets[0].height;
     for (uint32_t a = 1; a < d->n_targets; a++)
         if ((int)d->targets[a].width != W || (int)d->targets[a].height != H) return -3;
@@ -510,4 +559,7 @@ extern "C" int orc_render(orc_draw* d) {
     return 0;
 }
 
-extern "C" int orc_abi_version(void) { return 2; }
+extern "C" int orc_abi_version(void) { return 3; }
+
+// test hook: the f32 -> f16 conversion used for RGBA16F targets
+extern "C" uint16_t orc_float_to_half(float f) { return float_to_half(f); }

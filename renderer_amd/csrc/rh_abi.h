@@ -4,7 +4,7 @@
 #pragma once
 #include <stdint.h>
 
-#define RH_DEVICE_ABI_VERSION 7u
+#define RH_DEVICE_ABI_VERSION 8u
 #define RH_MODULE_MAGIC 0x52484d4fu   // "RHMO"
 
 #define RH_DEV_MAX_ATTRIBUTES 8
@@ -72,9 +72,10 @@ struct rh_bin_count_args {
 struct rh_attach_dev {
     uint8_t* ptr;               // texel (0,0)
     uint32_t pitch_px;          // row pitch in pixels
-    uint32_t format;            // RH_FORMAT_RGBA_U8 or RH_FORMAT_BGRA_U8
+    uint32_t format;            // RH_FORMAT_*
     uint32_t load_op;           // RH_LOAD_OP_*
     uint32_t clear_rgba8;       // clear colour already converted to UNORM8, r in byte 0
+    float clear_f[4];           // clear colour as f32 (float formats)
     // Multisampled passes: `ptr` is the multisampled texture (the samples of a pixel adjacent, pitch in pixels) and
     // the averaged samples are written to the single-sampled resolve target (null: no resolve).
     uint8_t* resolve_ptr;

@@ -116,6 +116,7 @@ struct rh_module {
     hipFunction_t bin_count = nullptr;
     hipFunction_t tile[RH_MAX_COLOR_TARGETS] = {nullptr, nullptr, nullptr, nullptr};
     hipFunction_t tile_ms[3] = {nullptr, nullptr, nullptr};        // 2, 4, 8 samples
+    hipFunction_t tile_wide[RH_MAX_COLOR_TARGETS] = {nullptr, nullptr, nullptr, nullptr};   // passes with a float attachment
 };
 
 struct SlotRef { uint32_t kind = 0, visibility = 0; rh_buffer* buf = nullptr; rh_texture* tex = nullptr; uint32_t filter = 0; };
@@ -500,6 +501,9 @@ int rh_module_load(rh_device* dev, const void* code_object, size_t size, rh_modu
         const char* names[RH_MAX_COLOR_TARGETS] = { "rh_tile_1", "rh_tile_2", "rh_tile_3", "rh_tile_4" };
         for (int i = 0; i < RH_MAX_COLOR_TARGETS; i++)
             if (hipModuleGetFunction(&m->tile[i], m->module, names[i]) != hipSuccess) { (void)hipModuleUnload(m->module); delete m; return fail("rh_module_load: fragment code object lacks %s", names[i]); }
+        const char* wide_names[RH_MAX_COLOR_TARGETS] = { "rh_tile_w1", "rh_tile_w2", "rh_tile_w3", "rh_tile_w4" };
+        for (int i = 0; i < RH_MAX_COLOR_TARGETS; i++)
+            if (hipModuleGetFunction(&m->tile_wide[i], m->module, wide_names[i]) != hipSuccess) { (void)hipModuleUnload(m->module); delete m; return fail("rh_module_load: fragment code object lacks %s", wide_names[i]); }
         const char* ms_names[3] = { "rh_tile_ms2", "rh_tile_ms4", "rh_tile_ms8" };
         for (int i = 0; i < 3; i++)
             if (hipModuleGetFunction(&m->tile_ms[i], m->module, ms_names[i]) != hipSuccess) { (void)hipModuleUnload(m->module); delete m; return fail("rh_module_load: fragment code object lacks %s", ms_names[i]); }
@@ -540,7 +544,8 @@ int rh_pipeline_create(rh_device* dev, const rh_pipeline_desc* d, rh_pipeline** 
     }
     for (uint32_t i = 0; i < d->n_targets; i++) {
         const rh_color_target_desc& t = d->targets[i];
-        if (t.format != RH_FORMAT_RGBA_U8 && t.format != RH_FORMAT_BGRA_U8) { delete p; return fail("rh_pipeline_create: colour target format %u is not implemented (RGBA8/BGRA8 only)", t.format); }
+        if (t.format > RH_FORMAT_RGBA_F32) { delete p; return fail("rh_pipeline_create: unknown colour target format %u", t.format); }
+        if (d->samples > 1 && t.format != RH_FORMAT_RGBA_U8 && t.format != RH_FORMAT_BGRA_U8) { delete p; return fail("rh_pipeline_create: multisampled colour target format %u is not implemented (RGBA8/BGRA8 only)", t.format); }
         if (t.src_factor > RH_BLEND_ONE_MINUS_SRC_ALPHA || t.dst_factor > RH_BLEND_ONE_MINUS_SRC_ALPHA) { delete p; return fail("rh_pipeline_create: unknown blend factor"); }
         if (t.src_factor != d->targets[0].src_factor || t.dst_factor != d->targets[0].dst_factor) { delete p; return fail("rh_pipeline_create: all colour targets must share one blend state"); }
         p->targets.push_back(t);
@@ -793,6 +798,7 @@ int execute_pass(rh_device* dev, const PassCmd& c) {
         rh_attach_dev& d = ta.att[i];
         d.ptr = (uint8_t*)a.texture->dptr; d.pitch_px = a.texture->width; d.format = a.texture->format; d.load_op = a.load_op;
         d.clear_rgba8 = unorm8(a.clear[0]) | (unorm8(a.clear[1]) << 8) | (unorm8(a.clear[2]) << 16) | (unorm8(a.clear[3]) << 24);
+        for (int k = 0; k < 4; k++) d.clear_f[k] = (float)a.clear[k];
         if (a.resolve_target) { d.resolve_ptr = (uint8_t*)a.resolve_target->dptr; d.resolve_pitch_px = a.resolve_target->width; d.resolve_format = a.resolve_target->format; }
         any_clear = any_clear || a.load_op == RH_LOAD_OP_CLEAR;
     }
@@ -814,8 +820,12 @@ int execute_pass(rh_device* dev, const PassCmd& c) {
         // every tile runs: the resolve rewrites the whole target from the multisampled texture (Load included)
         hipFunction_t fn = pl->fs->tile_ms[pl->samples == 2 ? 0 : (pl->samples == 4 ? 1 : 2)];
         if (n_launch_tiles > 0 && launch_module_kernel(fn, n_launch_tiles, &ta, sizeof ta, s)) return 1;
-    } else if ((total > 0 || any_clear) && n_launch_tiles > 0)
-        if (launch_module_kernel(pl->fs->tile[c.attachments.size() - 1], n_launch_tiles, &ta, sizeof ta, s)) return 1;
+    } else if ((total > 0 || any_clear) && n_launch_tiles > 0) {
+        bool any_float = false;
+        for (const rh_attachment_desc& a : c.attachments) any_float = any_float || a.texture->format == RH_FORMAT_RGBA_F16 || a.texture->format == RH_FORMAT_RGBA_F32;
+        hipFunction_t fn = any_float ? pl->fs->tile_wide[c.attachments.size() - 1] : pl->fs->tile[c.attachments.size() - 1];
+        if (launch_module_kernel(fn, n_launch_tiles, &ta, sizeof ta, s)) return 1;
+    }
     if (timing_mark(dev)) return 1;
 
     dev->stats.clusters = n_clusters; dev->stats.bin_entries = total;

@@ -289,19 +289,84 @@ constexpr int OFF_XR = 9, OFF_YR = 10, OFF_V0 = 11, OFF_DVDX = OFF_V0 + NV, OFF_
 static_assert(offsetof(TriData, XR) == OFF_XR * 4 && offsetof(TriData, v0) == OFF_V0 * 4 && offsetof(TriData, q0) == OFF_Q0 * 4,
               "fragment-side offsets must match TriData");
 
+// ---- attachment pixels --------------------------------------------------------------------------------------------
+// LDS slot of one attachment pixel.  Narrow kernels (every attachment 8-bit UNORM): the packed pixel, r in byte 0 (an R8
+// attachment loads and stores byte 0 only).  Wide kernels (some attachment is RGBA16F / RGBA32F): 16 bytes; a float
+// attachment keeps its four channels as f32 (RGBA16F values always rounded to f16, as the memory would hold them), a
+// UNORM attachment its packed pixel in .x.
+template <bool WIDE> struct Px { using T = uint32_t; };
+template <> struct Px<true> { using T = uint4; };
+
+RH_DEVICE bool is_float_format(uint32_t f) { return f == FORMAT_RGBA_F16 || f == FORMAT_RGBA_F32; }
+RH_DEVICE float round_to_f16(float v) { return (float)(_Float16)v; }
+
+RH_DEVICE uint32_t load_unorm(const rh_attach_dev& at, size_t pix) {
+    if (at.format == FORMAT_R_U8) return at.ptr[pix];
+    const uint32_t v = reinterpret_cast<const uint32_t*>(at.ptr)[pix];
+    return at.format == FORMAT_BGRA_U8 ? swap_rb(v) : v;
+}
+RH_DEVICE void store_unorm(const rh_attach_dev& at, size_t pix, uint32_t v) {
+    if (at.format == FORMAT_R_U8) { at.ptr[pix] = (uint8_t)v; return; }
+    reinterpret_cast<uint32_t*>(at.ptr)[pix] = at.format == FORMAT_BGRA_U8 ? swap_rb(v) : v;
+}
+
+RH_DEVICE uint32_t load_pixel(const rh_attach_dev& at, size_t pix, uint32_t*) { return load_unorm(at, pix); }
+RH_DEVICE uint4 load_pixel(const rh_attach_dev& at, size_t pix, uint4*) {
+    if (at.format == FORMAT_RGBA_F32) return reinterpret_cast<const uint4*>(at.ptr)[pix];
+    if (at.format == FORMAT_RGBA_F16) {
+        const _Float16* h = reinterpret_cast<const _Float16*>(at.ptr) + pix * 4;
+        return make_uint4(__float_as_uint((float)h[0]), __float_as_uint((float)h[1]), __float_as_uint((float)h[2]), __float_as_uint((float)h[3]));
+    }
+    return make_uint4(load_unorm(at, pix), 0u, 0u, 0u);
+}
+RH_DEVICE uint32_t clear_pixel(const rh_attach_dev& at, uint32_t*) { return at.clear_rgba8; }
+RH_DEVICE uint4 clear_pixel(const rh_attach_dev& at, uint4*) {
+    if (!is_float_format(at.format)) return make_uint4(at.clear_rgba8, 0u, 0u, 0u);
+    const bool h = at.format == FORMAT_RGBA_F16;
+    return make_uint4(__float_as_uint(h ? round_to_f16(at.clear_f[0]) : at.clear_f[0]), __float_as_uint(h ? round_to_f16(at.clear_f[1]) : at.clear_f[1]),
+                      __float_as_uint(h ? round_to_f16(at.clear_f[2]) : at.clear_f[2]), __float_as_uint(h ? round_to_f16(at.clear_f[3]) : at.clear_f[3]));
+}
+RH_DEVICE void store_pixel(const rh_attach_dev& at, size_t pix, uint32_t v) { store_unorm(at, pix, v); }
+RH_DEVICE void store_pixel(const rh_attach_dev& at, size_t pix, uint4 v) {
+    if (at.format == FORMAT_RGBA_F32) { reinterpret_cast<uint4*>(at.ptr)[pix] = v; return; }
+    if (at.format == FORMAT_RGBA_F16) {
+        _Float16* h = reinterpret_cast<_Float16*>(at.ptr) + pix * 4;
+        h[0] = (_Float16)__uint_as_float(v.x); h[1] = (_Float16)__uint_as_float(v.y); h[2] = (_Float16)__uint_as_float(v.z); h[3] = (_Float16)__uint_as_float(v.w);
+        return;
+    }
+    store_unorm(at, pix, v.x);
+}
+// Float attachments blend in f32 without clamping: out = fma(dst, DF, src*SF) per channel; an RGBA16F result is rounded
+// to f16 (to nearest even) after every fragment, like the 8-bit re-quantisation.
+template <int BLEND>
+RH_DEVICE void blend_pixel(uint32_t* px, const rh_attach_dev&, float4 s, uint32_t src_factor, uint32_t dst_factor) {
+    *px = blend<BLEND>(*px, s, src_factor, dst_factor);
+}
+template <int BLEND>
+RH_DEVICE void blend_pixel(uint4* px, const rh_attach_dev& at, float4 s, uint32_t src_factor, uint32_t dst_factor) {
+    if (!is_float_format(at.format)) { px->x = blend<BLEND>(px->x, s, src_factor, dst_factor); return; }
+    const float sf = blend_factor(src_factor, s.w), df = blend_factor(dst_factor, s.w);
+    const uint4 d = *px;
+    float o0 = __builtin_fmaf(__uint_as_float(d.x), df, s.x * sf), o1 = __builtin_fmaf(__uint_as_float(d.y), df, s.y * sf);
+    float o2 = __builtin_fmaf(__uint_as_float(d.z), df, s.z * sf), o3 = __builtin_fmaf(__uint_as_float(d.w), df, s.w * sf);
+    if (at.format == FORMAT_RGBA_F16) { o0 = round_to_f16(o0); o1 = round_to_f16(o1); o2 = round_to_f16(o2); o3 = round_to_f16(o3); }
+    *px = make_uint4(__float_as_uint(o0), __float_as_uint(o1), __float_as_uint(o2), __float_as_uint(o3));
+}
+
 // The LDS of a tile workgroup; declared once per exported kernel and shared by its specialisations.
-template <int NA>
+template <int NA, bool WIDE = false>
 struct TileLds {
     ClusterRecord rec[RH_BATCH_CLUSTERS];
     uint32_t rec_bbox[RH_BATCH_CLUSTERS];
-    uint32_t tile_px[NA][4 * REGION_STRIDE];
+    typename Px<WIDE>::T tile_px[NA][4 * REGION_STRIDE];
 };
 
-template <int NA, int BLEND, int TEX>
-RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA>& lds) {
+template <int NA, int BLEND, int TEX, bool WIDE = false>
+RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
+    using PxT = typename Px<WIDE>::T;
     ClusterRecord* const rec = lds.rec;
     uint32_t* const rec_bbox = lds.rec_bbox;
-    uint32_t (* const tile_px)[4 * REGION_STRIDE] = lds.tile_px;
+    PxT (* const tile_px)[4 * REGION_STRIDE] = lds.tile_px;
 
     const rh_draw_params& p = a.p;
     const int tid = (int)threadIdx.x, lane = tid & 63;
@@ -318,14 +383,9 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA>& lds) {
         for (int i = tid; i < RH_TILE_W * RH_TILE_H; i += RH_TILE_THREADS) {
             const int lx = i & (RH_TILE_W - 1), ly = i / RH_TILE_W;
             const uint32_t gx = (uint32_t)(ox + lx), gy = (uint32_t)(oy + ly);
-            uint32_t v = 0;
-            if (gx < p.width && gy < p.height) {
-                if (at.load_op != 0u) v = at.clear_rgba8;
-                else {
-                    v = reinterpret_cast<const uint32_t*>(at.ptr)[(size_t)gy * at.pitch_px + gx];
-                    if (at.format == FORMAT_BGRA_U8) v = swap_rb(v);
-                }
-            }
+            PxT v{};
+            if (gx < p.width && gy < p.height)
+                v = at.load_op != 0u ? clear_pixel(at, (PxT*)nullptr) : load_pixel(at, (size_t)gy * at.pitch_px + gx, (PxT*)nullptr);
             tile_px[t][((ly / REGION_H) * 2 + (lx / REGION_W)) * REGION_STRIDE + (ly % REGION_H) * REGION_W + (lx % REGION_W)] = v;
         }
     }
@@ -339,7 +399,7 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA>& lds) {
     const int sx0 = max(rx0, p.sc_x0 - ox), sy0 = max(ry0, p.sc_y0 - oy);
     const int sx1 = min(rx0 + REGION_W - 1, p.sc_x1 - 1 - ox), sy1 = min(ry0 + REGION_H - 1, p.sc_y1 - 1 - oy);
     const bool region_live = sx0 <= sx1 && sy0 <= sy1;
-    uint32_t* const region_px = &tile_px[0][wave * REGION_STRIDE];
+    PxT* const region_px = &tile_px[0][wave * REGION_STRIDE];
     const float lane_f = (float)lane;
     const float region_bias = (float)(ry0 * REGION_W + rx0);   // pidx = (ly - ry0) * REGION_W + (lx - rx0)
 
@@ -492,8 +552,8 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA>& lds) {
                         fragment_main(fctx, var, out);
 #pragma unroll
                         for (int n = 0; n < NA; n++) {
-                            uint32_t* px = region_px + n * (4 * REGION_STRIDE) + pidx;
-                            *px = blend<BLEND>(*px, out.color[n < RH_FRAGMENT_OUTPUTS ? n : RH_FRAGMENT_OUTPUTS - 1], a.src_factor, a.dst_factor);
+                            blend_pixel<BLEND>(region_px + n * (4 * REGION_STRIDE) + pidx, a.att[n],
+                                               out.color[n < RH_FRAGMENT_OUTPUTS ? n : RH_FRAGMENT_OUTPUTS - 1], a.src_factor, a.dst_factor);
                         }
                     }
                 };
@@ -517,9 +577,8 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA>& lds) {
             const int lx = i & (RH_TILE_W - 1), ly = i / RH_TILE_W;
             const uint32_t gx = (uint32_t)(ox + lx), gy = (uint32_t)(oy + ly);
             if (gx < p.width && gy < p.height) {
-                uint32_t v = tile_px[t][((ly / REGION_H) * 2 + (lx / REGION_W)) * REGION_STRIDE + (ly % REGION_H) * REGION_W + (lx % REGION_W)];
-                if (at.format == FORMAT_BGRA_U8) v = swap_rb(v);
-                reinterpret_cast<uint32_t*>(at.ptr)[(size_t)gy * at.pitch_px + gx] = v;
+                store_pixel(at, (size_t)gy * at.pitch_px + gx,
+                            tile_px[t][((ly / REGION_H) * 2 + (lx / REGION_W)) * REGION_STRIDE + (ly % REGION_H) * REGION_W + (lx % REGION_W)]);
             }
         }
     }
@@ -705,6 +764,13 @@ RH_DEVICE void tile_dispatch(const rh_tile_args& a) {
     tile_kernel<NA, 0, 0>(a, lds);
 }
 
+// Passes with an RGBA16F / RGBA32F attachment: 16-byte LDS pixels, every state read at run time.
+template <int NA>
+RH_DEVICE void tile_dispatch_wide(const rh_tile_args& a) {
+    __shared__ TileLds<NA, true> lds;
+    tile_kernel<NA, 0, 0, true>(a, lds);
+}
+
 } // namespace rh
 
 extern "C" __global__ __launch_bounds__(RH_TILE_THREADS, RH_TILE_MIN_WAVES) void rh_tile_1(rh_tile_args a) { rh::tile_dispatch<1>(a); }
@@ -714,3 +780,7 @@ extern "C" __global__ __launch_bounds__(RH_TILE_THREADS, RH_TILE_MIN_WAVES) void
 extern "C" __global__ __launch_bounds__(RH_TILE_THREADS) void rh_tile_ms2(rh_tile_args a) { rh::tile_kernel_ms<2>(a); }
 extern "C" __global__ __launch_bounds__(RH_TILE_THREADS) void rh_tile_ms4(rh_tile_args a) { rh::tile_kernel_ms<4>(a); }
 extern "C" __global__ __launch_bounds__(RH_TILE_THREADS) void rh_tile_ms8(rh_tile_args a) { rh::tile_kernel_ms<8>(a); }
+extern "C" __global__ __launch_bounds__(RH_TILE_THREADS) void rh_tile_w1(rh_tile_args a) { rh::tile_dispatch_wide<1>(a); }
+extern "C" __global__ __launch_bounds__(RH_TILE_THREADS) void rh_tile_w2(rh_tile_args a) { rh::tile_dispatch_wide<2>(a); }
+extern "C" __global__ __launch_bounds__(RH_TILE_THREADS) void rh_tile_w3(rh_tile_args a) { rh::tile_dispatch_wide<3>(a); }
+extern "C" __global__ __launch_bounds__(RH_TILE_THREADS) void rh_tile_w4(rh_tile_args a) { rh::tile_dispatch_wide<4>(a); }

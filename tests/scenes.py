@@ -89,6 +89,10 @@ def tiny_quads_scene(n, width, height, seed, lo=2, hi=8):
                 clear=(0., 0., 0., 1.), viewport=None, record=False)
 
 
+# target_format -> (oracle format id = reference src/format.rs order, bytes per texel)
+TARGET_FORMATS = {"r_u8": (0, 1), "bgra_u8": (1, 4), "rgba_u8": (2, 4), "rgba_f16": (3, 8), "rgba_f32": (4, 16)}
+
+
 # ---- drawing with the oracle -------------------------------------------------------------------------------------------------
 def draw_oracle(scene, threads=0, clip_to_viewport=True, initial=None, msaa=None):
     """Returns {'color': uint8 [H, W, 4] in the target's byte order, 'recording': ... (if record), 'fragments': n}.
@@ -96,8 +100,9 @@ def draw_oracle(scene, threads=0, clip_to_viewport=True, initial=None, msaa=None
     returned under 'msaa'."""
     from oracle import loader as O
     W, H = scene["width"], scene["height"]
-    fmt = O.FMT_BGRA_U8 if scene["target"] == "screen" else O.FMT_RGBA_U8
-    color = np.zeros((H, W, 4), dtype=np.uint8) if initial is None else initial.copy()
+    fmt = O.FMT_BGRA_U8 if scene["target"] == "screen" else TARGET_FORMATS[scene.get("target_format", "rgba_u8")][0]
+    bpt = 4 if scene["target"] == "screen" else TARGET_FORMATS[scene.get("target_format", "rgba_u8")][1]
+    color = np.zeros((H, W, bpt), dtype=np.uint8) if initial is None else initial.copy()
     targets = [dict(data=color, format=fmt, clear=scene["clear"])]
     rec = None
     if scene.get("record"):
@@ -180,7 +185,9 @@ class HipScene:
             self.target_texture = None
             target = Renderer.screen_target()
         else:
-            self.target_texture = r.texture(W, H, 1, Renderer.nearest_filtering(), Renderer.rgba_u8(), True, True, False)
+            tfmt = {"rgba_u8": Renderer.rgba_u8(), "bgra_u8": Renderer.bgra_u8(), "r_u8": Renderer.red_u8(),
+                    "rgba_f16": Renderer.rgba_f16(), "rgba_f32": Renderer.rgba_f32()}[scene.get("target_format", "rgba_u8")]
+            self.target_texture = r.texture(W, H, 1, Renderer.nearest_filtering(), tfmt, True, True, False)
             target = Renderer.texture_target(self.target_texture)
         self.pipeline = r.pipeline(program, blend, primitive, scene.get("samples", 1), [target])
         r.set_attribute(self.pipeline, 0, scene["position"])
@@ -205,7 +212,7 @@ class HipScene:
         h = self.target_texture.handle if self.target_texture is not None else self.renderer.screen_handle()
         image = np.ascontiguousarray(image)
         _ffi.check(_ffi.lib().rh_texture_write(h, 0, 0, 0, image.shape[1], image.shape[0], image.ctypes.data,
-                                               image.nbytes, image.shape[1] * 4))
+                                               image.nbytes, image.shape[1] * image.shape[2]))
 
     def draw(self):
         self.renderer.render(self.pipeline, self.clear, self.viewport, self.count)

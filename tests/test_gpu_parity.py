@@ -407,3 +407,51 @@ def test_multisampled_pass_rejects_a_recording_attachment(oracle):
     scene["samples"] = 4
     with pytest.raises(RendererError, match="samples|exactly one colour attachment"):
         scenes.draw_hip(scene)
+
+
+# ---- render targets of every format (reference src/target.rs:8-13, src/format.rs:3-30) --------------------------------
+@pytest.mark.parametrize("target_format", ["r_u8", "bgra_u8", "rgba_f16", "rgba_f32"])
+@pytest.mark.parametrize("blend", ["premultiplied", "additive"])
+def test_render_target_formats(oracle, target_format, blend):
+    """Bit-exact target bytes: R8 keeps the red channel, float targets blend unclamped in f32 (RGBA16F rounded to f16
+    after every fragment) - additive layers go far above 1.0 here."""
+    scene = scenes.random_quads_scene(9000, 14, 333, 217, seed=21, blend=blend)
+    scene["target_format"] = target_format
+    orc = scenes.draw_oracle(scene)
+    hip = scenes.draw_hip(scene)
+    assert hip["color"].shape == orc["color"].shape
+    assert np.array_equal(hip["color"], orc["color"]), f"{target_format}/{blend}: {(hip['color'] != orc['color']).any(axis=2).sum()} texels differ"
+    if target_format == "rgba_f32" and blend == "additive":
+        assert orc["color"].view(np.float32).max() > 2.0
+
+
+def test_float_target_load_and_recording_attachment_together(oracle):
+    """A float target and the 8-bit recording attachment in one pass (mixed pixel sizes), continuing from existing
+    float contents (LoadOp::Load) with a non-trivial clear colour on the recording attachment."""
+    scene = scenes.example_scene(60, 480, 270, record=True)
+    scene["target"] = "texture"
+    scene["target_format"] = "rgba_f16"
+    scene["clear"] = None
+    scene["record_clear"] = (0.25, 0.5, 0.125, 1.0)
+    rng = np.random.default_rng(1)
+    initial = rng.uniform(-2.0, 2.0, (270, 480, 4)).astype(np.float16).view(np.uint8).reshape(270, 480, 8)
+    orc = scenes.draw_oracle(scene, initial=initial)
+    hip = scenes.draw_hip(scene, initial=initial)
+    assert np.array_equal(hip["color"], orc["color"])
+    assert_same(hip["recording"], orc["recording"], "recording beside a float target")
+
+
+def test_float_target_sampled_by_a_second_pass(oracle):
+    """Pass 1 renders additive layers into an RGBA32F texture; pass 2 samples it (values above 1.0 survive) into RGBA8."""
+    from renderer_amd import Renderer
+    first = scenes.random_quads_scene(3000, 24, 256, 256, seed=8, blend="additive")
+    first["target_format"] = "rgba_f32"
+    o1 = scenes.draw_oracle(first)
+    hdr = o1["color"].view(np.float32).reshape(256, 256, 4)
+    second = scenes.random_quads_scene(50, 64, 320, 200, seed=9, texture=(hdr * np.float32(0.25)).astype(np.float32))
+    second["texture_format"] = "rgba_f32"
+    o2 = scenes.draw_oracle(second)
+    h1 = scenes.draw_hip(first)
+    assert np.array_equal(h1["color"], o1["color"])
+    second_hip = dict(second, texture=(h1["color"].view(np.float32).reshape(256, 256, 4) * np.float32(0.25)).astype(np.float32))
+    assert_same(scenes.draw_hip(second_hip)["color"], o2["color"], "sampling the float target's contents")

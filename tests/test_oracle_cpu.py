@@ -365,3 +365,46 @@ def test_multisample_thread_invariance(oracle):
     a = scenes.draw_oracle(s, threads=1)
     b = scenes.draw_oracle(s, threads=5)
     assert np.array_equal(a["color"], b["color"]) and np.array_equal(a["msaa"], b["msaa"]) and a["fragments"] == b["fragments"]
+
+
+# ---- render target formats -----------------------------------------------------------------------------------------------------
+def test_float_to_half_matches_numpy(oracle):
+    """The f32 -> f16 rounding RGBA16F targets use (nearest even, overflow to infinity, denormals kept) against numpy."""
+    import ctypes as C
+    from oracle import loader
+    lib = loader.raster_lib()
+    lib.orc_float_to_half.argtypes = [C.c_float]; lib.orc_float_to_half.restype = C.c_uint16
+    rng = np.random.default_rng(0)
+    bits = np.concatenate([rng.integers(0, 2 ** 32, 20000, dtype=np.uint64).astype(np.uint32),
+                           np.arange(0x33000000 - 5, 0x33000000 + 5, dtype=np.uint32),          # around 2^-25 (rounds to 0 / min denormal)
+                           np.arange(0x477fefff - 3, 0x477ff003, dtype=np.uint32),              # around 65520 (rounds to max / infinity)
+                           np.arange(0x38800000 - 4, 0x38800000 + 4, dtype=np.uint32)])         # around 2^-14 (denormal / normal)
+    vals = np.concatenate([bits.view(np.float32), (rng.standard_normal(20000) * np.exp(rng.uniform(-20, 12, 20000))).astype(np.float32)])
+    with np.errstate(all="ignore"):
+        want = vals.astype(np.float16).view(np.uint16)
+    for v, w in zip(vals, want):
+        if not np.isnan(v):
+            assert lib.orc_float_to_half(float(v)) == w, v
+
+
+def test_float_and_r8_targets_by_hand(oracle):
+    # three additive layers of (0.4, 0.8, 1.0, 0.5) (texture bytes 102, 204, 255, 128 / 255)
+    s = px_quad_scene(2.0, 2.0, 6.0, 6.0, W=8, H=8, rgba=(102, 204, 255, 128), n=3, clear=(0.5, 0., 0., 0.))
+    c = [f32(v) * f32(1.0 / 255.0) for v in (102, 204, 255, 128)]
+    # RGBA32F: unclamped f32 accumulation on top of the clear colour
+    o = scenes.draw_oracle(dict(s, target_format="rgba_f32"), threads=1)["color"].view(np.float32).reshape(8, 8, 4)
+    want = [f32(0.5), f32(0), f32(0), f32(0)]
+    for _ in range(3):
+        want = [f32(w + ck) for w, ck in zip(want, c)]
+    assert np.array_equal(o[3, 3], np.array(want, dtype=f32)) and o[3, 3, 2] == 3.0 and np.array_equal(o[0, 0], np.array([0.5, 0, 0, 0], dtype=f32))
+    # RGBA16F: the same, rounded to f16 after every layer
+    o = scenes.draw_oracle(dict(s, target_format="rgba_f16"), threads=1)["color"].view(np.float16).reshape(8, 8, 4)
+    want = [np.float16(0.5), np.float16(0), np.float16(0), np.float16(0)]
+    for _ in range(3):
+        want = [np.float16(f32(w) + ck) for w, ck in zip(want, c)]
+    assert np.array_equal(o[3, 3], np.array(want, dtype=np.float16))
+    # R8: red only, saturating at 255: 128 + 3 * 102 > 255
+    o = scenes.draw_oracle(dict(s, target_format="r_u8"), threads=1)["color"]
+    assert o.shape == (8, 8, 1) and o[3, 3, 0] == 255 and o[0, 0, 0] == 128
+    o = scenes.draw_oracle(dict(s, target_format="r_u8", instances=np.zeros((1, 2), dtype=f32)), threads=1)["color"]
+    assert o[3, 3, 0] == 128 + 102

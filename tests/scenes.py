@@ -94,7 +94,7 @@ TARGET_FORMATS = {"r_u8": (0, 1), "bgra_u8": (1, 4), "rgba_u8": (2, 4), "rgba_f1
 
 
 # ---- drawing with the oracle -------------------------------------------------------------------------------------------------
-def draw_oracle(scene, threads=0, clip_to_viewport=True, initial=None, msaa=None):
+def draw_oracle(scene, threads=0, clip_to_viewport=True, initial=None, msaa=None, initial_recording=None):
     """Returns {'color': uint8 [H, W, 4] in the target's byte order, 'recording': ... (if record), 'fragments': n}.
     scene['samples'] > 1: multisampled; `msaa` is the pipeline's multisampled texture [H, W, S, 4] (zeros when None),
     returned under 'msaa'."""
@@ -106,7 +106,7 @@ def draw_oracle(scene, threads=0, clip_to_viewport=True, initial=None, msaa=None
     targets = [dict(data=color, format=fmt, clear=scene["clear"])]
     rec = None
     if scene.get("record"):
-        rec = np.zeros((H, W, 4), dtype=np.uint8)
+        rec = np.zeros((H, W, 4), dtype=np.uint8) if initial_recording is None else initial_recording.copy()
         targets.append(dict(data=rec, format=O.FMT_RGBA_U8, clear=scene.get("record_clear", scene["clear"])))
     viewport = None
     if scene["viewport"] is not None:

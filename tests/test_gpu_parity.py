@@ -455,3 +455,34 @@ def test_float_target_sampled_by_a_second_pass(oracle):
     assert np.array_equal(h1["color"], o1["color"])
     second_hip = dict(second, texture=(h1["color"].view(np.float32).reshape(256, 256, 4) * np.float32(0.25)).astype(np.float32))
     assert_same(scenes.draw_hip(second_hip)["color"], o2["color"], "sampling the float target's contents")
+
+
+def test_two_recorded_pipelines_share_the_recording_texture(oracle):
+    """reference src/renderer.rs:178-188: every recorded pipeline gets the recording attachment, the first use of a
+    frame clears it, later pipelines load it, and only the Last one copies the frame out."""
+    from renderer_amd import Renderer
+    W, H = 480, 270
+    first = scenes.random_quads_scene(300, 40, W, H, seed=1, target="screen")
+    second = scenes.tiny_quads_scene(4000, W, H, seed=2)
+    second["target"] = "screen"
+    o1 = scenes.draw_oracle(dict(first, record=True, record_clear=(0.1, 0.2, 0.3, 1.0)))
+    o2 = scenes.draw_oracle(dict(second, record=True, record_clear=None, clear=None), initial=o1["color"], initial_recording=o1["recording"])
+    r = Renderer(W, H)
+    try:
+        a, b = scenes.HipScene(first, renderer=r), scenes.HipScene(second, renderer=r)
+        frames = []
+        r.start_recording([a.pipeline, b.pipeline], Renderer.clear_color(0.1, 0.2, 0.3, 1.0), 500., frames.append)
+        for _ in range(2):
+            r.render(a.pipeline, a.clear, None, a.count)
+            r.render(b.pipeline, None, None, b.count)
+            r.finish_frame()
+        r.synchronize()
+        r.recorder.process_mapped_buffers()
+        assert_same(r.read_screen(), o2["color"], "screen after both pipelines")
+        assert_same(r.recorder.recording_texture.read(), o2["recording"], "recording after both pipelines")
+        assert [f.frame_number for f in frames] == [1, 2]            # one capture per frame, after the Last pipeline
+        got = []
+        frames[0].image_data.bytes_fn(lambda b: got.append(np.array(b).reshape(H, frames[0].padded_bytes_per_row)))
+        assert_same(got[0][:, :W * 4].reshape(H, W, 4), o2["recording"], "captured frame")
+    finally:
+        r.close()

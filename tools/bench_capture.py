@@ -127,24 +127,47 @@ def main():
     L.LZ4F_compressUpdate.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
     L.LZ4F_compressUpdate.restype = C.c_size_t
     L.LZ4F_isError.argtypes = [C.c_size_t]; L.LZ4F_isError.restype = C.c_uint
-    ctx, prefs = C.c_void_p(), Prefs()
-    prefs.autoFlush = 1
-    assert not L.LZ4F_isError(L.LZ4F_createCompressionContext(C.byref(ctx), 100))
-    head = (C.c_uint8 * 32)()
-    assert not L.LZ4F_isError(L.LZ4F_compressBegin(ctx, head, 32, C.byref(prefs)))
     img = np.ascontiguousarray(last).tobytes()
-    src = (C.c_uint8 * len(img)).from_buffer_copy(img)
-    cap = L.LZ4F_compressBound(len(img), C.byref(prefs))
-    dst = (C.c_uint8 * cap)()
-    cpu_s = 0.0
-    for _ in range(args.cpu_frames):                           # only the library call on the image is timed
+
+    def compress_on_one_core(n_frames, result, slot):
+        """One LZ4F stream, the way one worker thread of the reference holds one (src/compressor.rs:64-69); only the
+        library call on the image is timed.  ctypes releases the GIL during the call, so threads run in parallel."""
+        ctx, prefs = C.c_void_p(), Prefs()
+        prefs.autoFlush = 1
+        assert not L.LZ4F_isError(L.LZ4F_createCompressionContext(C.byref(ctx), 100))
+        head = (C.c_uint8 * 32)()
+        assert not L.LZ4F_isError(L.LZ4F_compressBegin(ctx, head, 32, C.byref(prefs)))
+        src = (C.c_uint8 * len(img)).from_buffer_copy(img)
+        cap = L.LZ4F_compressBound(len(img), C.byref(prefs))
+        dst = (C.c_uint8 * cap)()
+        busy = 0.0
+        for _ in range(n_frames):
+            t1 = time.perf_counter()
+            n = L.LZ4F_compressUpdate(ctx, dst, cap, src, len(img), None)
+            busy += time.perf_counter() - t1
+            assert not L.LZ4F_isError(n)
+        result[slot] = busy
+
+    if args.cpu_frames > 0:
+        one = [0.0]
+        compress_on_one_core(args.cpu_frames, one, 0)
+        out["cpu_baseline"] = {"value": args.cpu_frames / one[0], "unit": "frames/s", "cores": 1, "kind": "reference-library",
+                               "sample": f"liblz4 1.9.3 level 0, {args.cpu_frames} frames of {len(img)} B on one core "
+                                         f"(compress only, no rendering), {one[0]:.2f} s"}
+        # the reference runs one stream per core (src/compressor.rs:24-26): the same on this box's CPU share
+        import threading
+        cores = min(16, os.cpu_count() or 1)
+        busy = [0.0] * cores
+        threads = [threading.Thread(target=compress_on_one_core, args=(args.cpu_frames, busy, i)) for i in range(cores)]
         t1 = time.perf_counter()
-        n = L.LZ4F_compressUpdate(ctx, dst, cap, src, len(img), None)
-        cpu_s += time.perf_counter() - t1
-        assert not L.LZ4F_isError(n)
-    out["cpu_baseline"] = {"value": args.cpu_frames / cpu_s, "unit": "frames/s", "cores": 1, "kind": "reference-library",
-                           "sample": f"liblz4 1.9.3 level 0, {args.cpu_frames} frames of {len(img)} B on one core "
-                                     f"(compress only, no rendering), {cpu_s:.2f} s"}
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        wall = time.perf_counter() - t1
+        out["cpu_baseline_all_cores"] = {"value": cores * args.cpu_frames / wall, "unit": "frames/s", "cores": cores, "kind": "reference-library",
+                                         "sample": f"{cores} threads, one LZ4F stream each, {args.cpu_frames} frames per thread, {wall:.2f} s wall "
+                                                   "(includes context set-up)"}
     print(json.dumps(out), flush=True)
 
 

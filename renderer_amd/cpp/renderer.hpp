@@ -396,6 +396,8 @@ public:
         if (!f.image_data) return;
         const uint32_t margin_x = viewport ? (uint32_t)std::ceil(viewport->margin_x) : 0, margin_y = viewport ? (uint32_t)std::ceil(viewport->margin_y) : 0;
         const Texture::Inner& tex = *recording_texture.inner;
+        // u32 arithmetic in the reference (src/video_recorder.rs:124-125): a viewport thinner than one pixel panics
+        if (2 * margin_x > tex.width || 2 * margin_y > tex.height) throw Panic("attempt to subtract with overflow");
         check(rh_cmd_copy_texture_to_buffer(encoder, tex.handle, margin_x, margin_y, f.image_data, f.padded_bytes_per_row, f.height,
                                             tex.width - 2 * margin_x, tex.height - 2 * margin_y));
     }

@@ -92,6 +92,9 @@ class VideoRecorder:
         tex = self.recording_texture
         extent_w = tex.size[0] - 2 * margin_x
         extent_h = tex.size[1] - 2 * margin_y
+        if extent_w < 0 or extent_h < 0:
+            # u32 arithmetic in the reference (src/video_recorder.rs:124-125): a viewport thinner than one pixel panics
+            raise _ffi.RendererError("attempt to subtract with overflow")
         _ffi.check(_ffi.lib().rh_cmd_copy_texture_to_buffer(
             encoder, tex.handle, margin_x, margin_y, video_frame.image_data.buffer(),
             video_frame.padded_bytes_per_row, video_frame.height, extent_w, extent_h))

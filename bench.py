@@ -58,11 +58,14 @@ def main():
     ap.add_argument("--workload", choices=["c1", "c2"], default="c1",
                     help="c1 (headline): --quads quads of --side px, alpha blend; c2: --quads quads of 2..8 px, additive")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--capture-frames", type=int, default=256,
-                    help="frames of the recorded-frames/s leg (BASELINE.json configs[4] shape, per GPU); 0 skips it")
+    ap.add_argument("--capture-frames", type=int, default=-1,
+                    help="frames of the recorded-frames/s leg (BASELINE.json configs[4] shape, per GPU); 0 skips it; "
+                         "default 256, or 128 (one round of the 128 streams) when more than two ranks share the host's /tmp")
     ap.add_argument("--capture-streams", type=int, default=128)
     args = ap.parse_args()
 
+    if args.capture_frames < 0:
+        args.capture_frames = 256 if max(args.gpus, int(os.environ.get("WORLD_SIZE", "1"))) <= 2 else 128
     default_workload = (args.workload, args.quads, args.side, args.width, args.height) == ("c1", 1_000_000, 16, 3840, 2160)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -78,8 +78,14 @@ def main():
         # purpose: it bundles a HIP runtime of its own and the two must share one (see renderer_amd/partition.py).
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if os.environ.get("RH_REHEARSE_ON_ONE_GPU") == "1":
+            # every rank on GPU 0 with gloo between them: a rehearsal of the multi-rank control flow on a one-GPU box
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group(backend="gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     import numpy as np
     import scenes
@@ -99,7 +105,7 @@ def main():
 
     def barrier():
         if dist is not None:
-            dist.barrier(device_ids=[local_rank])
+            dist.barrier(device_ids=[local_rank]) if dist.get_backend() == "nccl" else dist.barrier()
         renderer.synchronize()
 
     for _ in range(args.warmup):

@@ -40,12 +40,20 @@ def strip_for_rank(height, rank, world, tile=TILE):
     return min(first * tile, height), min((first + count) * tile, height)
 
 
+def comm_device(device, group=None):
+    """Where the tensors handed to the collectives live: the GPU with RCCL; host memory with gloo, which has no
+    all-gather or send/recv for device tensors (rehearsals of the multi-process path on one GPU use gloo)."""
+    import torch.distributed as dist
+    return "cpu" if dist.get_backend(group) == "gloo" else device
+
+
 def gather_bytes(payload, dst=0, device="cpu", group=None):
     """Gathers one variable-length byte string per rank to `dst` (RCCL/gloo have no gatherv: lengths are all-gathered,
     then every peer sends its bytes point to point).  Returns the list of payloads in rank order on `dst`, else None."""
     import torch
     import torch.distributed as dist
     rank, world = dist.get_rank(group), dist.get_world_size(group)
+    device = comm_device(device, group)
     length = torch.tensor([len(payload)], dtype=torch.int64, device=device)
     lengths = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
     dist.all_gather(lengths, length, group=group)
@@ -77,11 +85,12 @@ def all_gather_strips(strip, height, device="cpu", group=None):
     width = strip.shape[1]
     rows = [strip_for_rank(height, r, world) for r in range(world)]
     max_rows = max(r1 - r0 for r0, r1 in rows)
-    padded = torch.zeros((max_rows, width, 4), dtype=torch.uint8, device=device)
-    padded[:strip.shape[0]] = strip
+    via = comm_device(device, group)
+    padded = torch.zeros((max_rows, width, 4), dtype=torch.uint8, device=via)
+    padded[:strip.shape[0]] = strip.to(via)
     parts = [torch.empty_like(padded) for _ in range(world)]
     dist.all_gather(parts, padded, group=group)
-    return torch.cat([parts[r][:rows[r][1] - rows[r][0]] for r in range(world)], dim=0)
+    return torch.cat([parts[r][:rows[r][1] - rows[r][0]] for r in range(world)], dim=0).to(device)
 
 
 class _DeviceArray:

@@ -1,0 +1,61 @@
+"""The multi-process tools (one process per GPU under torch.distributed.run) rehearsed with two ranks sharing the one
+GPU of the test box and gloo between them (RH_REHEARSE_ON_ONE_GPU=1): rendezvous, strip assignment, the all-gather of
+the intermediate target, the gather of results and of encoded frames are the real code; only RCCL itself is replaced."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def launch(world, script, args, port):
+    env = dict(os.environ, RH_REHEARSE_ON_ONE_GPU="1")
+    if world == 1:
+        cmd = [sys.executable, os.path.join(ROOT, "tools", script)] + args
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(ROOT, "tools", script)] + args
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=280, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return out.stdout
+
+
+def test_two_rank_strips_equal_one_rank(tmp_path):
+    from PIL import Image
+    one, two = str(tmp_path / "one.png"), str(tmp_path / "two.png")
+    args = ["--size", "512", "--quads", "3000", "--side", "24"]
+    launch(1, "render_strips.py", args + ["--out", one], 0)
+    launch(2, "render_strips.py", args + ["--out", two], 29611)
+    a, b = np.array(Image.open(one)), np.array(Image.open(two))
+    assert a.shape == (512, 512, 4) and np.array_equal(a, b)
+    assert len(np.unique(a)) > 16                         # a real image, not a cleared target
+
+
+def test_two_rank_frame_parallel_recording_equals_one_rank(tmp_path):
+    one, two = str(tmp_path / "one.pngstream"), str(tmp_path / "two.pngstream")
+    args = ["--frames", "12", "--width", "320", "--height", "180"]
+    launch(1, "record_frame_parallel.py", args + ["--out", one], 0)
+    launch(2, "record_frame_parallel.py", args + ["--out", two], 29612)
+    a, b = open(one, "rb").read(), open(two, "rb").read()
+    assert a.count(b"IEND") == 12 and a == b              # the same 12 PNGs in frame order
+
+
+def test_bench_with_two_ranks_prints_one_json_line(tmp_path):
+    """bench.py under torch.distributed.run with two ranks (rehearsal mode): rank 0 prints exactly one JSON line on
+    stdout with the whole-job value; nothing else reaches stdout."""
+    import json
+    env = dict(os.environ, RH_REHEARSE_ON_ONE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29613",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--quads", "100000", "--no-cpu-baseline",
+           "--capture-frames", "8", "--capture-streams", "4"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=280, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and d["scaling"] == "weak"
+    assert d["roofline"]["frac"] > 0 and d["capture"]["value"] > 0 and d["capture"]["frames_per_gpu"] == 8

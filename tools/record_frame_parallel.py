@@ -76,8 +76,14 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if os.environ.get("RH_REHEARSE_ON_ONE_GPU") == "1":
+            # every rank on GPU 0, gloo between them: exercises the multi-process path where only one GPU is present
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group(backend="gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         device = f"cuda:{local_rank}"
     sink = pipe = None
     if rank == 0:
@@ -96,7 +102,7 @@ def main():
     t0 = time.perf_counter()
     n = record(args.frames, args.width, args.height, write, rank, world, local_rank, dist, device)
     if dist is not None:
-        dist.barrier(device_ids=[local_rank])
+        dist.barrier(device_ids=[local_rank]) if dist.get_backend() == "nccl" else dist.barrier()
     if rank == 0:
         dt = time.perf_counter() - t0
         if sink is not None:

@@ -86,8 +86,14 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if os.environ.get("RH_REHEARSE_ON_ONE_GPU") == "1":
+            # every rank on GPU 0, gloo between them: exercises the multi-process path where only one GPU is present
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group(backend="gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         device = f"cuda:{local_rank}"
     image, seconds = render_two_pass(args.size, args.quads, args.side, rank, world, local_rank, device)
     if rank == 0:

@@ -66,8 +66,7 @@ struct Ring {
 
 // Number of equal bytes of ring[ip..] and ring[match..], stopping at `limit` (a virtual offset bounding ip).  256 bytes
 // per step.
-__device__ __forceinline__ uint32_t count_match(const Ring& R, uint32_t ip, uint32_t match, uint32_t limit, int lane) {
-    uint32_t n = 0;
+__device__ __forceinline__ uint32_t count_match(const Ring& R, uint32_t ip, uint32_t match, uint32_t limit, int lane, uint32_t n = 0) {
     for (;;) {
         const uint32_t p = ip + n + (uint32_t)lane * 4u;
         uint32_t avail = p < limit ? limit - p : 0u; if (avail > 4u) avail = 4u;
@@ -176,47 +175,73 @@ __device__ uint32_t compress_block(Lds& L, const Ring& R, Stream& st, uint32_t n
                     h = (uint32_t)(((s8 << 24) * 889523592379ULL) >> (64 - HASHLOG));
                 }
                 const uint32_t mine = p - bias;
-                // candidate: the table entry, unless an earlier lane of this round has the same hash.  All valid lanes
-                // insert tentatively; a lane that does not read its own value back shares its hash with another lane.
-                uint32_t mi = 0, old = 0, back = 0;
-                // (other lanes write the same table, so a lane's own store must not be forwarded to its load: the
-                // compiler barrier makes the read-back a real LDS load; a volatile pointer would lose the LDS address
-                // space and turn these into flat accesses)
+                // Candidate of a lane: the table entry, unless an earlier lane of this round has the same hash (the
+                // sequential walk would have seen that lane's insert).  Lanes with equal hashes address the same table
+                // slot, so the slot itself finds each group's first lane: save the entry, store all-ones, atomic-min
+                // the lane numbers in, read the winner back, and let the winners restore the entry.  (A lane's own
+                // store must not be forwarded to its later load, other lanes write the same slot: the compiler
+                // barriers make every access a real LDS operation; a volatile pointer would lose the LDS address space.)
                 uint32_t* const table = L.hash;
-                if (valid) { old = table[h]; table[h] = mine; }
+                uint32_t old = 0, leader = (uint32_t)lane;
+                if (valid) { old = table[h]; table[h] = 0xffffffffu; }
                 asm volatile("" ::: "memory");
-                if (valid) back = table[h];
-                mi = old;
-                unsigned long long same = 1ull << lane;                     // lanes of this round with the same hash
-                const bool collisions = __ballot(valid && back != mine) != 0ull;
-                if (collisions) {
-                    if (valid) table[h] = old;                              // undo, then resolve exactly
-                    // one step per hash value that occurs more than once: its lanes learn their group
-                    unsigned long long losers = __ballot(valid && back != mine);
-                    while (losers) {
-                        const uint32_t hl = (uint32_t)__builtin_amdgcn_readlane((int)h, __builtin_ctzll(losers));
-                        const bool in_group = valid && h == hl;
-                        const unsigned long long group = __ballot(in_group);
-                        if (in_group) same = group;
-                        losers &= ~group;
-                    }
-                    const unsigned long long prev = valid ? (same & below) : 0ull;
-                    const uint32_t from_lane = (uint32_t)__shfl((int)mine, prev ? 63 - __builtin_clzll(prev) : lane);   // all lanes take part
-                    if (prev) mi = from_lane;
-                }
-                bool hit = false;
-                if (valid && tests) {
-                    const bool ok = !(dict_small && mi < prefix_idx_limit) && (mi + DISTANCE_MAX >= mine);
-                    if (ok) hit = R.rd32(mi + bias) == seq;
-                }
-                const unsigned long long hits = __ballot(hit);
+                if (valid) atomicMin(&table[h], (uint32_t)lane);
+                asm volatile("" ::: "memory");
+                if (valid) leader = table[h];
+                asm volatile("" ::: "memory");
+                if (valid && leader == (uint32_t)lane) table[h] = old;      // the table is as it was
+                const unsigned long long repeats = __ballot(valid && leader != (uint32_t)lane);   // lanes with an earlier lane of the same hash
                 const int first_invalid = (~vm) ? __builtin_ctzll(~vm) : 64;
+                uint32_t mi = old;
+                unsigned long long same = 1ull << lane;                     // (general path) lanes of this round with the same hash
+                // Up to the first repeating lane f every candidate is the table entry; f's own candidate is its group's
+                // first lane.  A repeated hash is nearly always a repeated sequence, i.e. f is a match, so the walk
+                // usually stops at or before f and the lanes behind it never matter.
+                const int f = repeats ? __builtin_ctzll(repeats) : 64;
+                const uint32_t from_leader = (uint32_t)__shfl((int)mine, (int)leader);          // all lanes take part
+                if (lane == f) mi = from_leader;
+                auto test = [&](uint32_t cand) {
+                    bool t = false;
+                    if (valid && tests) {
+                        const bool ok = !(dict_small && cand < prefix_idx_limit) && (cand + DISTANCE_MAX >= mine);
+                        if (ok) t = R.rd32(cand + bias) == seq;
+                    }
+                    return t;
+                };
+                unsigned long long hits = __ballot(test(mi));
+                bool general = false;
+                if (repeats) {
+                    const unsigned long long upto_f = f >= 63 ? ~0ull : (2ull << f) - 1ull;
+                    if (hits & upto_f) hits &= upto_f;                      // decided inside the exact prefix
+                    else {
+                        // The walk continues behind f: resolve every group exactly.  One step per hash value that
+                        // occurs more than once: its lanes learn their group.
+                        general = true;
+                        unsigned long long losers = repeats;
+                        while (losers) {
+                            const uint32_t hl = (uint32_t)__builtin_amdgcn_readlane((int)h, __builtin_ctzll(losers));
+                            const bool in_group = valid && h == hl;
+                            const unsigned long long group = __ballot(in_group);
+                            if (in_group) same = group;
+                            losers &= ~group;
+                        }
+                        const unsigned long long prev = valid ? (same & below) : 0ull;
+                        const uint32_t from_lane = (uint32_t)__shfl((int)mine, prev ? 63 - __builtin_clzll(prev) : lane);   // all lanes take part
+                        mi = prev ? from_lane : old;
+                        hits = __ballot(test(mi));
+                    }
+                }
                 const int last_insert = hits ? __builtin_ctzll(hits) : first_invalid - 1;
-                if (collisions) {
+                // the inserts of the lanes up to the stop, in order: per hash value the last of them stays
+                if (general) {
                     const unsigned long long inserting = last_insert < 0 ? 0ull : (last_insert >= 63 ? ~0ull : (2ull << last_insert) - 1ull);
-                    // of the lanes that insert, the last one per hash value leaves its position in the table
-                    if (lane <= last_insert && (same & above & inserting) == 0ull) table[h] = mine;
-                } else if (valid && lane > last_insert) table[h] = old;    // take back the inserts behind the stop
+                    if (valid && lane <= last_insert && (same & above & inserting) == 0ull) table[h] = mine;
+                } else {
+                    // hashes are distinct among the lanes up to f, except f and its group's first lane
+                    const uint32_t leader_of_f = (uint32_t)__builtin_amdgcn_readlane((int)leader, f < 64 ? f : 0);
+                    const bool shadowed = f <= last_insert && (uint32_t)lane == leader_of_f;
+                    if (valid && lane <= last_insert && !shadowed) table[h] = mine;
+                }
                 if (hits) {
                     const int e = __builtin_ctzll(hits);
                     ip = (uint32_t)__builtin_amdgcn_readlane((int)p, e);
@@ -231,16 +256,25 @@ __device__ uint32_t compress_block(Lds& L, const Ring& R, Stream& st, uint32_t n
             }
         }
         if (!found) goto last_literals;
+        // Everything that follows the search reads the ring at addresses known now: the bytes before ip and match (catch
+        // up), the literals behind the anchor, the dwords behind the four matching bytes (match length).  The loads are
+        // issued together so that they cost one LDS round trip instead of three dependent ones.  (Ring addresses wrap,
+        // so the unconditional reads are always inside the ring; what they return is only used where it is meaningful.)
+        const uint32_t fwd_ip = ip + MINMATCH, fwd_match = match + MINMATCH;
+        const uint32_t cu_a = R.byte(ip - 1u - (uint32_t)lane), cu_b = R.byte(match - 1u - (uint32_t)lane);
+        const uint32_t lit_byte = R.byte(anchor + (uint32_t)lane);
+        const uint32_t cm_a = R.rd32(fwd_ip + (uint32_t)lane * 4u), cm_b = R.rd32(fwd_match + (uint32_t)lane * 4u);
+        uint32_t caught_up = 0;
         if (immediate) { token_pos = op++; token = 0; }
         else {
-            // ---- catch up: extend the match backwards, 64 bytes per round
-            while (ip > anchor) {
+            // ---- catch up: extend the match backwards, 64 bytes per round (the first round from the loads above)
+            for (bool first = true; ip > anchor; first = false) {
                 const uint32_t d = (uint32_t)lane + 1u;
                 bool ok = (int32_t)(ip - anchor) >= (int32_t)d && (int32_t)(match - low_limit) >= (int32_t)d;
-                if (ok) ok = R.byte(ip - d) == R.byte(match - d);
+                if (ok) ok = first ? cu_a == cu_b : R.byte(ip - d) == R.byte(match - d);
                 const unsigned long long stop = __ballot(!ok);
                 const uint32_t c = stop ? (uint32_t)__builtin_ctzll(stop) : 64u;
-                ip -= c; match -= c;
+                ip -= c; match -= c; caught_up += c;
                 if (c < 64u) break;
             }
             const uint32_t lit = ip - anchor;
@@ -256,7 +290,8 @@ __device__ uint32_t compress_block(Lds& L, const Ring& R, Stream& st, uint32_t n
                 if (lane == 0) out[op] = (uint8_t)(len - n255 * 255u);
                 op++;
             } else token = lit << 4;
-            copy_out(out + op, R, anchor, lit, lane);
+            if (lit <= 64u) { if ((uint32_t)lane < lit) out[op + lane] = (uint8_t)lit_byte; }      // the usual literal run
+            else copy_out(out + op, R, anchor, lit, lane);
             op += lit;
         }
         {   const uint32_t offset = ip - match;
@@ -264,8 +299,22 @@ __device__ uint32_t compress_block(Lds& L, const Ring& R, Stream& st, uint32_t n
             op += 2;
         }
         {   // match length: the ring is flat in virtual offsets, so a match that starts in the history simply runs on
-            // into the current block
-            uint32_t match_code = count_match(R, ip + MINMATCH, match + MINMATCH, matchlimit, lane);
+            // into the current block.  The bytes caught up backwards and the first four are known to match; counting
+            // goes on behind them, the first 256 bytes from the loads above.
+            uint32_t fwd;
+            {   const uint32_t q = fwd_ip + (uint32_t)lane * 4u;
+                uint32_t avail = q < matchlimit ? matchlimit - q : 0u; if (avail > 4u) avail = 4u;
+                uint32_t same = 0;
+                if (avail) {
+                    const uint32_t x = cm_a ^ cm_b;
+                    same = x ? (uint32_t)__builtin_ctz(x) >> 3 : 4u;
+                    if (same > avail) same = avail;
+                }
+                const unsigned long long stop = __ballot(same < 4u);
+                if (stop) { const int first = __builtin_ctzll(stop); fwd = (uint32_t)first * 4u + (uint32_t)__builtin_amdgcn_readlane((int)same, first); }
+                else fwd = count_match(R, fwd_ip, fwd_match, matchlimit, lane, 256u);
+            }
+            uint32_t match_code = caught_up + fwd;
             ip += match_code + MINMATCH;
             if (op + (1 + LASTLITERALS) + (match_code + 240) / 255 > max_out) return 0;
             if (match_code >= ML_MASK) {

@@ -17,15 +17,19 @@ FLAGS = ["--genco", "--no-gpu-bundle-output", "--offload-arch=gfx950", "-O3", "-
 
 class Compiler:
     @staticmethod
-    def compile_shaders(directory, force=False):
-        built = []
+    def compile_shaders(directory, force=False, jobs=None):
+        """Compiles every shader source under `directory`; out-of-date ones are built by a few hipcc processes at once
+        (a fragment object holds a dozen kernels and takes the better part of a minute)."""
+        from concurrent.futures import ThreadPoolExecutor
+        sources = []
         for root, _dirs, files in os.walk(directory):
             for name in sorted(files):
                 if name.endswith(".vert.hip") or name.endswith(".frag.hip"):
-                    out = Compiler.compile_shader(os.path.join(root, name), force=force)
-                    if out:
-                        built.append(out)
-        return built
+                    sources.append(os.path.join(root, name))
+        jobs = jobs or max(1, min(8, (os.cpu_count() or 2) // 2, len(sources)))
+        with ThreadPoolExecutor(max_workers=max(1, jobs)) as pool:
+            built = list(pool.map(lambda path: Compiler.compile_shader(path, force=force), sources))
+        return [b for b in built if b]
 
     @staticmethod
     def compile_shader(path, force=False):

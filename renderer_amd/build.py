@@ -25,23 +25,26 @@ def build_library(force=False):
 
 
 def build_examples(force=False):
-    """The C++ host mirror's quads example (examples/quads_main_thread.cpp -> examples/quads_main_thread)."""
+    """The C++ host mirror's examples: examples/quads_main_thread.cpp (the reference's quads example call for call) and
+    examples/quads_render_thread.cpp (the same through the RenderThread proxy)."""
     root = os.path.join(HERE, "..")
-    src = os.path.join(root, "examples", "quads_main_thread.cpp")
-    exe = os.path.join(root, "examples", "quads_main_thread")
-    deps = [src, LIB, os.path.join(root, "include", "renderer_hip.h"), os.path.join(HERE, "cpp", "renderer.hpp"),
-            os.path.join(HERE, "cpp", "png_codec.hpp")]
-    if not force and os.path.exists(exe) and all(os.path.getmtime(exe) >= os.path.getmtime(d) for d in deps):
-        return exe
-    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-I", os.path.join(root, "include"), "-I", os.path.join(HERE, "cpp"),
-                           src, "-o", exe, "-L", HERE, "-lrenderer_hip", "-lz", "-Wl,-rpath,$ORIGIN/../renderer_amd"])
-    return exe
+    built = []
+    for name, extra in (("quads_main_thread", []), ("quads_render_thread", ["-pthread"])):
+        src = os.path.join(root, "examples", name + ".cpp")
+        exe = os.path.join(root, "examples", name)
+        deps = [src, LIB, os.path.join(root, "include", "renderer_hip.h")] + \
+            [os.path.join(HERE, "cpp", f) for f in os.listdir(os.path.join(HERE, "cpp"))]
+        if force or not os.path.exists(exe) or any(os.path.getmtime(exe) < os.path.getmtime(d) for d in deps):
+            subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-I", os.path.join(root, "include"), "-I", os.path.join(HERE, "cpp"),
+                                   src, "-o", exe, "-L", HERE, "-lrenderer_hip", "-lz", "-Wl,-rpath,$ORIGIN/../renderer_amd"] + extra)
+        built.append(exe)
+    return built
 
 
 def build_all(force=False):
     lib = build_library(force)
     shaders = Compiler.compile_shaders(os.path.join(HERE, "shaders"), force=force)
-    return lib, shaders + [build_examples(force)]
+    return lib, shaders + build_examples(force)
 
 
 if __name__ == "__main__":

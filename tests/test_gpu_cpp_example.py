@@ -55,3 +55,21 @@ def test_cpp_quads_example_multisampled(oracle, tmp_path):
     want = scenes.draw_oracle(scene)["color"][..., [2, 1, 0, 3]]          # the screen is BGRA
     got = np.array(Image.open(os.path.join(tmp_path, f"frame_{frames}.png")).convert("RGBA"))
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("samples", [1, 4])
+def test_cpp_render_thread_example_matches_oracle(oracle, tmp_path, samples):
+    """renderer_amd/cpp/render_thread.hpp: the quads example with every call sent as a message to the worker thread that
+    owns the Renderer (index handles for all objects); the final screen equals the oracle's frame."""
+    from PIL import Image
+    exe = os.path.join(ROOT, "examples", "quads_render_thread")
+    assert os.path.exists(exe), "examples/quads_render_thread is built by `python -m renderer_amd.build`"
+    W, H, frames = 480, 270, 45
+    out = subprocess.run([exe, os.path.join(ROOT, "renderer_amd", "shaders"), os.path.join(ROOT, "tests", "golden", "letter_f.png"),
+                          str(tmp_path), str(frames), str(W), str(H), str(samples)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    scene = scenes.example_scene(frames, width=W, height=H)
+    scene["samples"] = samples
+    want = scenes.draw_oracle(scene)["color"][..., [2, 1, 0, 3]]          # the screen is BGRA
+    got = np.array(Image.open(os.path.join(tmp_path, f"frame_{frames}.png")).convert("RGBA"))
+    assert np.array_equal(got, want)

@@ -132,7 +132,9 @@ def test_cpp_host_mirror_builds():
     """The C++ mirror of the reference API compiles against the C ABI header and links with the library."""
     import subprocess
     from renderer_amd import build
-    exe = build.build_examples()
-    assert os.path.exists(exe)
-    out = subprocess.run([exe], capture_output=True, text=True)
-    assert out.returncode == 2 and "usage" in out.stderr
+    exes = build.build_examples()
+    assert [os.path.basename(e) for e in exes] == ["quads_main_thread", "quads_render_thread"]
+    for exe in exes:
+        assert os.path.exists(exe)
+        out = subprocess.run([exe], capture_output=True, text=True)
+        assert out.returncode == 2 and "usage" in out.stderr

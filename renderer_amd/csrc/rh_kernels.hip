@@ -140,26 +140,36 @@ extern "C" __global__ __launch_bounds__(256) void rh_sort_hist(const uint32_t* k
 
 // scatter: `offsets` is the exclusive scan of hist.  Each wave owns 1024 consecutive pairs and walks them in order,
 // 64 at a time; a lane's rank among the lanes with the same digit comes from eight ballots, so equal keys keep their
-// input order (stability is what preserves primitive order inside a tile).
+// input order (stability is what preserves primitive order inside a tile).  The workgroup first sorts its 4096 pairs by
+// digit inside LDS and then writes them out in that order: the pairs of one digit leave as one contiguous run instead
+// of 4-byte writes all over the output.
 extern "C" __global__ __launch_bounds__(256) void rh_sort_scatter(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
                                                                  uint32_t n, uint32_t shift, const uint32_t* offsets, uint32_t n_blocks) {
-    __shared__ uint32_t cnt[4][256];
+    __shared__ uint32_t cnt[4][256];            // per wave and digit: count, then the next free local slot
+    __shared__ uint32_t digit_start[256];       // first local slot of each digit
+    __shared__ uint32_t global_base[256];       // where this workgroup's run of each digit starts in the output
+    __shared__ uint32_t skey[SORT_CHUNK], sval[SORT_CHUNK];
+    __shared__ uint32_t lds4[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < 4 * 256; i += WG) (&cnt[0][0])[i] = 0;
     __syncthreads();
-    const size_t wave_base = (size_t)blockIdx.x * SORT_CHUNK + (size_t)wave * (SORT_CHUNK / 4);
+    const size_t block_base = (size_t)blockIdx.x * SORT_CHUNK;
+    const size_t wave_base = block_base + (size_t)wave * (SORT_CHUNK / 4);
     // per-wave digit counts
     for (int step = 0; step < SORT_CHUNK / 4 / 64; step++) {
         size_t idx = wave_base + (size_t)step * 64 + lane;
         if (idx < n) atomicAdd(&cnt[wave][(keys_in[idx] >> shift) & 0xffu], 1u);
     }
     __syncthreads();
-    // turn counts into running bases: global offset of (digit, block) + counts of the earlier waves
+    // local layout: digits ascending, inside a digit the waves in order (= input order)
     {
         const int d = threadIdx.x;
-        uint32_t base = offsets[(size_t)d * n_blocks + blockIdx.x];
-        uint32_t c0 = cnt[0][d], c1 = cnt[1][d], c2 = cnt[2][d];
-        cnt[0][d] = base; cnt[1][d] = base + c0; cnt[2][d] = base + c0 + c1; cnt[3][d] = base + c0 + c1 + c2;
+        const uint32_t c0 = cnt[0][d], c1 = cnt[1][d], c2 = cnt[2][d], c3 = cnt[3][d];
+        uint32_t total;
+        const uint32_t start = block_exclusive_scan(c0 + c1 + c2 + c3, lds4, total);
+        digit_start[d] = start;
+        global_base[d] = offsets[(size_t)d * n_blocks + blockIdx.x];
+        cnt[0][d] = start; cnt[1][d] = start + c0; cnt[2][d] = start + c0 + c1; cnt[3][d] = start + c0 + c1 + c2;
     }
     __syncthreads();
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -176,13 +186,19 @@ extern "C" __global__ __launch_bounds__(256) void rh_sort_scatter(const uint32_t
             peers &= ((d >> b) & 1u) ? bal : ~bal;
         }
         if (valid) {
-            const uint32_t rank = (uint32_t)__popcll(peers & lt_mask);
-            const uint32_t dst = cnt[wave][d] + rank;
-            keys_out[dst] = key; vals_out[dst] = val;
+            const uint32_t slot = cnt[wave][d] + (uint32_t)__popcll(peers & lt_mask);
+            skey[slot] = key; sval[slot] = val;
         }
-        // the highest lane of every digit group advances that digit's base (reads above finish before the update:
+        // the highest lane of every digit group advances that digit's slot (reads above finish before the update:
         // same wave, program order, LDS operations complete in order)
         if (valid && (peers >> lane) == 1ull) cnt[wave][d] += (uint32_t)__popcll(peers);
+    }
+    __syncthreads();
+    const uint32_t chunk_n = (uint32_t)(n - block_base < (size_t)SORT_CHUNK ? n - block_base : (size_t)SORT_CHUNK);
+    for (uint32_t i = threadIdx.x; i < chunk_n; i += WG) {
+        const uint32_t key = skey[i], d = (key >> shift) & 0xffu;
+        const uint32_t dst = global_base[d] + (i - digit_start[d]);
+        keys_out[dst] = key; vals_out[dst] = sval[i];
     }
 }
 

@@ -470,14 +470,14 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
                 run_v = len | (total << 3) | (c1 << 10) | (c2 << 17) | (c3 << 24);
             }
             // Hits in order; k and everything read with readlane is wave-uniform and lives on the scalar unit.
-            int k = 0, s_first = 0;
+            int k = 0;
             while (k < nh) {
                 const uint32_t info = __builtin_amdgcn_readlane(info_v, k);
-                // per-lane inputs of this pass: cluster record, pixel, liveness
+                // per-lane inputs of the passes of this hit (or pack): cluster record, box, first pixel index, pixel count
                 uint32_t flags;
                 const float* rf;
-                float hx0f, hy0f, wf, idx_f;
-                bool live;
+                float hx0f, hy0f, wf, idx0_f, limit_f;
+                int npass;
                 if (info >> 31) {
                     const uint32_t run = __builtin_amdgcn_readlane(run_v, k);
                     const int c1 = (int)((run >> 10) & 127u), c2 = (int)((run >> 17) & 127u), c3 = (int)(run >> 24);
@@ -488,8 +488,9 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
                     const uint2 m = make_uint2((uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)box_v), (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)info_v));
                     hx0f = (float)(m.x & 0xffu); hy0f = (float)((m.x >> 8) & 0xffu);
                     wf = (float)(int)(((m.x >> 16) & 0xffu) - (m.x & 0xffu) + 1u);
-                    idx_f = (float)(lane - st);
-                    live = lane < (int)((run >> 3) & 127u);
+                    idx0_f = (float)(lane - st);
+                    limit_f = (float)((int)((run >> 3) & 127u) - st);         // lane < total <=> lane - st < total - st
+                    npass = 1;
                     rf = reinterpret_cast<const float*>(rec) + (int)(m.y & 0xffu) * REC_FLOATS;
                     flags = FLAG_RECT | FLAG_HAS_A | FLAG_HAS_B;
                     k += (int)(run & 7u);
@@ -497,20 +498,23 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
                     const uint32_t box = __builtin_amdgcn_readlane(box_v, k);
                     const int w = (int)((box >> 16) & 0xffu) - (int)(box & 0xffu) + 1, n = (int)((info >> 16) & 0x3ffu);
                     hx0f = (float)(box & 0xffu); hy0f = (float)((box >> 8) & 0xffu); wf = (float)w;
-                    idx_f = lane_f + (float)s_first;
-                    live = idx_f < (float)n;
+                    idx0_f = lane_f;
+                    limit_f = (float)n;
+                    npass = (n + 63) >> 6;
                     rf = reinterpret_cast<const float*>(rec) + (int)(info & 0xffu) * REC_FLOATS;
                     flags = (info >> 8) & 0x3fu;
-                    s_first += 64;
-                    if (s_first >= n) { s_first = 0; k++; }
+                    k++;
                 }
-                const float invw = __builtin_amdgcn_rcpf(wf);
+                const float invw = __builtin_amdgcn_rcpf(wf), half_invw = 0.5f * invw;
+                for (int pass = 0; pass < npass; pass++) {
+                const float idx_f = idx0_f + (float)(pass * 64);
+                const bool live = idx_f < limit_f;
                 const bool has_a = (flags & FLAG_HAS_A) != 0u, has_b = (flags & FLAG_HAS_B) != 0u;
                 const bool any_persp = (flags & (FLAG_PERSP_A | FLAG_PERSP_B)) != 0u;
                 const TriData& tri_a = *reinterpret_cast<const TriData*>(rf);
                 const TriData& tri_b = *reinterpret_cast<const TriData*>(rf + TRI_FLOATS);
                 // floor((idx + 0.5) / w): the half keeps the quotient at least 1/128 away from an integer
-                const float row_f = floorf(__builtin_fmaf(idx_f, invw, 0.5f * invw));
+                const float row_f = floorf(__builtin_fmaf(idx_f, invw, half_invw));
                 const float col_f = __builtin_fmaf(-row_f, wf, idx_f);
                 const float lxf = hx0f + col_f, lyf = hy0f + row_f;          // tile-relative pixel, exact small integers
                 // region-relative LDS index of the pixel
@@ -563,6 +567,7 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
 #pragma nounroll
                     for (int phase = 0; phase < 2; phase++) shade(phase ? cov_b : cov_a, phase != 0);
                 }
+                }       // passes of the hit
             }
         }
     }

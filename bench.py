@@ -33,12 +33,15 @@ def pmc_traffic_bytes(tag="c1"):
     rocprofv3 --pmc run for FETCH_SIZE, one for WRITE_SIZE; both counters are in KiB).  FETCH_SIZE is doubled, the
     gfx950 correction for its 64-B tally of 128-B read requests; counters cannot be collected from inside this
     process, so the figure is the profiled one and is None when no profile of the default workload is present."""
-    path = os.path.join(ROOT, "profiles", "r01", "bench_%s_v6_pmc_avg_per_launch.json" % tag)
-    try:
-        k = json.load(open(path))["rh_tile_1"]
-        return (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0
-    except (OSError, KeyError, ValueError):
-        return None
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "bench_%s_v*_pmc_avg_per_launch.json" % tag)))
+    for path in reversed(paths):               # the newest profile of this workload
+        try:
+            k = json.load(open(path))["rh_tile_1"]
+            return (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
 
 
 def main():
@@ -60,12 +63,17 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--capture-frames", type=int, default=-1,
                     help="frames of the recorded-frames/s leg (BASELINE.json configs[4] shape, per GPU); 0 skips it; "
-                         "default 256, or 128 (one round of the 128 streams) when more than two ranks share the host's /tmp")
-    ap.add_argument("--capture-streams", type=int, default=128)
+                         "default 512, or 128 when more than two ranks share the host's /tmp")
+    ap.add_argument("--capture-streams", type=int, default=-1,
+                    help="stream files per GPU; default 256 (the LZ4 kernel holds one stream per compute unit at a time: "
+                         "a round of up to 256 streams takes as long as a round of one), or 128 with more than two ranks")
     args = ap.parse_args()
 
+    few_ranks = max(args.gpus, int(os.environ.get("WORLD_SIZE", "1"))) <= 2
     if args.capture_frames < 0:
-        args.capture_frames = 256 if max(args.gpus, int(os.environ.get("WORLD_SIZE", "1"))) <= 2 else 128
+        args.capture_frames = 512 if few_ranks else 128
+    if args.capture_streams < 0:
+        args.capture_streams = 256 if few_ranks else 128
     default_workload = (args.workload, args.quads, args.side, args.width, args.height) == ("c1", 1_000_000, 16, 3840, 2160)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

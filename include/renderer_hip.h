@@ -61,7 +61,8 @@ enum {
     RH_OPTION_STRIP_ROW1 = 3,         /* only pixel rows [ROW0, ROW1) (multiples of 32, or the target height); clears
                                          included.  ROW1 = 0 (default) disables the restriction. */
     RH_OPTION_GENERAL_KERNELS = 4,    /* 1: always run the kernel body that reads blend factors, texture formats and
-                                         filters at run time instead of the body specialised for the pipeline's state
+                                         filters at run time instead of the body specialised for the pipeline's state,
+                                         and the prefix-sum form that serves any length instead of the short forms
                                          (identical results; for testing); default 0 */
 };
 

@@ -70,13 +70,14 @@ struct rh_device {
     int general_kernels = 0;                       // RH_OPTION_GENERAL_KERNELS
     std::string name;
     // scratch for binning
-    Scratch ranges, block_sums, chunk_tmp, keys_a, vals_a, keys_b, vals_b, hist, tile_start, tile_end;
+    Scratch ranges, block_sums, chunk_tmp, keys_a, vals_a, keys_b, vals_b, hist, tile_start;
     Scratch png_slots, png_rows, png_out;          // GPU PNG encoder scratch
     void* png_host = nullptr; size_t png_host_cap = 0;   // pinned
     unsigned long long* d_total = nullptr;
     unsigned long long* h_total = nullptr;      // pinned
     // allocation caches (exact-size reuse; capture buffers come and go every frame)
     std::multimap<size_t, void*> free_device, free_pinned;
+    size_t free_device_bytes = 0, free_pinned_bytes = 0;
     std::vector<rh_buffer*> pending_maps;
     rh_pass_stats stats{};
     // optional per-pass HIP-event timing
@@ -156,28 +157,39 @@ struct rh_cmdbuf { rh_device* dev = nullptr; std::vector<Cmd> cmds; };
 // ---- allocation caches ------------------------------------------------------------------------------------------------
 namespace {
 
+constexpr size_t RH_CACHE_MAX_BLOCKS = 4096;
+constexpr size_t RH_DEVICE_CACHE_MAX_BYTES = (size_t)48 << 30;      // of 288 GB
+constexpr size_t RH_PINNED_CACHE_MAX_BYTES = (size_t)8 << 30;
+
 void device_retain(rh_device* dev) { dev->refs.fetch_add(1); }
 void device_release(rh_device* dev);
 
 int device_alloc(rh_device* dev, size_t size, void** out) {
     auto it = dev->free_device.find(size);
-    if (it != dev->free_device.end()) { *out = it->second; dev->free_device.erase(it); return 0; }
+    if (it != dev->free_device.end()) { *out = it->second; dev->free_device.erase(it); dev->free_device_bytes -= size; return 0; }
     RH_HIP(hipMalloc(out, size ? size : 1));
     return 0;
 }
 void device_free(rh_device* dev, size_t size, void* p) {
     if (!p) return;
-    if (dev->free_device.size() < 64) dev->free_device.emplace(size, p); else (void)hipFree(p);
+    // Freed blocks wait for the next request of the same size (hipFree waits for the whole device and hipMalloc of a 4K
+    // frame takes about a millisecond: a recording run with hundreds of capture buffers in flight would pay both per
+    // frame).  The cache is bounded in blocks and in bytes.
+    if (dev->free_device.size() < RH_CACHE_MAX_BLOCKS && dev->free_device_bytes + size <= RH_DEVICE_CACHE_MAX_BYTES) {
+        dev->free_device.emplace(size, p); dev->free_device_bytes += size;
+    } else (void)hipFree(p);
 }
 int pinned_alloc(rh_device* dev, size_t size, void** out) {
     auto it = dev->free_pinned.find(size);
-    if (it != dev->free_pinned.end()) { *out = it->second; dev->free_pinned.erase(it); return 0; }
+    if (it != dev->free_pinned.end()) { *out = it->second; dev->free_pinned.erase(it); dev->free_pinned_bytes -= size; return 0; }
     RH_HIP(hipHostMalloc(out, size ? size : 1, hipHostMallocDefault));
     return 0;
 }
 void pinned_free(rh_device* dev, size_t size, void* p) {
     if (!p) return;
-    if (dev->free_pinned.size() < 64) dev->free_pinned.emplace(size, p); else (void)hipHostFree(p);
+    if (dev->free_pinned.size() < RH_CACHE_MAX_BLOCKS && dev->free_pinned_bytes + size <= RH_PINNED_CACHE_MAX_BYTES) {
+        dev->free_pinned.emplace(size, p); dev->free_pinned_bytes += size;
+    } else (void)hipHostFree(p);
 }
 
 int set_device(rh_device* dev) { RH_HIP(hipSetDevice(dev->ordinal)); return 0; }
@@ -242,7 +254,7 @@ void device_release(rh_device* dev) {
     (void)hipSetDevice(dev->ordinal);
     (void)hipStreamSynchronize(dev->stream);
     Scratch* all[] = { &dev->ranges, &dev->block_sums, &dev->chunk_tmp, &dev->keys_a, &dev->vals_a, &dev->keys_b, &dev->vals_b,
-                       &dev->hist, &dev->tile_start, &dev->tile_end, &dev->png_slots, &dev->png_rows, &dev->png_out };
+                       &dev->hist, &dev->tile_start, &dev->png_slots, &dev->png_rows, &dev->png_out };
     for (Scratch* s : all) s->release();
     for (hipEvent_t e : dev->event_pool) (void)hipEventDestroy(e);
     for (hipEvent_t e : dev->timing_events) (void)hipEventDestroy(e);
@@ -751,7 +763,8 @@ int execute_pass(rh_device* dev, const PassCmd& c) {
     const uint32_t n_clusters = empty_scissor ? 0u : p.n_clusters;
 
     hipStream_t s = dev->stream;
-    if (dev->tile_start.ensure((size_t)n_tiles * 4) || dev->tile_end.ensure((size_t)n_tiles * 4)) return 1;
+    if (dev->tile_start.ensure((size_t)n_tiles * 8)) return 1;                    // [start of every tile | end of every tile]
+    uint32_t* const tile_start = dev->tile_start.as<uint32_t>(); uint32_t* const tile_end = tile_start + n_tiles;
     uint64_t total = 0;
     uint32_t* sorted_vals = nullptr;
     if (timing_mark(dev)) return 1;
@@ -763,7 +776,7 @@ int execute_pass(rh_device* dev, const PassCmd& c) {
         ba.p = p; ba.p.n_clusters = n_clusters;
         ba.ranges = dev->ranges.as<rh_tile_range>(); ba.block_sums = dev->block_sums.as<uint32_t>();
         if (launch_module_kernel(pl->vs->bin_count, n_blocks, &ba, sizeof ba, s)) return 1;
-        rhk::exclusive_scan(dev->block_sums.as<uint32_t>(), n_blocks, dev->chunk_tmp.as<uint32_t>(), dev->d_total, s);
+        rhk::exclusive_scan(dev->block_sums.as<uint32_t>(), n_blocks, dev->chunk_tmp.as<uint32_t>(), dev->d_total, s, dev->general_kernels != 0);
         RH_HIP(hipMemcpyAsync(dev->h_total, dev->d_total, 8, hipMemcpyDeviceToHost, s));
         RH_HIP(hipStreamSynchronize(s));
         total = *dev->h_total;
@@ -776,21 +789,20 @@ int execute_pass(rh_device* dev, const PassCmd& c) {
             rhk::bin_emit(dev->ranges.as<rh_tile_range>(), n_clusters, p.tiles_x, dev->block_sums.as<uint32_t>(),
                           dev->keys_a.as<uint32_t>(), dev->vals_a.as<uint32_t>(), s);
             int where = rhk::radix_sort_pairs(dev->keys_a.as<uint32_t>(), dev->vals_a.as<uint32_t>(), dev->keys_b.as<uint32_t>(), dev->vals_b.as<uint32_t>(),
-                                              n, bits_for(n_tiles), dev->hist.as<uint32_t>(), dev->chunk_tmp.as<uint32_t>(), s);
+                                              n, bits_for(n_tiles), dev->hist.as<uint32_t>(), dev->chunk_tmp.as<uint32_t>(), s, dev->general_kernels != 0);
             uint32_t* sorted_keys = where ? dev->keys_b.as<uint32_t>() : dev->keys_a.as<uint32_t>();
             sorted_vals = where ? dev->vals_b.as<uint32_t>() : dev->vals_a.as<uint32_t>();
-            rhk::tile_ranges(sorted_keys, n, dev->tile_start.as<uint32_t>(), dev->tile_end.as<uint32_t>(), n_tiles, s);
+            rhk::tile_ranges(sorted_keys, n, tile_start, tile_end, n_tiles, s);
         }
     }
     if (total == 0) {
-        RH_HIP(hipMemsetAsync(dev->tile_start.ptr, 0, (size_t)n_tiles * 4, s));
-        RH_HIP(hipMemsetAsync(dev->tile_end.ptr, 0, (size_t)n_tiles * 4, s));
+        RH_HIP(hipMemsetAsync(tile_start, 0, (size_t)n_tiles * 8, s));
     }
 
     rh_tile_args ta;
     memset(&ta, 0, sizeof ta);
     ta.p = p; ta.p.n_clusters = n_clusters;
-    ta.list = sorted_vals; ta.tile_start = dev->tile_start.as<uint32_t>(); ta.tile_end = dev->tile_end.as<uint32_t>();
+    ta.list = sorted_vals; ta.tile_start = tile_start; ta.tile_end = tile_end;
     ta.n_att = (uint32_t)c.attachments.size();
     bool any_clear = false;
     for (size_t i = 0; i < c.attachments.size(); i++) {

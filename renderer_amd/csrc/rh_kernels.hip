@@ -10,6 +10,7 @@ namespace {
 constexpr int WG = 256;
 constexpr int SCAN_ITEMS = 16;                 // items per thread in the chunked scan
 constexpr int SCAN_CHUNK = WG * SCAN_ITEMS;    // 4096
+constexpr uint32_t SCAN_FUSED_CHUNKS = 2048;   // up to 8 M items: the apply phase adds up the chunk sums before its own itself
 constexpr int SORT_ITEMS = 16;
 constexpr int SORT_CHUNK = WG * SORT_ITEMS;    // 4096 pairs per workgroup, 1024 per wave
 
@@ -37,7 +38,7 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* l
 
 } // namespace
 
-// ---- chunked exclusive scan (in place), three launches for any n -------------------------------------------------------
+// ---- chunked exclusive scan (in place): one launch for one chunk, two up to SCAN_FUSED_CHUNKS chunks, else three ----------
 // phase 1: per-chunk sums
 extern "C" __global__ __launch_bounds__(256) void rh_scan_reduce(const uint32_t* data, uint32_t n, uint32_t* chunk_sums) {
     __shared__ uint32_t lds4[4];
@@ -69,16 +70,31 @@ extern "C" __global__ __launch_bounds__(256) void rh_scan_chunks(uint32_t* chunk
     if (threadIdx.x == 0 && total_out) *total_out = running;
 }
 
-// phase 3: per-chunk exclusive scan plus the chunk's base
-extern "C" __global__ __launch_bounds__(256) void rh_scan_apply(uint32_t* data, uint32_t n, const uint32_t* chunk_bases) {
+// phase 3: per-chunk exclusive scan plus the chunk's base.  With `fused` the chunk array still holds the raw sums of
+// phase 1 and every workgroup adds up the sums of the chunks before its own (a few loads per thread for the chunk
+// counts this is used with), which saves the single-workgroup launch of phase 2; the last workgroup writes the grand
+// total.  A one-chunk scan needs no phase 1 either: its base is zero.
+extern "C" __global__ __launch_bounds__(256) void rh_scan_apply(uint32_t* data, uint32_t n, const uint32_t* chunk_bases, uint32_t fused,
+                                                               unsigned long long* total_out) {
     __shared__ uint32_t lds4[4];
+    __shared__ unsigned long long before[4];
     const size_t base = (size_t)blockIdx.x * SCAN_CHUNK + (size_t)threadIdx.x * SCAN_ITEMS;
     uint32_t v[SCAN_ITEMS];
     uint32_t s = 0;
 #pragma unroll
     for (int i = 0; i < SCAN_ITEMS; i++) { v[i] = (base + i < n) ? data[base + i] : 0u; s += v[i]; }
+    unsigned long long chunk_base = 0;
+    if (fused) {
+        unsigned long long part = 0;
+        for (uint32_t i = threadIdx.x; i < blockIdx.x; i += WG) part += chunk_bases[i];
+        for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off);
+        if ((threadIdx.x & 63) == 0) before[threadIdx.x >> 6] = part;
+        __syncthreads();
+        chunk_base = before[0] + before[1] + before[2] + before[3];
+    } else chunk_base = chunk_bases[blockIdx.x];
     uint32_t total;
-    uint32_t ex = block_exclusive_scan(s, lds4, total) + chunk_bases[blockIdx.x];
+    uint32_t ex = block_exclusive_scan(s, lds4, total) + (uint32_t)chunk_base;
+    if (fused && total_out && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total_out = chunk_base + total;
 #pragma unroll
     for (int i = 0; i < SCAN_ITEMS; i++) { if (base + i < n) data[base + i] = ex; ex += v[i]; }
 }
@@ -239,12 +255,17 @@ uint32_t scan_chunks_for(uint32_t n) { return div_up(n, SCAN_CHUNK); }
 uint32_t sort_blocks_for(uint32_t n) { return div_up(n, SORT_CHUNK); }
 
 // In-place exclusive scan of data[0..n); chunk_tmp needs scan_chunks_for(n) words.
-void exclusive_scan(uint32_t* data, uint32_t n, uint32_t* chunk_tmp, unsigned long long* total_out, hipStream_t s) {
+void exclusive_scan(uint32_t* data, uint32_t n, uint32_t* chunk_tmp, unsigned long long* total_out, hipStream_t s, bool general) {
     if (n == 0) { if (total_out) (void)hipMemsetAsync(total_out, 0, sizeof(unsigned long long), s); return; }
     const uint32_t chunks = scan_chunks_for(n);
+    if (chunks <= SCAN_FUSED_CHUNKS && !general) {
+        if (chunks > 1) hipLaunchKernelGGL(rh_scan_reduce, dim3(chunks), dim3(WG), 0, s, data, n, chunk_tmp);
+        hipLaunchKernelGGL(rh_scan_apply, dim3(chunks), dim3(WG), 0, s, data, n, chunk_tmp, 1u, total_out);
+        return;
+    }
     hipLaunchKernelGGL(rh_scan_reduce, dim3(chunks), dim3(WG), 0, s, data, n, chunk_tmp);
     hipLaunchKernelGGL(rh_scan_chunks, dim3(1), dim3(WG), 0, s, chunk_tmp, chunks, total_out);
-    hipLaunchKernelGGL(rh_scan_apply, dim3(chunks), dim3(WG), 0, s, data, n, chunk_tmp);
+    hipLaunchKernelGGL(rh_scan_apply, dim3(chunks), dim3(WG), 0, s, data, n, chunk_tmp, 0u, (unsigned long long*)nullptr);
 }
 
 void bin_emit(const rh_tile_range* ranges, uint32_t n_clusters, uint32_t tiles_x, const uint32_t* block_bases,
@@ -257,7 +278,7 @@ void bin_emit(const rh_tile_range* ranges, uint32_t n_clusters, uint32_t tiles_x
 // (keys_a, vals_a) and 1 when it is in (keys_b, vals_b).  hist needs 256 * sort_blocks_for(n) words, chunk_tmp
 // scan_chunks_for(256 * sort_blocks_for(n)) words.
 int radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, uint32_t n, uint32_t key_bits,
-                     uint32_t* hist, uint32_t* chunk_tmp, hipStream_t s) {
+                     uint32_t* hist, uint32_t* chunk_tmp, hipStream_t s, bool general) {
     if (n == 0) return 0;
     const uint32_t blocks = sort_blocks_for(n);
     int cur = 0;
@@ -265,16 +286,16 @@ int radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint3
         uint32_t* ki = cur ? keys_b : keys_a; uint32_t* vi = cur ? vals_b : vals_a;
         uint32_t* ko = cur ? keys_a : keys_b; uint32_t* vo = cur ? vals_a : vals_b;
         hipLaunchKernelGGL(rh_sort_hist, dim3(blocks), dim3(WG), 0, s, ki, n, shift, hist, blocks);
-        exclusive_scan(hist, 256u * blocks, chunk_tmp, nullptr, s);
+        exclusive_scan(hist, 256u * blocks, chunk_tmp, nullptr, s, general);
         hipLaunchKernelGGL(rh_sort_scatter, dim3(blocks), dim3(WG), 0, s, ki, vi, ko, vo, n, shift, hist, blocks);
         cur ^= 1;
     }
     return cur;
 }
 
+// tile_end must be tile_start + n_tiles (one allocation, cleared by one fill).
 void tile_ranges(const uint32_t* keys, uint32_t n, uint32_t* tile_start, uint32_t* tile_end, uint32_t n_tiles, hipStream_t s) {
-    (void)hipMemsetAsync(tile_start, 0, (size_t)n_tiles * 4, s);
-    (void)hipMemsetAsync(tile_end, 0, (size_t)n_tiles * 4, s);
+    (void)hipMemsetAsync(tile_start, 0, (size_t)n_tiles * 8, s);
     if (n == 0) return;
     hipLaunchKernelGGL(rh_tile_ranges, dim3(div_up(n, WG)), dim3(WG), 0, s, keys, n, tile_start, tile_end);
 }

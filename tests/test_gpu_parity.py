@@ -155,6 +155,21 @@ def test_general_and_specialised_kernel_bodies_agree(oracle):
         assert_same(got, want, f"general={general}")
 
 
+def test_short_and_general_prefix_sums_agree(oracle):
+    """Enough (tile, quad) pairs that the sort's histogram scan spans several chunks: the two-launch form (chunk bases
+    summed inside the apply phase) and the three-launch form that serves any length order the quads identically."""
+    scene = scenes.tiny_quads_scene(300000, 1024, 512, seed=31, lo=2, hi=6)
+    scene["blend"] = "premultiplied"          # the result depends on the order of every overlapping pair
+    want = scenes.draw_oracle(scene)["color"]
+    for general in (False, True):
+        hs = scenes.HipScene(scene)
+        hs.renderer.set_general_kernels(general)
+        hs.draw()
+        got = hs.read_color()
+        hs.close()
+        assert_same(got, want, f"general={general}")
+
+
 @pytest.mark.parametrize("fmt", ["r_u8", "bgra_u8"])
 @pytest.mark.parametrize("filter", ["linear", "nearest"])
 def test_other_texture_formats(oracle, fmt, filter):

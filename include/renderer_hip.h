@@ -255,7 +255,9 @@ int rh_compressor_read(rh_compressor* c, uint32_t stream, void* dst, size_t cap,
 /* Zero-copy form of rh_compressor_read: *ptr / *len describe the first ready run of bytes of `stream` (pinned host
  * memory owned by the compressor, NULL / 0 when nothing is ready); rh_compressor_consume releases the first n ready
  * bytes.  A run stays valid until it is consumed; runs of different streams may be written out from different threads,
- * peek and consume themselves are called from the compressor's thread. */
+ * peek and consume themselves are called from one thread at a time, which may be another thread than the one that
+ * queues packets with rh_compressor_write_packet meanwhile (they share no state); every other call on the compressor
+ * (submit, flush, finish_stream, destroy) must wait until that thread is done. */
 int rh_compressor_peek(rh_compressor* c, uint32_t stream, const uint8_t** ptr, size_t* len);
 int rh_compressor_consume(rh_compressor* c, uint32_t stream, size_t n);
 /* Flushes and appends the LZ4F end mark to `stream` (LZ4F_compressEnd, when the reference drops the writer). */

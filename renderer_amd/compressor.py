@@ -43,6 +43,8 @@ class Compressor:
         self.raw_video_size = 0
         self.compressed_size = 0
         self._pool = None
+        self._background = None     # one thread that appends finished rounds to the files beside the render thread
+        self._draining = None
 
     def compress_to_disk(self, video_frame):
         stream = (video_frame.frame_number - 1) % self.n_streams
@@ -68,15 +70,28 @@ class Compressor:
         """Hands the queued packets to the GPU (streams run concurrently there) and, while they are being compressed,
         appends the bytes of the previous hand-off to the files -- the reference's worker threads do both beside the
         render thread (src/compressor.rs:100-131)."""
+        self._join_drain()
         _ffi.check(_ffi.lib().rh_compressor_submit(self.handle))
         self._release_queued()          # the library keeps the capture buffers alive until they are compressed
-        self._drain()
+        # The file writes go to a background thread: until the next hand-off this thread only queues packets
+        # (rh_compressor_write_packet), which touches none of the state that peek/consume use.
+        if self._background is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._background = ThreadPoolExecutor(max_workers=1)
+        self._draining = self._background.submit(self._drain)
 
     def flush(self):
         """Compresses all queued packets, waits for them and appends the bytes to the files."""
+        self._join_drain()
         _ffi.check(_ffi.lib().rh_compressor_flush(self.handle))
         self._release_queued()
         self._drain()
+
+    def _join_drain(self):
+        """Waits for the background file writes of the previous hand-off (and re-raises what they raised)."""
+        if self._draining is not None:
+            pending, self._draining = self._draining, None
+            pending.result()
 
     def _drain(self):
         """Writes every ready byte to its stream file straight from the library's pinned memory; the files are written
@@ -131,6 +146,9 @@ class Compressor:
         if self._pool is not None:
             self._pool.shutdown()
             self._pool = None
+        if self._background is not None:
+            self._background.shutdown()
+            self._background = None
         _ffi.lib().rh_compressor_destroy(self.handle)
         self.handle = None
 

@@ -913,6 +913,7 @@ struct rh_compressor {
     rh_device* dev = nullptr;
     uint32_t n_streams = 0;
     hipStream_t stream = nullptr;                    // compression runs beside rendering
+    hipStream_t copy_stream = nullptr;               // brings a finished round's bytes back while the next round is compressed
     hipEvent_t frames_ready = nullptr;               // recorded on the device's stream when a round is submitted
     rh_lz4_stream_state* d_states = nullptr;
     struct Packet { std::vector<uint8_t> meta; rh_buffer* image = nullptr; };
@@ -923,12 +924,16 @@ struct rh_compressor {
     std::vector<std::deque<Segment>> ready;          // per stream: compressed bytes not yet consumed
     // the round in flight
     struct Round {
-        bool active = false;
+        bool active = false;                         // its kernel has been launched and its bytes not yet collected
+        bool waited = false;                         // its kernel has finished: `lens` is valid, the images are released
+        int out_buf = 0;                             // which of the two output areas it writes
         std::vector<uint32_t> job_stream;
         std::vector<size_t> out_off, out_cap;
+        std::vector<unsigned long long> lens;
         std::vector<rh_buffer*> images;
     } round;
-    Scratch d_jobs, d_stage, d_out, d_lens;
+    Scratch d_jobs, d_stage, d_out[2], d_lens;       // two output areas: round k+1 is compressed while round k's bytes are copied out
+    int out_sel = 0;
     unsigned long long* h_lens = nullptr; size_t h_lens_cap = 0;
 };
 
@@ -973,7 +978,9 @@ int compressor_submit_round(rh_compressor* c) {
     }
     const uint32_t n = (uint32_t)R.job_stream.size();
     if (n == 0) return 0;
-    if (c->d_jobs.ensure(n * sizeof(rh_lz4_job)) || c->d_stage.ensure(stage.size()) || c->d_out.ensure(out_total) || c->d_lens.ensure(n * 8)) return 1;
+    R.out_buf = c->out_sel; c->out_sel ^= 1;
+    Scratch& d_out = c->d_out[R.out_buf];
+    if (c->d_jobs.ensure(n * sizeof(rh_lz4_job)) || c->d_stage.ensure(stage.size()) || d_out.ensure(out_total) || c->d_lens.ensure(n * 8)) return 1;
     if (n > c->h_lens_cap) {
         if (c->h_lens) (void)hipHostFree(c->h_lens);
         c->h_lens = nullptr; c->h_lens_cap = 0;
@@ -992,7 +999,7 @@ int compressor_submit_round(rh_compressor* c) {
         jb.write_ptr[2] = st + 32; jb.write_len[2] = pk.meta.size();
         jb.n_writes = 3;
         if (pk.image) { jb.write_ptr[3] = (const uint8_t*)pk.image->dptr; jb.write_len[3] = pk.image->size; jb.n_writes = 4; }
-        jb.out = c->d_out.as<uint8_t>() + R.out_off[j];
+        jb.out = d_out.as<uint8_t>() + R.out_off[j];
         jb.out_len = c->d_lens.as<unsigned long long>() + j;
         R.images.push_back(pk.image);                 // stays retained until the round completes
         c->queue[R.job_stream[j]].pop_front();
@@ -1006,22 +1013,34 @@ int compressor_submit_round(rh_compressor* c) {
     int rc = rhk::lz4f_compress_launch(c->d_jobs.as<rh_lz4_job>(), n, c->d_states, c->stream);
     if (rc) return fail("rh_compressor: kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
     RH_HIP(hipMemcpyAsync(c->h_lens, c->d_lens.ptr, n * 8, hipMemcpyDeviceToHost, c->stream));
-    R.active = true;
+    R.active = true; R.waited = false;
     return 0;
 }
 
-// Waits for the round in flight and brings exactly its compressed bytes to the host (only they cross PCIe).
-int compressor_complete_round(rh_compressor* c) {
+// Waits for the kernel of the round in flight: its compressed sizes are known and its capture buffers are free again.
+int compressor_wait_round(rh_compressor* c) {
     rh_compressor::Round& R = c->round;
+    if (!R.active || R.waited) return 0;
+    const uint32_t n = (uint32_t)R.job_stream.size();
+    RH_HIP(hipStreamSynchronize(c->stream));
+    R.waited = true;
+    R.lens.assign(c->h_lens, c->h_lens + n);
+    for (uint32_t j = 0; j < n; j++) {
+        if (R.images[j]) rh_buffer_release(R.images[j]);
+        if (R.lens[j] > R.out_cap[j]) return fail("rh_compressor: stream %u overflowed its output area", R.job_stream[j]);
+    }
+    R.images.clear();
+    return 0;
+}
+
+// Brings exactly the compressed bytes of a finished round to the host (only they cross PCIe), on the copy stream, so
+// that a round launched meanwhile keeps compressing.
+int compressor_collect_round(rh_compressor* c, rh_compressor::Round& R) {
     if (!R.active) return 0;
     R.active = false;
     const uint32_t n = (uint32_t)R.job_stream.size();
-    RH_HIP(hipStreamSynchronize(c->stream));
     size_t total = 0;
-    for (uint32_t j = 0; j < n; j++) {
-        if (c->h_lens[j] > R.out_cap[j]) return fail("rh_compressor: stream %u overflowed its output area", R.job_stream[j]);
-        total += c->h_lens[j];
-    }
+    for (uint32_t j = 0; j < n; j++) total += (size_t)R.lens[j];
     int bi = -1;
     for (size_t i = 0; i < c->bufs.size(); i++) if (c->bufs[i].live == 0 && c->bufs[i].cap >= total) { bi = (int)i; break; }
     if (bi < 0) {
@@ -1037,24 +1056,27 @@ int compressor_complete_round(rh_compressor* c) {
     rh_compressor::RoundBuf& b = c->bufs[bi];
     size_t off = 0;
     for (uint32_t j = 0; j < n; j++) {
-        const size_t len = (size_t)c->h_lens[j];
-        if (len) RH_HIP(hipMemcpyAsync((uint8_t*)b.h + off, c->d_out.as<uint8_t>() + R.out_off[j], len, hipMemcpyDeviceToHost, c->stream));
+        const size_t len = (size_t)R.lens[j];
+        if (len) RH_HIP(hipMemcpyAsync((uint8_t*)b.h + off, c->d_out[R.out_buf].as<uint8_t>() + R.out_off[j], len, hipMemcpyDeviceToHost, c->copy_stream));
         off += len;
     }
-    RH_HIP(hipStreamSynchronize(c->stream));
+    RH_HIP(hipStreamSynchronize(c->copy_stream));
     off = 0;
     for (uint32_t j = 0; j < n; j++) {
-        const size_t len = (size_t)c->h_lens[j];
+        const size_t len = (size_t)R.lens[j];
         if (len) {
             rh_compressor::Segment sg; sg.ptr = (const uint8_t*)b.h + off; sg.len = len; sg.buf = bi;
             c->ready[R.job_stream[j]].push_back(std::move(sg));
             b.live++;
         }
         off += len;
-        if (R.images[j]) rh_buffer_release(R.images[j]);
     }
-    R.images.clear();
     return 0;
+}
+
+int compressor_complete_round(rh_compressor* c) {
+    if (compressor_wait_round(c)) return 1;
+    return compressor_collect_round(c, c->round);
 }
 
 bool compressor_queue_empty(const rh_compressor* c) {
@@ -1076,10 +1098,18 @@ int rh_compressor_create(rh_device* dev, uint32_t n_streams, int level, rh_compr
     if (e == hipSuccess) e = hipMemsetAsync(c->d_states, 0, (size_t)n_streams * sizeof(rh_lz4_stream_state), dev->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(dev->stream);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    // A stream of another priority gets a hardware queue of its own: with the few queues a process has, a second
+    // stream of the same priority can land on the queue of the compression stream, behind a kernel that runs a second.
+    if (e == hipSuccess) {
+        int least = 0, greatest = 0;
+        e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->copy_stream, hipStreamNonBlocking, greatest);
+    }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->frames_ready, hipEventDisableTiming);
     if (e != hipSuccess) {
         if (c->frames_ready) (void)hipEventDestroy(c->frames_ready);
         if (c->stream) (void)hipStreamDestroy(c->stream);
+        if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
         if (c->d_states) (void)hipFree(c->d_states);
         delete c;
         return fail("rh_compressor_create: %s", hipGetErrorString(e));
@@ -1101,13 +1131,15 @@ void rh_compressor_destroy(rh_compressor* c) {
     (void)hipStreamSynchronize(dev->stream);
     for (auto& q : c->queue) for (auto& pk : q) if (pk.image) rh_buffer_release(pk.image);
     for (rh_buffer* b : c->round.images) if (b) rh_buffer_release(b);
-    Scratch* all[] = { &c->d_jobs, &c->d_stage, &c->d_out, &c->d_lens };
+    (void)hipStreamSynchronize(c->copy_stream);
+    Scratch* all[] = { &c->d_jobs, &c->d_stage, &c->d_out[0], &c->d_out[1], &c->d_lens };
     for (Scratch* s : all) s->release();
     for (auto& b : c->bufs) if (b.h) (void)hipHostFree(b.h);
     if (c->h_lens) (void)hipHostFree(c->h_lens);
     if (c->d_states) (void)hipFree(c->d_states);
     (void)hipEventDestroy(c->frames_ready);
     (void)hipStreamDestroy(c->stream);
+    (void)hipStreamDestroy(c->copy_stream);
     delete c;
     device_release(dev);
 }
@@ -1128,9 +1160,13 @@ int rh_compressor_submit(rh_compressor* c) {
     if (!c) return fail("rh_compressor_submit: null compressor");
     if (set_device(c->dev)) return 1;
     for (;;) {
-        if (compressor_complete_round(c)) return 1;
-        if (compressor_queue_empty(c)) return 0;
+        if (compressor_wait_round(c)) return 1;
+        if (compressor_queue_empty(c)) return compressor_collect_round(c, c->round);
+        // the next round starts before the finished one's bytes are copied out (it writes the other output area)
+        rh_compressor::Round prev = std::move(c->round);
+        c->round = rh_compressor::Round();
         if (compressor_submit_round(c)) return 1;
+        if (compressor_collect_round(c, prev)) return 1;
         if (compressor_queue_empty(c)) return 0;      // the last round stays in flight
     }
 }

@@ -19,9 +19,11 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def run_capture(frames=128, streams=64, quads=100_000, side=32, width=3840, height=2160, out="/tmp/rh_cap", hip_ordinal=0,
-                seed=4, before_timing=None, after_timing=None):
+                seed=4, before_timing=None, after_timing=None, warmup=None):
     """Renders and records `frames` frames; returns (elapsed seconds, info dict, last recorded image).  `before_timing`
-    and `after_timing` are called around the timed loop (multi-process runs put their barriers there)."""
+    and `after_timing` are called around the timed loop (multi-process runs put their barriers there).  `warmup` untimed
+    frames come first, by default two rounds of the streams: the compressor pins one host buffer per round in flight
+    (about a second per 8 GB, once) and recycles them afterwards."""
     import numpy as np
     import scenes
     from renderer_amd import Compressor, Renderer
@@ -57,10 +59,13 @@ def run_capture(frames=128, streams=64, quads=100_000, side=32, width=3840, heig
         r.render(hs.pipeline, hs.clear, hs.viewport, hs.count)
         r.finish_frame()
 
-    for _ in range(2):
+    for _ in range(2 * streams if warmup is None else warmup):
         step()
     comp.flush()
     r.synchronize()
+    for f in comp.files:                 # the warm-up's bytes are not kept (nothing here reads the files back)
+        f.truncate(0)
+        f.seek(0)
     t_compress[0] = 0.0
     raw0, packed0 = comp.raw_video_size, comp.compressed_size
 
@@ -99,11 +104,13 @@ def main():
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--out", default="/tmp/rh_cap")
+    ap.add_argument("--warmup", type=int, default=-1, help="untimed frames before the timed ones (default: two rounds of the streams)")
     ap.add_argument("--cpu-frames", type=int, default=4, help="frames compressed by liblz4 on one host core for the baseline")
     args = ap.parse_args()
 
     import numpy as np
-    elapsed, info, last = run_capture(args.frames, args.streams, args.quads, args.side, args.width, args.height, args.out)
+    elapsed, info, last = run_capture(args.frames, args.streams, args.quads, args.side, args.width, args.height, args.out,
+                                      warmup=None if args.warmup < 0 else args.warmup)
     out = {"metric": "recorded frames/s", "value": args.frames / elapsed, "unit": "frames/s", "n_gpus": 1,
            "frames": args.frames, "streams": args.streams, "config": {"workload": info["workload"]},
            "ms_per_frame": elapsed / args.frames * 1e3, "compress_ms_per_frame": info["compress_ms_per_frame"],

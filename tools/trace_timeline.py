@@ -18,3 +18,12 @@ for a,bb in lz:
 names=collections.Counter()
 for r in rows: names[r['Kernel_Name'][:40]]+=int(r['End_Timestamp'])-int(r['Start_Timestamp'])
 print({k:round(v/1e6) for k,v in names.most_common(8)})
+mc=glob.glob(sys.argv[1]+'/*/*memory_copy_trace.csv')
+if mc:
+    cr=list(csv.DictReader(open(mc[0])))
+    big=[(int(r['Start_Timestamp'])-t0,int(r['End_Timestamp'])-t0,r.get('Direction','')) for r in cr if int(r['End_Timestamp'])-int(r['Start_Timestamp'])>2e5]
+    b2=collections.Counter(int(a/1e8) for a,_,_ in big)
+    print('long copies (>0.2 ms) per 100ms:',[b2[i] for i in range(max(b2)+1)] if b2 else [])
+    tot=collections.Counter()
+    for a,b,d in big: tot[d]+=b-a
+    print({k:round(v/1e6) for k,v in tot.items()})

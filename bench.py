@@ -152,7 +152,9 @@ def main():
         try:
             cap_s, cap_info, _ = bench_capture.run_capture(
                 frames=args.capture_frames, streams=args.capture_streams, out=f"/tmp/rh_bench_capture_{os.getpid()}_{rank}",
-                hip_ordinal=local_rank, seed=4 + rank)
+                hip_ordinal=local_rank, seed=4 + rank,
+                # untimed rounds first (the compressor pins its host buffers in them); one when many ranks share /tmp
+                warmup=(2 if few_ranks else 1) * args.capture_streams)
         except Exception as e:                   # e.g. no room for the stream files: report it, keep the quads/s line
             cap_error = f"rank {rank}: {type(e).__name__}: {e}"
         if dist is not None:

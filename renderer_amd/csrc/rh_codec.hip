@@ -24,6 +24,15 @@
 
 namespace {
 
+// Pointers that are read from the job record are generic as far as the compiler can tell, and a store through a
+// generic pointer is a FLAT instruction: it counts as an LDS operation too, so the wait before the next ring read would
+// also wait for every byte written to the output.  These types say "global memory".
+typedef __attribute__((address_space(1))) uint8_t g_u8;
+typedef __attribute__((address_space(1))) uint32_t g_u32;
+typedef __attribute__((address_space(1))) const uint8_t g_cu8;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) const u32x4 g_cu32x4;
+
 constexpr uint32_t KB64 = 65536u;
 constexpr int MINMATCH = 4, LASTLITERALS = 5, MFLIMIT = 12, LZ4_MINLENGTH = MFLIMIT + 1;
 constexpr int HASHLOG = 12;
@@ -37,8 +46,11 @@ constexpr uint32_t RING_DWORDS = 2 * KB64 / 4;
 // whether it lies in the dictionary, in the previous blocks of the same write, or in the current block.  The byte at
 // virtual offset v is stored at (v + rot) mod 128 KiB; after a full 64 KiB block `rot` advances by 64 KiB, which turns
 // the block into the history of the next one without moving a byte.
+// The ring's first two dwords are repeated behind its end (`again`), so that the unaligned 4- and 8-byte reads take
+// the dwords i, i+1, i+2 without wrapping each index: one address computation and one paired LDS read.
 struct Lds {
     uint32_t ring[RING_DWORDS];
+    uint32_t again[2];
     uint32_t hash[1 << HASHLOG];
 };
 
@@ -47,11 +59,11 @@ struct Ring {
     uint32_t rot;
     __device__ __forceinline__ uint32_t rd32(uint32_t v) const {
         const uint32_t a = v + rot, i = (a >> 2) & (RING_DWORDS - 1u);
-        return __builtin_amdgcn_alignbyte(w[(i + 1u) & (RING_DWORDS - 1u)], w[i], a & 3u);
+        return __builtin_amdgcn_alignbyte(w[i + 1u], w[i], a & 3u);
     }
     __device__ __forceinline__ uint64_t rd64(uint32_t v) const {
         const uint32_t a = v + rot, i = (a >> 2) & (RING_DWORDS - 1u), s = a & 3u;
-        const uint32_t x = w[i], y = w[(i + 1u) & (RING_DWORDS - 1u)], z = w[(i + 2u) & (RING_DWORDS - 1u)];
+        const uint32_t x = w[i], y = w[i + 1u], z = w[i + 2u];
         return (uint64_t)__builtin_amdgcn_alignbyte(y, x, s) | ((uint64_t)__builtin_amdgcn_alignbyte(z, y, s) << 32);
     }
     __device__ __forceinline__ uint32_t byte(uint32_t v) const {
@@ -95,7 +107,7 @@ __device__ __forceinline__ uint32_t count_match(const Ring& R, uint32_t ip, uint
 
 // Cooperative copy of n bytes from the ring (virtual offset v) to global memory: bytes up to the first 4-byte boundary
 // of dst, then whole dwords, then the tail.
-__device__ __forceinline__ void copy_out(uint8_t* dst, const Ring& R, uint32_t v, uint32_t n, int lane) {
+__device__ __forceinline__ void copy_out(g_u8* dst, const Ring& R, uint32_t v, uint32_t n, int lane) {
     if (n <= 64u) {                                   // the usual literal run: one byte per lane
         if ((uint32_t)lane < n) dst[lane] = (uint8_t)R.byte(v + (uint32_t)lane);
         return;
@@ -104,7 +116,7 @@ __device__ __forceinline__ void copy_out(uint8_t* dst, const Ring& R, uint32_t v
     if (head > n) head = n;
     if ((uint32_t)lane < head) dst[lane] = (uint8_t)R.byte(v + (uint32_t)lane);
     const uint32_t words = (n - head) >> 2;
-    uint32_t* d32 = reinterpret_cast<uint32_t*>(dst + head);
+    g_u32* d32 = (g_u32*)(dst + head);
     for (uint32_t i = (uint32_t)lane; i < words; i += 64u) d32[i] = R.rd32(v + head + 4u * i);
     const uint32_t done = head + 4u * words;
     if (done + (uint32_t)lane < n) dst[done + lane] = (uint8_t)R.byte(v + done + (uint32_t)lane);
@@ -130,7 +142,7 @@ __device__ __forceinline__ uint32_t walk(uint32_t k) {
 // The sequential algorithm between two matches is: [insert ip-2; test-and-insert ip] (after a match) or [insert the
 // block's first byte] (at the start), then the miss walk from the next position.  One round evaluates 64 consecutive
 // steps of that sequence: the `pre` leading lanes of the first round take the special positions, the others the walk.
-__device__ uint32_t compress_block(Lds& L, const Ring& R, Stream& st, uint32_t n, uint8_t* out, uint32_t max_out, bool ext_dict,
+__device__ uint32_t compress_block(Lds& L, const Ring& R, Stream& st, uint32_t n, g_u8* out, uint32_t max_out, bool ext_dict,
                                    bool dict_small, int lane) {
     const uint32_t start_index = st.current_offset;
     const uint32_t dict_size = st.dict_size;
@@ -368,13 +380,16 @@ extern "C" __global__ __launch_bounds__(64) void rh_lz4f_compress(const rh_lz4_j
     Lds& L = *reinterpret_cast<Lds*>(lds_raw);
     uint8_t* const ring8 = reinterpret_cast<uint8_t*>(L.ring);
     const int lane = (int)threadIdx.x;
-    const rh_lz4_job job = jobs[blockIdx.x];
+    // (a reference, not a copy: a local copy with its run-time indexed arrays would live in per-lane memory, and
+    // everything derived from it -- block sizes, positions, every branch of the match loop -- would be treated as
+    // varying across the lanes instead of running on the scalar unit)
+    const rh_lz4_job& job = jobs[blockIdx.x];
     rh_lz4_stream_state& S = states[job.stream];
     Ring R; R.w = L.ring; R.rot = 0;
 
     // bring the stream state into LDS
     for (int i = lane; i < (1 << HASHLOG); i += 64) L.hash[i] = S.hash[i];
-    Stream st; st.current_offset = S.current_offset; st.dict_size = S.dict_size;
+    Stream st; st.current_offset = __builtin_amdgcn_readfirstlane(S.current_offset); st.dict_size = __builtin_amdgcn_readfirstlane(S.dict_size);
     {   const uint32_t d = st.dict_size;              // <= 64 KiB, stored at the end of S.dict
         for (uint32_t i = (uint32_t)lane * 16u; i < d; i += 64u * 16u) {
             const uint32_t off = KB64 - ((d + 15u) & ~15u) + i;
@@ -383,15 +398,15 @@ extern "C" __global__ __launch_bounds__(64) void rh_lz4f_compress(const rh_lz4_j
     }
     __syncthreads();
 
-    uint8_t* out = job.out;
+    g_u8* out = (g_u8*)job.out;
     uint64_t op = 0;
     for (uint32_t wi = 0; wi < job.n_writes; wi++) {
-        const uint8_t* src = job.write_ptr[wi];
+        g_cu8* src = (g_cu8*)job.write_ptr[wi];
         const uint64_t size = job.write_len[wi];
         if (size == 0) continue;
         bool first_block = true;
         for (uint64_t done = 0; done < size; ) {
-            const uint32_t n = (uint32_t)((size - done) < KB64 ? (size - done) : KB64);
+            const uint32_t n = __builtin_amdgcn_readfirstlane((uint32_t)((size - done) < KB64 ? (size - done) : KB64));
             // LZ4_renormDictT
             if (st.current_offset + n > 0x80000000u) {
                 const uint32_t delta = st.current_offset - KB64;
@@ -405,21 +420,22 @@ extern "C" __global__ __launch_bounds__(64) void rh_lz4f_compress(const rh_lz4_j
             }
             // load the block behind the history: `rot` is 0 or 64 KiB, so the block is one contiguous, 16-byte aligned
             // half of the ring (the byte loop handles unaligned sources and tails)
-            {   const uint8_t* s = src + done;
+            {   g_cu8* s = src + done;
                 uint8_t* const blk8 = ring8 + ((CUR + R.rot) & (2u * KB64 - 1u));
                 if ((reinterpret_cast<uintptr_t>(s) & 15u) == 0) {
                     for (uint32_t i = (uint32_t)lane * 16u; i + 16u <= n; i += 64u * 16u)
-                        *reinterpret_cast<uint4*>(blk8 + i) = *reinterpret_cast<const uint4*>(s + i);
+                        *reinterpret_cast<u32x4*>(blk8 + i) = *(g_cu32x4*)(s + i);
                     const uint32_t tail = n & ~15u;
                     for (uint32_t i = tail + (uint32_t)lane; i < n; i += 64u) blk8[i] = s[i];
                 } else {
                     for (uint32_t i = (uint32_t)lane; i < n; i += 64u) blk8[i] = s[i];
                 }
             }
+            if (lane == 0) { L.again[0] = L.ring[0]; L.again[1] = L.ring[1]; }        // (after every write to the ring: dictionary, block, slide)
             __syncthreads();
             const bool small = st.dict_size < KB64 && st.dict_size < st.current_offset;
             const bool ext = first_block;
-            uint8_t* blk = out + op;
+            g_u8* blk = out + op;
             Stream before = st;
             uint32_t c = compress_block(L, R, st, n, blk + 4, n - 1, ext, small, lane);
             if (c == 0) { st = before; st.dict_size += n; st.current_offset += n; }      // state advances even when the block is stored

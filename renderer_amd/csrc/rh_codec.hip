@@ -51,8 +51,8 @@ constexpr uint32_t RING_DWORDS = 2 * KB64 / 4;
 struct Lds {
     uint32_t ring[RING_DWORDS];
     uint32_t again[2];
-    uint32_t hash[1 << HASHLOG];
-};
+    uint32_t hash[(1 << HASHLOG) + 64];       // + one private slot per lane: lanes past the end of the walk go there,
+};                                            //   so every lane runs the table protocol and no step needs a lane mask
 
 struct Ring {
     const uint32_t* w;
@@ -188,12 +188,10 @@ __device__ uint32_t compress_block(Lds& L, const Ring& R, Stream& st, uint32_t n
                     else { p = w0 + walk(k); valid = w0 + walk(k + 1u) <= mflimit_plus_one; }
                 }
                 const unsigned long long vm = __ballot(valid);
-                uint32_t h = 0, seq = 0;
-                if (valid) {
-                    const uint64_t s8 = R.rd64(p);
-                    seq = (uint32_t)s8;
-                    h = Ring::hash5_of(s8);
-                }
+                // (a lane past the end reads wrapped ring bytes: harmless, its hash is replaced by its private slot)
+                const uint64_t s8 = R.rd64(p);
+                const uint32_t seq = (uint32_t)s8;
+                const uint32_t h = valid ? Ring::hash5_of(s8) : (uint32_t)(1 << HASHLOG) + (uint32_t)lane;
                 const uint32_t mine = p - bias;
                 // Candidate of a lane: the table entry, unless an earlier lane of this round has the same hash (the
                 // sequential walk would have seen that lane's insert).  Lanes with equal hashes address the same table
@@ -202,15 +200,15 @@ __device__ uint32_t compress_block(Lds& L, const Ring& R, Stream& st, uint32_t n
                 // store must not be forwarded to its later load, other lanes write the same slot: the compiler
                 // barriers make every access a real LDS operation; a volatile pointer would lose the LDS address space.)
                 uint32_t* const table = L.hash;
-                uint32_t old = 0, leader = (uint32_t)lane;
-                if (valid) { old = table[h]; table[h] = 0xffffffffu; }
+                const uint32_t old = table[h];
+                table[h] = 0xffffffffu;
                 asm volatile("" ::: "memory");
-                if (valid) atomicMin(&table[h], (uint32_t)lane);
+                atomicMin(&table[h], (uint32_t)lane);
                 asm volatile("" ::: "memory");
-                if (valid) leader = table[h];
+                const uint32_t leader = table[h];
                 asm volatile("" ::: "memory");
-                if (valid && leader == (uint32_t)lane) table[h] = old;      // the table is as it was
-                const unsigned long long repeats = __ballot(valid && leader != (uint32_t)lane);   // lanes with an earlier lane of the same hash
+                if (leader == (uint32_t)lane) table[h] = old;               // the table is as it was
+                const unsigned long long repeats = __ballot(leader != (uint32_t)lane);   // lanes with an earlier lane of the same hash (never a lane past the end)
                 const int first_invalid = (~vm) ? __builtin_ctzll(~vm) : 64;
                 uint32_t mi = old;
                 unsigned long long same = 1ull << lane;                     // (general path) lanes of this round with the same hash
@@ -221,12 +219,9 @@ __device__ uint32_t compress_block(Lds& L, const Ring& R, Stream& st, uint32_t n
                 const uint32_t from_leader = (uint32_t)__shfl((int)mine, (int)leader);          // all lanes take part
                 if (lane == f) mi = from_leader;
                 auto test = [&](uint32_t cand) {
-                    bool t = false;
-                    if (valid && tests) {
-                        const bool ok = !(dict_small && cand < prefix_idx_limit) && (cand + DISTANCE_MAX >= mine);
-                        if (ok) t = R.rd32(cand + bias) == seq;
-                    }
-                    return t;
+                    // (the ring read is unconditional: any address is inside the ring, the result only counts when in reach)
+                    const bool ok = !(dict_small && cand < prefix_idx_limit) && (cand + DISTANCE_MAX >= mine);
+                    return valid && tests && ok && R.rd32(cand + bias) == seq;
                 };
                 unsigned long long hits = __ballot(test(mi));
                 bool general = false;

@@ -90,12 +90,10 @@ __device__ __forceinline__ uint32_t count_match(const Ring& R, uint32_t ip, uint
     for (;;) {
         const uint32_t p = ip + n + (uint32_t)lane * 4u;
         uint32_t avail = p < limit ? limit - p : 0u; if (avail > 4u) avail = 4u;
-        uint32_t same = 0;
-        if (avail) {
-            const uint32_t d = R.rd32(p) ^ R.rd32(match + n + (uint32_t)lane * 4u);
-            same = d ? (uint32_t)__builtin_ctz(d) >> 3 : 4u;
-            if (same > avail) same = avail;
-        }
+        // (unconditional reads: any address is inside the ring; `avail` bounds what counts)
+        const uint32_t d = R.rd32(p) ^ R.rd32(match + n + (uint32_t)lane * 4u);
+        uint32_t same = d ? (uint32_t)__builtin_ctz(d) >> 3 : 4u;
+        if (same > avail) same = avail;
         const unsigned long long stop = __ballot(same < 4u);
         if (stop) {
             const int first = __builtin_ctzll(stop);
@@ -285,8 +283,9 @@ __device__ uint32_t compress_block(Lds& L, const Ring& R, Stream& st, uint32_t n
             // ---- catch up: extend the match backwards, 64 bytes per round (the first round from the loads above)
             for (bool first = true; ip > anchor; first = false) {
                 const uint32_t d = (uint32_t)lane + 1u;
-                bool ok = (int32_t)(ip - anchor) >= (int32_t)d && (int32_t)(match - low_limit) >= (int32_t)d;
-                if (ok) ok = first ? cu_a == cu_b : R.byte(ip - d) == R.byte(match - d);
+                const bool room = (int32_t)(ip - anchor) >= (int32_t)d && (int32_t)(match - low_limit) >= (int32_t)d;
+                const bool equal = first ? cu_a == cu_b : R.byte(ip - d) == R.byte(match - d);      // (first: wave-uniform)
+                const bool ok = room && equal;
                 const unsigned long long stop = __ballot(!ok);
                 const uint32_t c = stop ? (uint32_t)__builtin_ctzll(stop) : 64u;
                 ip -= c; match -= c; caught_up += c;
@@ -319,12 +318,9 @@ __device__ uint32_t compress_block(Lds& L, const Ring& R, Stream& st, uint32_t n
             uint32_t fwd;
             {   const uint32_t q = fwd_ip + (uint32_t)lane * 4u;
                 uint32_t avail = q < matchlimit ? matchlimit - q : 0u; if (avail > 4u) avail = 4u;
-                uint32_t same = 0;
-                if (avail) {
-                    const uint32_t x = cm_a ^ cm_b;
-                    same = x ? (uint32_t)__builtin_ctz(x) >> 3 : 4u;
-                    if (same > avail) same = avail;
-                }
+                const uint32_t x = cm_a ^ cm_b;
+                uint32_t same = x ? (uint32_t)__builtin_ctz(x) >> 3 : 4u;
+                if (same > avail) same = avail;
                 const unsigned long long stop = __ballot(same < 4u);
                 if (stop) { const int first = __builtin_ctzll(stop); fwd = (uint32_t)first * 4u + (uint32_t)__builtin_amdgcn_readlane((int)same, first); }
                 else fwd = count_match(R, fwd_ip, fwd_match, matchlimit, lane, 256u);

@@ -44,6 +44,38 @@ def pmc_traffic_bytes(tag="c1"):
     return None
 
 
+def capture_plan(n_ranks, dist, local_rank):
+    """(frames, streams, untimed warm-up rounds) per GPU for the recorded-frames/s leg.  The frames of the leg's scene
+    hardly compress (about 28 MB each), every rank writes its stream files to the host's /tmp and pins up to two
+    host buffers of one round's bytes: the largest plan is taken that leaves half of the free disk space and of the
+    available memory untouched with all ranks of the host running it; the ranks settle on the most careful choice."""
+    import shutil
+    plans = [(512, 256, 2), (256, 256, 1), (128, 128, 1)]
+    frame_bytes = 30e6
+    try:
+        disk = shutil.disk_usage("/tmp").free
+    except OSError:
+        disk = 0
+    try:
+        import psutil
+        ram = psutil.virtual_memory().available
+    except Exception:
+        ram = 64e9
+    choice = len(plans) - 1
+    for i, (frames, streams, rounds) in enumerate(plans):
+        on_disk = n_ranks * max(frames, rounds * streams) * frame_bytes           # warm-up bytes are dropped before the timed frames
+        pinned = n_ranks * 2 * streams * frame_bytes * 1.25
+        if on_disk <= 0.5 * disk and pinned <= 0.5 * ram:
+            choice = i
+            break
+    if dist is not None:
+        import torch
+        t = torch.tensor([choice], dtype=torch.int64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        choice = int(t.item())
+    return plans[choice]
+
+
 def main():
     # Libraries underneath (RCCL prints a version banner at start-up) write to stdout: keep the real stdout for the one
     # JSON line and send everything else to stderr.
@@ -63,17 +95,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--capture-frames", type=int, default=-1,
                     help="frames of the recorded-frames/s leg (BASELINE.json configs[4] shape, per GPU); 0 skips it; "
-                         "default 512, or 128 when more than two ranks share the host's /tmp")
+                         "default: 512 frames into 256 streams, or less when the ranks of this host would not find "
+                         "room for their stream files in /tmp or for their pinned buffers in memory (see capture_plan)")
     ap.add_argument("--capture-streams", type=int, default=-1,
                     help="stream files per GPU; default 256 (the LZ4 kernel holds one stream per compute unit at a time: "
-                         "a round of up to 256 streams takes as long as a round of one), or 128 with more than two ranks")
+                         "a round of up to 256 streams takes as long as a round of one)")
     args = ap.parse_args()
 
-    few_ranks = max(args.gpus, int(os.environ.get("WORLD_SIZE", "1"))) <= 2
-    if args.capture_frames < 0:
-        args.capture_frames = 512 if few_ranks else 128
-    if args.capture_streams < 0:
-        args.capture_streams = 256 if few_ranks else 128
+    capture_auto = args.capture_frames < 0 and args.capture_streams < 0      # sized below, once the ranks can agree
+    capture_warm_rounds = 1
     default_workload = (args.workload, args.quads, args.side, args.width, args.height) == ("c1", 1_000_000, 16, 3840, 2160)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -146,6 +176,12 @@ def main():
     # Second half of the metric: recorded frames/s.  Every rank renders, records and GPU-compresses its own frames into
     # its own stream files (frame-parallel, no data-path collective); the job value is the sum over ranks.
     capture = None
+    if capture_auto:
+        args.capture_frames, args.capture_streams, capture_warm_rounds = capture_plan(n_gpus, dist, local_rank)
+    elif args.capture_streams < 0:
+        args.capture_streams = 256
+    elif args.capture_frames < 0:
+        args.capture_frames = 2 * args.capture_streams
     if args.capture_frames > 0 and args.workload == "c1":
         import bench_capture
         cap_s, cap_info, cap_error = float("inf"), None, None
@@ -153,8 +189,8 @@ def main():
             cap_s, cap_info, _ = bench_capture.run_capture(
                 frames=args.capture_frames, streams=args.capture_streams, out=f"/tmp/rh_bench_capture_{os.getpid()}_{rank}",
                 hip_ordinal=local_rank, seed=4 + rank,
-                # untimed rounds first (the compressor pins its host buffers in them); one when many ranks share /tmp
-                warmup=(2 if few_ranks else 1) * args.capture_streams)
+                # untimed rounds first: the compressor pins its host buffers in them
+                warmup=capture_warm_rounds * args.capture_streams)
         except Exception as e:                   # e.g. no room for the stream files: report it, keep the quads/s line
             cap_error = f"rank {rank}: {type(e).__name__}: {e}"
         if dist is not None:

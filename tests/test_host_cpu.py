@@ -138,3 +138,23 @@ def test_cpp_host_mirror_builds():
         assert os.path.exists(exe)
         out = subprocess.run([exe], capture_output=True, text=True)
         assert out.returncode == 2 and "usage" in out.stderr
+
+
+def test_bench_capture_plan_shrinks_with_ranks_and_room(monkeypatch):
+    """bench.py sizes its recorded-frames leg from the free space in /tmp and the available memory: the largest plan
+    when there is room, smaller ones as more ranks share the host, never below the smallest."""
+    import collections
+    import importlib.util
+    import shutil
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    Usage = collections.namedtuple("Usage", "total used free")
+    import psutil
+    Mem = collections.namedtuple("Mem", "available")
+    monkeypatch.setattr(psutil, "virtual_memory", lambda: Mem(available=300e9))
+    monkeypatch.setattr(shutil, "disk_usage", lambda path: Usage(252e9, 172e9, 80e9))
+    plans = [bench.capture_plan(n, None, 0) for n in (1, 2, 4, 8)]
+    assert plans == [(512, 256, 2), (512, 256, 2), (256, 256, 1), (128, 128, 1)]
+    monkeypatch.setattr(shutil, "disk_usage", lambda path: Usage(252e9, 251e9, 1e9))
+    assert bench.capture_plan(1, None, 0) == (128, 128, 1)

@@ -4,7 +4,7 @@
 #pragma once
 #include <stdint.h>
 
-#define RH_DEVICE_ABI_VERSION 8u
+#define RH_DEVICE_ABI_VERSION 9u
 #define RH_MODULE_MAGIC 0x52484d4fu   // "RHMO"
 
 #define RH_DEV_MAX_ATTRIBUTES 8
@@ -95,4 +95,9 @@ struct rh_tile_args {
     // 1 + (blend_class - 1) * 2 + (texture_class - 1) with blend_class 1 = (One, OneMinusSrcAlpha), 2 = (One, One) and
     // texture_class 1 = every bound texture RGBA8 at least 2x2 with linear samplers, 2 = the same with nearest samplers.
     uint32_t variant;
+    // The pass may be queued before the host knows how many (tile, cluster) pairs it has: the kernels size their work
+    // from *pair_total, and when that exceeds `pair_capacity` (the room the host gave the pair arrays) nobody writes
+    // anything -- the host notices and runs the pass again with enough room.  Null: the lists are known to fit.
+    uint32_t pair_capacity;
+    const unsigned long long* pair_total;
 };

@@ -75,6 +75,12 @@ struct rh_device {
     void* png_host = nullptr; size_t png_host_cap = 0;   // pinned
     unsigned long long* d_total = nullptr;
     unsigned long long* h_total = nullptr;      // pinned
+    // A pass is queued whole, sized by `pair_guess`, before its pair count has come back; the count is looked at
+    // before the next command runs (resolve_pending) and the pass runs again, waiting for the count, if it did not fit.
+    uint64_t pair_guess = 0;                    // room given to the pair arrays of a queued pass; 0: no pass seen yet
+    hipEvent_t counted = nullptr;               // recorded behind the copy of the count to h_total
+    const void* pending_pass = nullptr;         // (a PassCmd of the command buffer being submitted)
+    uint32_t pending_capacity = 0;
     // allocation caches (exact-size reuse; capture buffers come and go every frame)
     std::multimap<size_t, void*> free_device, free_pinned;
     size_t free_device_bytes = 0, free_pinned_bytes = 0;
@@ -224,7 +230,8 @@ int rh_device_create(int hip_ordinal, uint32_t width, uint32_t height, rh_device
     dev->name = std::string(prop.name) + " (" + prop.gcnArchName + ")";
     hipError_t e = hipStreamCreateWithFlags(&dev->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete dev; return fail("hipStreamCreate failed: %s", hipGetErrorString(e)); }
-    if (hipMalloc((void**)&dev->d_total, 8) != hipSuccess || hipHostMalloc((void**)&dev->h_total, 8, hipHostMallocDefault) != hipSuccess) {
+    if (hipMalloc((void**)&dev->d_total, 8) != hipSuccess || hipHostMalloc((void**)&dev->h_total, 8, hipHostMallocDefault) != hipSuccess ||
+        hipEventCreateWithFlags(&dev->counted, hipEventDisableTiming) != hipSuccess) {
         delete dev; return fail("rh_device_create: allocation failed");
     }
     if (rh_texture_create(dev, width, height, 1, RH_FORMAT_BGRA_U8, 1,
@@ -260,6 +267,7 @@ void device_release(rh_device* dev) {
     for (hipEvent_t e : dev->timing_events) (void)hipEventDestroy(e);
     for (auto& kv : dev->free_device) (void)hipFree(kv.second);
     for (auto& kv : dev->free_pinned) (void)hipHostFree(kv.second);
+    if (dev->counted) (void)hipEventDestroy(dev->counted);
     if (dev->d_total) (void)hipFree(dev->d_total);
     if (dev->h_total) (void)hipHostFree(dev->h_total);
     if (dev->png_host) (void)hipHostFree(dev->png_host);
@@ -705,7 +713,7 @@ int launch_module_kernel(hipFunction_t fn, uint32_t grid, void* args, size_t arg
     return 0;
 }
 
-int execute_pass(rh_device* dev, const PassCmd& c) {
+int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer) {
     rh_pipeline* pl = c.pipeline;
     const rh_texture* t0 = c.attachments[0].texture;
     const uint32_t W = t0->width, H = t0->height;
@@ -765,7 +773,9 @@ int execute_pass(rh_device* dev, const PassCmd& c) {
     hipStream_t s = dev->stream;
     if (dev->tile_start.ensure((size_t)n_tiles * 8)) return 1;                    // [start of every tile | end of every tile]
     uint32_t* const tile_start = dev->tile_start.as<uint32_t>(); uint32_t* const tile_end = tile_start + n_tiles;
-    uint64_t total = 0;
+    uint64_t total = 0;                          // pairs, or the room for them when the count has not come back yet
+    bool deferred = false;
+    const unsigned long long* pair_total = nullptr;
     uint32_t* sorted_vals = nullptr;
     if (timing_mark(dev)) return 1;
     if (n_clusters > 0) {
@@ -778,21 +788,32 @@ int execute_pass(rh_device* dev, const PassCmd& c) {
         if (launch_module_kernel(pl->vs->bin_count, n_blocks, &ba, sizeof ba, s)) return 1;
         rhk::exclusive_scan(dev->block_sums.as<uint32_t>(), n_blocks, dev->chunk_tmp.as<uint32_t>(), dev->d_total, s, dev->general_kernels != 0);
         RH_HIP(hipMemcpyAsync(dev->h_total, dev->d_total, 8, hipMemcpyDeviceToHost, s));
-        RH_HIP(hipStreamSynchronize(s));
-        total = *dev->h_total;
-        if (total >= 0x7fffffffull) return fail("render pass: %llu (tile, cluster) pairs exceed the 31-bit pair index", (unsigned long long)total);
+        // Once a pass has been seen the rest is queued without waiting for the count, with room for `pair_guess`
+        // pairs; the kernels read the count on the device.  (The option that forces the general kernels also forces
+        // the waiting form, so that tests cover both.)
+        deferred = may_defer && dev->pair_guess > 0 && !dev->general_kernels;
+        if (deferred) {
+            RH_HIP(hipEventRecord(dev->counted, s));
+            total = dev->pair_guess;
+            pair_total = dev->d_total;
+        } else {
+            RH_HIP(hipStreamSynchronize(s));
+            total = *dev->h_total;
+            if (total >= 0x7fffffffull) return fail("render pass: %llu (tile, cluster) pairs exceed the 31-bit pair index", (unsigned long long)total);
+            dev->pair_guess = std::max<uint64_t>(dev->pair_guess, std::min<uint64_t>(total + total / 4 + 4096, 0x7ffffffeull));
+        }
         if (total > 0) {
             const uint32_t n = (uint32_t)total;
             const uint32_t sort_blocks = rhk::sort_blocks_for(n);
             if (dev->keys_a.ensure((size_t)n * 4) || dev->vals_a.ensure((size_t)n * 4) || dev->keys_b.ensure((size_t)n * 4) || dev->vals_b.ensure((size_t)n * 4) ||
                 dev->hist.ensure((size_t)sort_blocks * 256 * 4) || dev->chunk_tmp.ensure((size_t)rhk::scan_chunks_for(sort_blocks * 256) * 4)) return 1;
             rhk::bin_emit(dev->ranges.as<rh_tile_range>(), n_clusters, p.tiles_x, dev->block_sums.as<uint32_t>(),
-                          dev->keys_a.as<uint32_t>(), dev->vals_a.as<uint32_t>(), s);
+                          dev->keys_a.as<uint32_t>(), dev->vals_a.as<uint32_t>(), s, pair_total, n);
             int where = rhk::radix_sort_pairs(dev->keys_a.as<uint32_t>(), dev->vals_a.as<uint32_t>(), dev->keys_b.as<uint32_t>(), dev->vals_b.as<uint32_t>(),
-                                              n, bits_for(n_tiles), dev->hist.as<uint32_t>(), dev->chunk_tmp.as<uint32_t>(), s, dev->general_kernels != 0);
+                                              n, bits_for(n_tiles), dev->hist.as<uint32_t>(), dev->chunk_tmp.as<uint32_t>(), s, dev->general_kernels != 0, pair_total);
             uint32_t* sorted_keys = where ? dev->keys_b.as<uint32_t>() : dev->keys_a.as<uint32_t>();
             sorted_vals = where ? dev->vals_b.as<uint32_t>() : dev->vals_a.as<uint32_t>();
-            rhk::tile_ranges(sorted_keys, n, tile_start, tile_end, n_tiles, s);
+            rhk::tile_ranges(sorted_keys, n, tile_start, tile_end, n_tiles, s, pair_total);
         }
     }
     if (total == 0) {
@@ -803,6 +824,7 @@ int execute_pass(rh_device* dev, const PassCmd& c) {
     memset(&ta, 0, sizeof ta);
     ta.p = p; ta.p.n_clusters = n_clusters;
     ta.list = sorted_vals; ta.tile_start = tile_start; ta.tile_end = tile_end;
+    ta.pair_total = pair_total; ta.pair_capacity = (uint32_t)total;
     ta.n_att = (uint32_t)c.attachments.size();
     bool any_clear = false;
     for (size_t i = 0; i < c.attachments.size(); i++) {
@@ -840,9 +862,29 @@ int execute_pass(rh_device* dev, const PassCmd& c) {
     }
     if (timing_mark(dev)) return 1;
 
-    dev->stats.clusters = n_clusters; dev->stats.bin_entries = total;
+    if (deferred) { dev->pending_pass = &c; dev->pending_capacity = (uint32_t)total; }
+    dev->stats.clusters = n_clusters; dev->stats.bin_entries = deferred ? 0 : total;
     dev->stats.tiles_x = p.tiles_x; dev->stats.tiles_y = p.tiles_y; dev->stats.tile_w = RH_TILE_W; dev->stats.tile_h = RH_TILE_H;
     return 0;
+}
+
+// Looks at the pair count of the pass that was queued without waiting for it (before anything else is queued behind
+// it): normally it fitted and there is nothing to do; otherwise its kernels have written nothing, and the pass runs
+// again in the waiting form.
+int resolve_pending(rh_device* dev) {
+    if (!dev->pending_pass) return 0;
+    const PassCmd& c = *static_cast<const PassCmd*>(dev->pending_pass);
+    const uint64_t capacity = dev->pending_capacity;
+    dev->pending_pass = nullptr;
+    RH_HIP(hipEventSynchronize(dev->counted));
+    const uint64_t total = *dev->h_total;
+    if (total >= 0x7fffffffull) return fail("render pass: %llu (tile, cluster) pairs exceed the 31-bit pair index", (unsigned long long)total);
+    dev->stats.bin_entries = total;
+    if (total <= capacity) {
+        dev->pair_guess = std::max<uint64_t>(dev->pair_guess, std::min<uint64_t>(total + total / 4 + 4096, 0x7ffffffeull));
+        return 0;
+    }
+    return execute_pass(dev, c, false);
 }
 
 int execute_copy(rh_device* dev, const CopyCmd& c) {
@@ -865,9 +907,12 @@ int rh_submit(rh_device* dev, rh_cmdbuf* const* list, size_t n) {
         if (!cb) continue;
         if (!rc) {
             for (const Cmd& c : cb->cmds) {
-                rc = c.kind == 0 ? execute_pass(dev, c.pass) : execute_copy(dev, c.copy);
+                rc = resolve_pending(dev);
+                if (!rc) rc = c.kind == 0 ? execute_pass(dev, c.pass, true) : execute_copy(dev, c.copy);
                 if (rc) break;
             }
+            if (!rc) rc = resolve_pending(dev);       // (the commands go away with the buffer)
+            dev->pending_pass = nullptr;
         }
         rh_cmdbuf_release(cb);
     }

@@ -13,13 +13,14 @@ uint32_t sort_blocks_for(uint32_t n);
 void exclusive_scan(uint32_t* data, uint32_t n, uint32_t* chunk_tmp, unsigned long long* total_out, hipStream_t s, bool general = false);
 
 void bin_emit(const rh_tile_range* ranges, uint32_t n_clusters, uint32_t tiles_x, const uint32_t* block_bases,
-              uint32_t* keys, uint32_t* vals, hipStream_t s);
+              uint32_t* keys, uint32_t* vals, hipStream_t s, const unsigned long long* pair_total = nullptr, uint32_t capacity = 0);
 
 int radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, uint32_t n, uint32_t key_bits,
-                     uint32_t* hist, uint32_t* chunk_tmp, hipStream_t s, bool general = false);
+                     uint32_t* hist, uint32_t* chunk_tmp, hipStream_t s, bool general = false, const unsigned long long* pair_total = nullptr);
 
 // tile_end must be tile_start + n_tiles (one allocation, cleared by one fill).
-void tile_ranges(const uint32_t* keys, uint32_t n, uint32_t* tile_start, uint32_t* tile_end, uint32_t n_tiles, hipStream_t s);
+void tile_ranges(const uint32_t* keys, uint32_t n, uint32_t* tile_start, uint32_t* tile_end, uint32_t n_tiles, hipStream_t s,
+                 const unsigned long long* pair_total = nullptr);
 
 void copy_texture_to_buffer(const uint8_t* tex, uint32_t tex_pitch_bytes, uint32_t ox, uint32_t oy, uint32_t bpt, uint32_t w, uint32_t h,
                             uint8_t* dst, uint32_t dst_pitch, hipStream_t s);

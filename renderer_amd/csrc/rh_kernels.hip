@@ -103,9 +103,13 @@ extern "C" __global__ __launch_bounds__(256) void rh_scan_apply(uint32_t* data, 
 // One thread per cluster (same 256-cluster partition as rh_bin_count).  Cluster c writes its (tile, c) pairs at
 // block_base + exclusive prefix within the block, tiles in row-major order, so the pair array is ordered by cluster.
 // Clusters that touch more than 32 tiles are written cooperatively by the whole workgroup.
+// `pair_total` / `capacity` (here and in the kernels below): the number of pairs is read on the device, and a pass whose
+// pairs do not fit the arrays writes nothing (see rh_tile_args::pair_total); a null pointer means "n is exact".
 extern "C" __global__ __launch_bounds__(256) void rh_bin_emit(const rh_tile_range* ranges, uint32_t n_clusters, uint32_t tiles_x,
-                                                             const uint32_t* block_bases, uint32_t* keys, uint32_t* vals) {
+                                                             const uint32_t* block_bases, uint32_t* keys, uint32_t* vals,
+                                                             const unsigned long long* pair_total, uint32_t capacity) {
     __shared__ uint32_t lds4[4];
+    if (pair_total && *pair_total > capacity) return;
     __shared__ uint32_t big_n;
     __shared__ uint32_t big_cluster[WG], big_off[WG];
     if (threadIdx.x == 0) big_n = 0;
@@ -140,8 +144,10 @@ extern "C" __global__ __launch_bounds__(256) void rh_bin_emit(const rh_tile_rang
 
 // ---- stable LSD radix sort, 8 bits per pass ------------------------------------------------------------------------------
 // histogram: hist[digit * n_blocks + block]
-extern "C" __global__ __launch_bounds__(256) void rh_sort_hist(const uint32_t* keys, uint32_t n, uint32_t shift, uint32_t* hist, uint32_t n_blocks) {
+extern "C" __global__ __launch_bounds__(256) void rh_sort_hist(const uint32_t* keys, uint32_t n, uint32_t shift, uint32_t* hist, uint32_t n_blocks,
+                                                              const unsigned long long* pair_total) {
     __shared__ uint32_t h[256];
+    if (pair_total) { if (*pair_total > n) return; n = (uint32_t)*pair_total; }          // (n arrives as the capacity)
     h[threadIdx.x] = 0;
     __syncthreads();
     const size_t base = (size_t)blockIdx.x * SORT_CHUNK;
@@ -160,7 +166,10 @@ extern "C" __global__ __launch_bounds__(256) void rh_sort_hist(const uint32_t* k
 // digit inside LDS and then writes them out in that order: the pairs of one digit leave as one contiguous run instead
 // of 4-byte writes all over the output.
 extern "C" __global__ __launch_bounds__(256) void rh_sort_scatter(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
-                                                                 uint32_t n, uint32_t shift, const uint32_t* offsets, uint32_t n_blocks) {
+                                                                 uint32_t n, uint32_t shift, const uint32_t* offsets, uint32_t n_blocks,
+                                                                 const unsigned long long* pair_total) {
+    if (pair_total) { if (*pair_total > n) return; n = (uint32_t)*pair_total; }
+    if ((size_t)blockIdx.x * SORT_CHUNK >= n) return;
     __shared__ uint32_t cnt[4][256];            // per wave and digit: count, then the next free local slot
     __shared__ uint32_t digit_start[256];       // first local slot of each digit
     __shared__ uint32_t global_base[256];       // where this workgroup's run of each digit starts in the output
@@ -219,7 +228,9 @@ extern "C" __global__ __launch_bounds__(256) void rh_sort_scatter(const uint32_t
 }
 
 // ---- tile ranges from the sorted key array --------------------------------------------------------------------------------
-extern "C" __global__ __launch_bounds__(256) void rh_tile_ranges(const uint32_t* keys, uint32_t n, uint32_t* tile_start, uint32_t* tile_end) {
+extern "C" __global__ __launch_bounds__(256) void rh_tile_ranges(const uint32_t* keys, uint32_t n, uint32_t* tile_start, uint32_t* tile_end,
+                                                                const unsigned long long* pair_total) {
+    if (pair_total) { if (*pair_total > n) return; n = (uint32_t)*pair_total; }
     const size_t i = (size_t)blockIdx.x * WG + threadIdx.x;
     if (i >= n) return;
     const uint32_t k = keys[i];
@@ -269,35 +280,36 @@ void exclusive_scan(uint32_t* data, uint32_t n, uint32_t* chunk_tmp, unsigned lo
 }
 
 void bin_emit(const rh_tile_range* ranges, uint32_t n_clusters, uint32_t tiles_x, const uint32_t* block_bases,
-              uint32_t* keys, uint32_t* vals, hipStream_t s) {
+              uint32_t* keys, uint32_t* vals, hipStream_t s, const unsigned long long* pair_total, uint32_t capacity) {
     if (n_clusters == 0) return;
-    hipLaunchKernelGGL(rh_bin_emit, dim3(div_up(n_clusters, WG)), dim3(WG), 0, s, ranges, n_clusters, tiles_x, block_bases, keys, vals);
+    hipLaunchKernelGGL(rh_bin_emit, dim3(div_up(n_clusters, WG)), dim3(WG), 0, s, ranges, n_clusters, tiles_x, block_bases, keys, vals, pair_total, capacity);
 }
 
 // Sorts n pairs by the low `key_bits` bits of the key.  Buffers ping-pong; returns 0 when the result is in
 // (keys_a, vals_a) and 1 when it is in (keys_b, vals_b).  hist needs 256 * sort_blocks_for(n) words, chunk_tmp
 // scan_chunks_for(256 * sort_blocks_for(n)) words.
 int radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, uint32_t n, uint32_t key_bits,
-                     uint32_t* hist, uint32_t* chunk_tmp, hipStream_t s, bool general) {
+                     uint32_t* hist, uint32_t* chunk_tmp, hipStream_t s, bool general, const unsigned long long* pair_total) {
     if (n == 0) return 0;
     const uint32_t blocks = sort_blocks_for(n);
     int cur = 0;
     for (uint32_t shift = 0; shift < key_bits; shift += 8) {
         uint32_t* ki = cur ? keys_b : keys_a; uint32_t* vi = cur ? vals_b : vals_a;
         uint32_t* ko = cur ? keys_a : keys_b; uint32_t* vo = cur ? vals_a : vals_b;
-        hipLaunchKernelGGL(rh_sort_hist, dim3(blocks), dim3(WG), 0, s, ki, n, shift, hist, blocks);
+        hipLaunchKernelGGL(rh_sort_hist, dim3(blocks), dim3(WG), 0, s, ki, n, shift, hist, blocks, pair_total);
         exclusive_scan(hist, 256u * blocks, chunk_tmp, nullptr, s, general);
-        hipLaunchKernelGGL(rh_sort_scatter, dim3(blocks), dim3(WG), 0, s, ki, vi, ko, vo, n, shift, hist, blocks);
+        hipLaunchKernelGGL(rh_sort_scatter, dim3(blocks), dim3(WG), 0, s, ki, vi, ko, vo, n, shift, hist, blocks, pair_total);
         cur ^= 1;
     }
     return cur;
 }
 
 // tile_end must be tile_start + n_tiles (one allocation, cleared by one fill).
-void tile_ranges(const uint32_t* keys, uint32_t n, uint32_t* tile_start, uint32_t* tile_end, uint32_t n_tiles, hipStream_t s) {
+void tile_ranges(const uint32_t* keys, uint32_t n, uint32_t* tile_start, uint32_t* tile_end, uint32_t n_tiles, hipStream_t s,
+                 const unsigned long long* pair_total) {
     (void)hipMemsetAsync(tile_start, 0, (size_t)n_tiles * 8, s);
     if (n == 0) return;
-    hipLaunchKernelGGL(rh_tile_ranges, dim3(div_up(n, WG)), dim3(WG), 0, s, keys, n, tile_start, tile_end);
+    hipLaunchKernelGGL(rh_tile_ranges, dim3(div_up(n, WG)), dim3(WG), 0, s, keys, n, tile_start, tile_end, pair_total);
 }
 
 void copy_texture_to_buffer(const uint8_t* tex, uint32_t tex_pitch_bytes, uint32_t ox, uint32_t oy, uint32_t bpt, uint32_t w, uint32_t h,

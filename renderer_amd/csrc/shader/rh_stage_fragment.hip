@@ -368,6 +368,7 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
     uint32_t* const rec_bbox = lds.rec_bbox;
     PxT (* const tile_px)[4 * REGION_STRIDE] = lds.tile_px;
 
+    if (a.pair_total && *a.pair_total > a.pair_capacity) return;     // the pair arrays were too small: the host runs the pass again
     const rh_draw_params& p = a.p;
     const int tid = (int)threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: everything derived from it is wave-uniform
@@ -607,6 +608,7 @@ struct TileLdsMs {
 template <int S>
 RH_DEVICE void tile_kernel_ms(const rh_tile_args& a) {
     __shared__ TileLdsMs<S> lds;
+    if (a.pair_total && *a.pair_total > a.pair_capacity) return;     // the pair arrays were too small: the host runs the pass again
     const rh_draw_params& p = a.p;
     const rh_attach_dev& at = a.att[0];
     const int tid = (int)threadIdx.x, lane = tid & 63;

@@ -101,7 +101,7 @@ def run_one(seed):
         scene["clear"] = None
     orc = scenes.draw_oracle(scene, clip_to_viewport=clip, initial=initial)
     try:
-        hip = scenes.draw_hip(scene, clip_to_viewport=clip, initial=initial)
+        hip = scenes.draw_hip(scene, clip_to_viewport=clip, initial=initial, twice=seed % 2 == 0)
     except RendererError as e:
         # recording through a viewport thinner than one pixel: the capture extent underflows, as in the reference
         if "subtract with overflow" in str(e) and scene.get("record") and scene["viewport"] is not None:

@@ -231,11 +231,15 @@ class HipScene:
             self.renderer.close()
 
 
-def draw_hip(scene, clip_to_viewport=True, initial=None):
+def draw_hip(scene, clip_to_viewport=True, initial=None, twice=False):
+    """`twice` (scenes that clear their targets): the frame is drawn, thrown away and drawn again, so that the checked
+    frame is one the device queued before its pair count was known (the first pass of a device waits for it)."""
     hs = HipScene(scene, clip_to_viewport=clip_to_viewport)
     try:
         if initial is not None:
             hs.set_initial(initial)
+        elif twice:
+            hs.draw()
         hs.draw()
         out = {"color": hs.read_color(), "stats": hs.renderer.last_pass_stats()}
         if scene.get("samples", 1) > 1:

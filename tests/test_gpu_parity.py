@@ -155,6 +155,23 @@ def test_general_and_specialised_kernel_bodies_agree(oracle):
         assert_same(got, want, f"general={general}")
 
 
+def test_pass_queued_before_its_pair_count_is_known(oracle):
+    """After its first pass a device queues a pass whole, with room for the pairs of the largest pass seen so far
+    plus a quarter, and looks at the count afterwards.  Scenes that fit (same size, smaller) and a scene that does not
+    (ten times the pairs: its kernels write nothing and the pass runs again) all match the oracle."""
+    from renderer_amd import Renderer
+    W, H = 640, 360
+    r = Renderer(W, H)
+    for n, seed in ((3000, 1), (3000, 2), (500, 3), (40000, 4), (40000, 5), (100, 6)):
+        scene = scenes.random_quads_scene(n, 12, W, H, seed=seed)
+        hs = scenes.HipScene(scene, renderer=r)
+        hs.draw()
+        got = hs.read_color()
+        hs.close()
+        assert_same(got, scenes.draw_oracle(scene)["color"], f"{n} quads after the previous scene")
+    r.close()
+
+
 def test_short_and_general_prefix_sums_agree(oracle):
     """Enough (tile, quad) pairs that the sort's histogram scan spans several chunks: the two-launch form (chunk bases
     summed inside the apply phase) and the three-launch form that serves any length order the quads identically."""

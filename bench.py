@@ -169,6 +169,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # the frame the timed steps drew, kept for the comparison with the CPU oracle's frame of the same scene (outside
+    # the timed region)
+    hip_frame = hs.read_color() if (rank == 0 and n_gpus == 1 and not args.no_cpu_baseline) else None
+
     # release the quads scene before the recording leg
     hs.close()
     renderer.close()
@@ -207,6 +211,7 @@ def main():
                        "ms_per_frame_per_gpu": cap_s / args.capture_frames * 1e3, "workload": cap_info["workload"],
                        "raw_MB_per_frame": cap_info["raw_MB_per_frame"], "compressed_MB_per_frame": cap_info["compressed_MB_per_frame"]}
 
+    parity_failed = False
     if rank == 0:
         total_quads = args.quads * args.steps * n_gpus
         value = total_quads / elapsed
@@ -253,6 +258,11 @@ def main():
             out["cpu_baseline"] = {"value": args.quads / cpu_s, "unit": "quads/s", "cores": cores, "kind": "port",
                                    "sample": f"one full frame of the same scene ({args.quads} quads, {orc['fragments']} fragments) "
                                              f"on {cores} threads, {cpu_s:.2f} s wall; CPU restatement, not lavapipe"}
+            # parity of exactly what was timed: every byte of the HIP frame against the oracle's frame
+            differ = int((hip_frame != orc["color"]).any(axis=2).sum())
+            out["parity"] = {"pixels": int(hip_frame.shape[0] * hip_frame.shape[1]), "differ": differ,
+                             "against": "CPU oracle, same scene, bit-exact"}
+            parity_failed = differ != 0
         if capture is not None:
             out["capture"] = capture
         sys.stdout.flush()
@@ -260,6 +270,9 @@ def main():
 
     if dist is not None:
         dist.destroy_process_group()
+    if parity_failed:
+        sys.stderr.write("bench.py: the timed frame differs from the CPU oracle's\n")
+        sys.exit(3)
 
 
 if __name__ == "__main__":

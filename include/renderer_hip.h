@@ -215,6 +215,8 @@ typedef struct rh_pass_stats {
     uint64_t bin_entries;     /* (cluster, tile) pairs after binning */
     uint32_t tiles_x, tiles_y;
     uint32_t tile_w, tile_h;    /* pixels per tile (one workgroup) */
+    uint64_t reruns;          /* passes of this device, so far, that were queued before their pair count was known, did
+                                 not fit the room they had been given and ran again */
 } rh_pass_stats;
 int rh_device_last_pass_stats(rh_device* dev, rh_pass_stats* out);
 

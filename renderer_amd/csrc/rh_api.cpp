@@ -333,10 +333,13 @@ int rh_buffer_create(rh_device* dev, size_t size, uint32_t usage, const void* in
     b->dev = dev; b->size = size; b->usage = usage;
     if (device_alloc(dev, size, &b->dptr)) { delete b; return 1; }
     device_retain(dev);
-    if (init && init_len) {
-        hipError_t e = hipMemcpyAsync(b->dptr, init, init_len, hipMemcpyHostToDevice, dev->stream);
-        if (e != hipSuccess) { device_free(dev, size, b->dptr); delete b; device_release(dev); return fail("rh_buffer_create: upload failed: %s", hipGetErrorString(e)); }
-    }
+    // wgpu buffers start zero-initialised, and the allocation may be a recycled one: everything the initial data does
+    // not cover is cleared (a never-set uniform, the headroom of a grown Buffer, capture rows the copy does not reach)
+    hipError_t e = hipSuccess;
+    const size_t filled = (init && init_len) ? init_len : 0;
+    if (filled) e = hipMemcpyAsync(b->dptr, init, filled, hipMemcpyHostToDevice, dev->stream);
+    if (e == hipSuccess && filled < size) e = hipMemsetAsync((uint8_t*)b->dptr + filled, 0, size - filled, dev->stream);
+    if (e != hipSuccess) { device_free(dev, size, b->dptr); delete b; device_release(dev); return fail("rh_buffer_create: initialisation failed: %s", hipGetErrorString(e)); }
     *out = b;
     return 0;
 }
@@ -884,6 +887,9 @@ int resolve_pending(rh_device* dev) {
         dev->pair_guess = std::max<uint64_t>(dev->pair_guess, std::min<uint64_t>(total + total / 4 + 4096, 0x7ffffffeull));
         return 0;
     }
+    // the attempt that wrote nothing is not a pass of its own: its timing marks go back to the pool
+    for (int k = 0; k < 3 && dev->timing && !dev->timing_events.empty(); k++) { dev->event_pool.push_back(dev->timing_events.back()); dev->timing_events.pop_back(); }
+    dev->stats.reruns++;
     return execute_pass(dev, c, false);
 }
 

@@ -483,12 +483,10 @@ size_t lz4_lds_bytes() { return sizeof(Lds); }
 
 int lz4f_compress_launch(const rh_lz4_job* d_jobs, uint32_t n_jobs, rh_lz4_stream_state* d_states, hipStream_t s) {
     if (n_jobs == 0) return 0;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rh_lz4f_compress), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lds));
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    // the attribute belongs to the current device (a process may hold several rh_device objects): set per launch, a
+    // launch is one round of packets
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rh_lz4f_compress), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lds));
+    if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(rh_lz4f_compress, dim3(n_jobs), dim3(64), sizeof(Lds), s, d_jobs, d_states);
     return (int)hipGetLastError();
 }

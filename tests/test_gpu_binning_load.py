@@ -1,0 +1,147 @@
+"""GPU parity at the binning depths the benchmark configurations reach.  The per-tile lists come out of a stable sort
+of (tile, quad) pairs by tile number; its work grows with the number of tiles (more key bits) and with the number of
+pairs, and the order it leaves inside a tile is the blend order.  Small targets exercise one sorting pass only, so
+these scenes use targets of more than 256 and more than 65536 tiles under enough pairs that every pass moves many of
+them, drawn both in the form that waits for the pair count and queued before the count is known (the second draw of a
+device).  Bar: bit-exact against the CPU oracle."""
+import numpy as np
+import pytest
+
+import scenes
+from test_gpu_parity import assert_same
+
+pytestmark = pytest.mark.gpu
+
+
+def draw_both_forms(scene, what):
+    want = scenes.draw_oracle(scene)["color"]
+    hs = scenes.HipScene(scene)
+    try:
+        hs.draw()                                   # first pass of the device: waits for its pair count
+        assert_same(hs.read_color(), want, what + " (waiting form)")
+        hs.draw()                                   # queued whole before the count is known
+        got = hs.read_color()
+        stats = hs.renderer.last_pass_stats()
+    finally:
+        hs.close()
+    assert_same(got, want, what + " (queued before the count)")
+    return stats
+
+
+def test_100k_alpha_quads_on_1024_tiles(oracle):
+    """2048x1024 target (32 x 32 tiles of 64x32): tile numbers need 10 bits; ~12 layers of pre-multiplied alpha, so
+    every pixel depends on the order of its quads."""
+    scene = scenes.random_quads_scene(100_000, 16, 2048, 1024, seed=101)
+    stats = draw_both_forms(scene, "100k quads / 1024 tiles")
+    assert stats["tiles_x"] * stats["tiles_y"] > 256 and stats["bin_entries"] > 100_000
+
+
+@pytest.mark.parametrize("blend", ["additive", "premultiplied"])
+def test_300k_tiny_quads_at_4k(oracle, blend):
+    """BASELINE configs[2] shape at a size the oracle draws in a second: 2..8 px quads at 3840x2160 (4080 tiles, 12 bits);
+    additive as the configuration has it, and pre-multiplied so that the order inside a tile shows."""
+    scene = scenes.tiny_quads_scene(300_000, 3840, 2160, seed=102)
+    scene["blend"] = blend
+    stats = draw_both_forms(scene, f"300k tiny quads at 4K / {blend}")
+    assert stats["tiles_x"] * stats["tiles_y"] == 60 * 68
+
+
+def test_headline_shape_200k_quads_at_4k(oracle):
+    """BASELINE configs[1] shape with a fifth of the quads: 16 px quads, pre-multiplied alpha, linear filter, 4K."""
+    scene = scenes.random_quads_scene(200_000, 16, 3840, 2160, seed=103)
+    stats = draw_both_forms(scene, "200k quads at 4K")
+    assert stats["bin_entries"] > 200_000
+
+
+def test_more_than_65536_tiles(oracle):
+    """16384 x 8224 target: 256 x 257 = 65792 tiles, tile numbers need 17 bits (BASELINE configs[3] has 16384^2)."""
+    scene = scenes.random_quads_scene(6000, 48, 16384, 8224, seed=104)
+    # a few columns of overlapping quads so that some tiles hold deep, order-sensitive lists
+    rng = np.random.default_rng(104)
+    stack = scene["instances"][:1500]
+    stack[:, 0] = (rng.integers(0, 4, 1500) * 0.5 - 0.75 + rng.uniform(-0.004, 0.004, 1500)).astype(np.float32)
+    stats = draw_both_forms(scene, "65792 tiles")
+    assert stats["tiles_x"] * stats["tiles_y"] > 65536
+
+
+def tiny_then(r, W, H):
+    """Leaves the device with the smallest room it ever gives the pair arrays of a queued pass."""
+    tiny = scenes.random_quads_scene(40, 12, W, H, seed=1)
+    hs = scenes.HipScene(tiny, renderer=r)
+    hs.draw(); hs.draw()
+    assert_same(hs.read_color(), scenes.draw_oracle(tiny)["color"], "tiny scene")
+    return hs
+
+
+def test_pass_that_did_not_fit_runs_again_load_additive_recording(oracle):
+    """A dense pass queued with the room of a tiny predecessor: its pairs do not fit, its kernels must write NOTHING
+    (the colour target is loaded, not cleared, and blended additively: one stray write would show), and the pass runs
+    again; the recording attachment rides along."""
+    from renderer_amd import Renderer
+    W, H = 640, 360
+    r = Renderer(W, H)
+    try:
+        tiny_then(r, W, H)
+        before = r.last_pass_stats()["reruns"]
+        scene = scenes.random_quads_scene(40_000, 12, W, H, seed=2, blend="additive", clear=None)
+        scene["record"] = True
+        scene["record_clear"] = (0.0, 0.0, 0.0, 1.0)
+        init = np.random.default_rng(3).integers(0, 120, (H, W, 4), dtype=np.uint8)
+        want = scenes.draw_oracle(scene, initial=init)
+        hs = scenes.HipScene(scene, renderer=r)
+        hs.set_initial(init)
+        r.set_timing(True); r.drain_timings()
+        hs.draw()
+        timings = r.drain_timings(); r.set_timing(False)
+        stats = r.last_pass_stats()
+        assert stats["reruns"] == before + 1 and stats["bin_entries"] > 40_000
+        assert timings["passes"] == 1               # the attempt that wrote nothing is not counted as a pass
+        assert_same(hs.read_color(), want["color"], "loaded additive target after the re-run")
+        assert_same(hs.read_recording(), want["recording"], "recording attachment after the re-run")
+    finally:
+        r.close()
+
+
+def test_pass_that_did_not_fit_runs_again_multisampled(oracle):
+    from renderer_amd import Renderer
+    W, H = 333, 217
+    r = Renderer(W, H)
+    try:
+        tiny_then(r, W, H)
+        before = r.last_pass_stats()["reruns"]
+        scene = scenes.random_quads_scene(30_000, 12, W, H, seed=5, blend="additive", clear=None)
+        scene["samples"] = 4
+        junk = np.full((H, W, 4), 77, dtype=np.uint8)
+        want = scenes.draw_oracle(scene, initial=junk)          # Load continues from the (zeroed) multisampled texture
+        hs = scenes.HipScene(scene, renderer=r)
+        hs.set_initial(junk)
+        hs.draw()
+        assert r.last_pass_stats()["reruns"] == before + 1
+        assert_same(hs.pipeline.msaa_texture.read().reshape(H, W * 4, 4), want["msaa"].reshape(H, W * 4, 4), "samples after the re-run")
+        assert_same(hs.read_color(), want["color"], "resolve after the re-run")
+    finally:
+        r.close()
+
+
+def test_unset_and_oversized_instance_buffers_read_zeros(oracle):
+    """wgpu zero-initialises buffers: instances beyond the uploaded data (the headroom a grown Buffer keeps,
+    reference src/buffer.rs:57-67) and a buffer that was never set read as zeros, also when the allocation is a
+    recycled one."""
+    from renderer_amd import Renderer
+    W, H = 320, 200
+    r = Renderer(W, H)
+    try:
+        # fill the allocation cache with junk-holding blocks of the sizes the instanced buffer will ask for
+        junk_scene = scenes.random_quads_scene(100, 12, W, H, seed=9)
+        for _ in range(2):
+            hs = scenes.HipScene(junk_scene, renderer=r)
+            hs.draw()
+            r.synchronize()
+        scene = scenes.random_quads_scene(100, 12, W, H, seed=10)
+        hs = scenes.HipScene(scene, renderer=r)
+        hs.count = (120, 4)                         # 20 instances past the uploaded 100: still inside the 2048-byte buffer
+        hs.draw()
+        padded = dict(scene, instances=np.concatenate([scene["instances"], np.zeros((20, 2), dtype=np.float32)]))
+        assert_same(hs.read_color(), scenes.draw_oracle(padded)["color"], "instances past the data read zeros")
+    finally:
+        r.close()

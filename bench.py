@@ -93,6 +93,9 @@ def main():
     ap.add_argument("--workload", choices=["c1", "c2"], default="c1",
                     help="c1 (headline): --quads quads of --side px, alpha blend; c2: --quads quads of 2..8 px, additive")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--texture-size", type=int, default=0,
+                    help="experiment: sample an NxN subsampling of the texture instead of the 256x256 original")
+    ap.add_argument("--filter", choices=["linear", "nearest"], default="linear", help="experiment: sampler filter (headline: linear)")
     ap.add_argument("--capture-frames", type=int, default=-1,
                     help="frames of the recorded-frames/s leg (BASELINE.json configs[4] shape, per GPU); 0 skips it; "
                          "default: 512 frames into 256 streams, or less when the ranks of this host would not find "
@@ -104,7 +107,7 @@ def main():
 
     capture_auto = args.capture_frames < 0 and args.capture_streams < 0      # sized below, once the ranks can agree
     capture_warm_rounds = 1
-    default_workload = (args.workload, args.quads, args.side, args.width, args.height) == ("c1", 1_000_000, 16, 3840, 2160)
+    default_workload = (args.workload, args.quads, args.side, args.width, args.height, args.texture_size, args.filter) == ("c1", 1_000_000, 16, 3840, 2160, 0, "linear")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -133,7 +136,10 @@ def main():
     if args.workload == "c2":
         scene = scenes.tiny_quads_scene(args.quads, args.width, args.height, seed=2 + rank)
     else:
-        scene = scenes.random_quads_scene(args.quads, args.side, args.width, args.height, seed=1 + rank)
+        scene = scenes.random_quads_scene(args.quads, args.side, args.width, args.height, seed=1 + rank, filter=args.filter)
+        if args.texture_size:
+            step = max(1, 256 // args.texture_size)
+            scene["texture"] = np.ascontiguousarray(scene["texture"][::step, ::step][:args.texture_size, :args.texture_size])
     renderer = Renderer(args.width, args.height, hip_ordinal=local_rank)
     hs = scenes.HipScene(scene, renderer=renderer)
 

@@ -4,7 +4,7 @@
 #pragma once
 #include <stdint.h>
 
-#define RH_DEVICE_ABI_VERSION 9u
+#define RH_DEVICE_ABI_VERSION 10u
 #define RH_MODULE_MAGIC 0x52484d4fu   // "RHMO"
 
 #define RH_DEV_MAX_ATTRIBUTES 8
@@ -13,12 +13,13 @@
 
 // Rasteriser geometry
 #define RH_SUBPIXEL_BITS 8
-#define RH_TILE_W 64               // screen tile in pixels (one workgroup per tile; each of its four wavefronts
-#define RH_TILE_H 32               // owns a 32x16 region of it)
-#ifndef RH_BATCH_CLUSTERS
-#define RH_BATCH_CLUSTERS 64       // clusters (triangle pairs) set up per batch inside a tile workgroup
+#define RH_TILE_W 32               // screen tile in pixels: one wavefront (a workgroup of its own) shades a tile from its
+#define RH_TILE_H 32               // list of set-up records; no two waves share pixels, so a tile needs no barrier
+#define RH_TILE_THREADS 64
+#ifndef RH_ROUND_HITS
+#define RH_ROUND_HITS 32           // set-up records a tile wave brings into LDS at a time
 #endif
-#define RH_TILE_THREADS 256
+#define RH_MS_EXTRA_WORDS(S) (12 + 6 * (S))   // dwords a multisampled pass adds to an extended record (S samples)
 
 enum { RH_MODULE_STAGE_VERTEX = 1, RH_MODULE_STAGE_FRAGMENT = 2 };
 
@@ -30,7 +31,8 @@ struct rh_module_info_t {
     uint32_t n_varyings;     // floats interpolated per fragment
     uint32_t n_outputs;      // colour outputs the fragment function writes
     uint32_t vertex_tag;     // hash of the vertex function's source name: ties a fragment object to its vertex object
-    uint32_t reserved[2];
+    uint32_t rec_bytes;      // fragment objects: bytes of one set-up record (depends on the number of varyings)
+    uint32_t ext_bytes;      // fragment objects: bytes of one extended record of a single-sampled pass
 };
 
 struct rh_slot_dev {
@@ -69,6 +71,21 @@ struct rh_bin_count_args {
     uint32_t* block_sums;       // [ceil(n_clusters / 256)]
 };
 
+// Triangle set-up (its own launch, one thread per (tile, cluster) pair of the sorted pair array): runs the vertex
+// function for the cluster's vertices and writes the pair's record: what a fragment needs to find its pixels and its
+// varyings, relative to the pair's tile.  Records are in list order, so a tile reads its records as one contiguous run.
+struct rh_setup_args {
+    rh_draw_params p;
+    const uint32_t* clusters;   // [pairs] cluster of every pair, sorted by (tile, cluster)
+    const uint32_t* tiles;      // [pairs] tile of every pair
+    uint8_t* rec;               // [pairs][rec_bytes]: bounding box, flags, shared diagonal, plane equations
+    uint8_t* ext;               // [pairs][ext_bytes]: edge functions and 1/w planes (written for the clusters that need
+                                // them) and, in a multisampled pass, the per-sample edge constants
+    uint32_t ext_bytes;
+    uint32_t n_pairs;           // pairs, or the room for them when `pair_total` is set
+    const unsigned long long* pair_total;
+};
+
 struct rh_attach_dev {
     uint8_t* ptr;               // texel (0,0)
     uint32_t pitch_px;          // row pitch in pixels
@@ -85,7 +102,9 @@ struct rh_attach_dev {
 
 struct rh_tile_args {
     rh_draw_params p;
-    const uint32_t* list;       // cluster ids sorted by (tile, cluster)
+    const uint8_t* rec;         // set-up records of the sorted pairs (rh_setup_args::rec)
+    const uint8_t* ext;
+    uint32_t ext_bytes;
     const uint32_t* tile_start; // [tiles]
     const uint32_t* tile_end;   // [tiles]
     rh_attach_dev att[RH_DEV_MAX_TARGETS];
@@ -93,7 +112,7 @@ struct rh_tile_args {
     uint32_t src_factor, dst_factor;
     // Which specialisation of the kernel body to run: 0 = every state read at run time; otherwise
     // 1 + (blend_class - 1) * 2 + (texture_class - 1) with blend_class 1 = (One, OneMinusSrcAlpha), 2 = (One, One) and
-    // texture_class 1 = every bound texture RGBA8 at least 2x2 with linear samplers, 2 = the same with nearest samplers.
+    // texture_class 1 = every bound texture RGBA8, at least 2x2 and at most 16 MiB, with linear samplers, 2 = the same with nearest samplers.
     uint32_t variant;
     // The pass may be queued before the host knows how many (tile, cluster) pairs it has: the kernels size their work
     // from *pair_total, and when that exceeds `pair_capacity` (the room the host gave the pair arrays) nobody writes

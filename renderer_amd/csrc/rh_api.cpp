@@ -71,6 +71,7 @@ struct rh_device {
     std::string name;
     // scratch for binning
     Scratch ranges, block_sums, chunk_tmp, keys_a, vals_a, keys_b, vals_b, hist, tile_start;
+    Scratch rec, ext;                              // set-up records of the sorted (tile, cluster) pairs
     Scratch png_slots, png_rows, png_out;          // GPU PNG encoder scratch
     void* png_host = nullptr; size_t png_host_cap = 0;   // pinned
     unsigned long long* d_total = nullptr;
@@ -121,6 +122,7 @@ struct rh_module {
     hipModule_t module = nullptr;
     rh_module_info_t info{};
     hipFunction_t bin_count = nullptr;
+    hipFunction_t setup[4] = {nullptr, nullptr, nullptr, nullptr};   // 1, 2, 4, 8 samples
     hipFunction_t tile[RH_MAX_COLOR_TARGETS] = {nullptr, nullptr, nullptr, nullptr};
     hipFunction_t tile_ms[3] = {nullptr, nullptr, nullptr};        // 2, 4, 8 samples
     hipFunction_t tile_wide[RH_MAX_COLOR_TARGETS] = {nullptr, nullptr, nullptr, nullptr};   // passes with a float attachment
@@ -261,7 +263,7 @@ void device_release(rh_device* dev) {
     (void)hipSetDevice(dev->ordinal);
     (void)hipStreamSynchronize(dev->stream);
     Scratch* all[] = { &dev->ranges, &dev->block_sums, &dev->chunk_tmp, &dev->keys_a, &dev->vals_a, &dev->keys_b, &dev->vals_b,
-                       &dev->hist, &dev->tile_start, &dev->png_slots, &dev->png_rows, &dev->png_out };
+                       &dev->hist, &dev->tile_start, &dev->rec, &dev->ext, &dev->png_slots, &dev->png_rows, &dev->png_out };
     for (Scratch* s : all) s->release();
     for (hipEvent_t e : dev->event_pool) (void)hipEventDestroy(e);
     for (hipEvent_t e : dev->timing_events) (void)hipEventDestroy(e);
@@ -527,6 +529,10 @@ int rh_module_load(rh_device* dev, const void* code_object, size_t size, rh_modu
         const char* wide_names[RH_MAX_COLOR_TARGETS] = { "rh_tile_w1", "rh_tile_w2", "rh_tile_w3", "rh_tile_w4" };
         for (int i = 0; i < RH_MAX_COLOR_TARGETS; i++)
             if (hipModuleGetFunction(&m->tile_wide[i], m->module, wide_names[i]) != hipSuccess) { (void)hipModuleUnload(m->module); delete m; return fail("rh_module_load: fragment code object lacks %s", wide_names[i]); }
+        const char* setup_names[4] = { "rh_setup", "rh_setup_ms2", "rh_setup_ms4", "rh_setup_ms8" };
+        for (int i = 0; i < 4; i++)
+            if (hipModuleGetFunction(&m->setup[i], m->module, setup_names[i]) != hipSuccess) { (void)hipModuleUnload(m->module); delete m; return fail("rh_module_load: fragment code object lacks %s", setup_names[i]); }
+        if (m->info.rec_bytes == 0 || m->info.rec_bytes % 16 || m->info.ext_bytes % 16) { (void)hipModuleUnload(m->module); delete m; return fail("rh_module_load: fragment code object declares a malformed record size"); }
         const char* ms_names[3] = { "rh_tile_ms2", "rh_tile_ms4", "rh_tile_ms8" };
         for (int i = 0; i < 3; i++)
             if (hipModuleGetFunction(&m->tile_ms[i], m->module, ms_names[i]) != hipSuccess) { (void)hipModuleUnload(m->module); delete m; return fail("rh_module_load: fragment code object lacks %s", ms_names[i]); }
@@ -710,9 +716,9 @@ int timing_mark(rh_device* dev) {
     return 0;
 }
 
-int launch_module_kernel(hipFunction_t fn, uint32_t grid, void* args, size_t args_size, hipStream_t s) {
+int launch_module_kernel(hipFunction_t fn, uint32_t grid, uint32_t block, void* args, size_t args_size, hipStream_t s) {
     void* config[] = { HIP_LAUNCH_PARAM_BUFFER_POINTER, args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &args_size, HIP_LAUNCH_PARAM_END };
-    RH_HIP(hipModuleLaunchKernel(fn, grid, 1, 1, 256, 1, 1, 0, s, nullptr, config));
+    RH_HIP(hipModuleLaunchKernel(fn, grid, 1, 1, block, 1, 1, 0, s, nullptr, config));
     return 0;
 }
 
@@ -779,7 +785,9 @@ int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer) {
     uint64_t total = 0;                          // pairs, or the room for them when the count has not come back yet
     bool deferred = false;
     const unsigned long long* pair_total = nullptr;
-    uint32_t* sorted_vals = nullptr;
+    const int ms_index = pl->samples == 1 ? 0 : (pl->samples == 2 ? 1 : (pl->samples == 4 ? 2 : 3));
+    const uint32_t rec_bytes = pl->fs->info.rec_bytes;
+    const uint32_t ext_bytes = pl->fs->info.ext_bytes + (pl->samples > 1 ? 4u * RH_MS_EXTRA_WORDS(pl->samples) : 0u);
     if (timing_mark(dev)) return 1;
     if (n_clusters > 0) {
         const uint32_t n_blocks = (n_clusters + 255) / 256;
@@ -788,7 +796,7 @@ int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer) {
         rh_bin_count_args ba;
         ba.p = p; ba.p.n_clusters = n_clusters;
         ba.ranges = dev->ranges.as<rh_tile_range>(); ba.block_sums = dev->block_sums.as<uint32_t>();
-        if (launch_module_kernel(pl->vs->bin_count, n_blocks, &ba, sizeof ba, s)) return 1;
+        if (launch_module_kernel(pl->vs->bin_count, n_blocks, 256, &ba, sizeof ba, s)) return 1;
         rhk::exclusive_scan(dev->block_sums.as<uint32_t>(), n_blocks, dev->chunk_tmp.as<uint32_t>(), dev->d_total, s, dev->general_kernels != 0);
         RH_HIP(hipMemcpyAsync(dev->h_total, dev->d_total, 8, hipMemcpyDeviceToHost, s));
         // Once a pass has been seen the rest is queued without waiting for the count, with room for `pair_guess`
@@ -815,8 +823,17 @@ int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer) {
             int where = rhk::radix_sort_pairs(dev->keys_a.as<uint32_t>(), dev->vals_a.as<uint32_t>(), dev->keys_b.as<uint32_t>(), dev->vals_b.as<uint32_t>(),
                                               n, bits_for(n_tiles), dev->hist.as<uint32_t>(), dev->chunk_tmp.as<uint32_t>(), s, dev->general_kernels != 0, pair_total);
             uint32_t* sorted_keys = where ? dev->keys_b.as<uint32_t>() : dev->keys_a.as<uint32_t>();
-            sorted_vals = where ? dev->vals_b.as<uint32_t>() : dev->vals_a.as<uint32_t>();
+            uint32_t* sorted_vals = where ? dev->vals_b.as<uint32_t>() : dev->vals_a.as<uint32_t>();
             rhk::tile_ranges(sorted_keys, n, tile_start, tile_end, n_tiles, s, pair_total);
+            // triangle set-up: one record per pair, in list order
+            if (dev->rec.ensure((size_t)n * rec_bytes) || dev->ext.ensure((size_t)n * ext_bytes)) return 1;
+            rh_setup_args sa;
+            memset(&sa, 0, sizeof sa);
+            sa.p = p; sa.p.n_clusters = n_clusters;
+            sa.clusters = sorted_vals; sa.tiles = sorted_keys;
+            sa.rec = dev->rec.as<uint8_t>(); sa.ext = dev->ext.as<uint8_t>(); sa.ext_bytes = ext_bytes;
+            sa.n_pairs = n; sa.pair_total = pair_total;
+            if (launch_module_kernel(pl->fs->setup[ms_index], (n + 255) / 256, 256, &sa, sizeof sa, s)) return 1;
         }
     }
     if (total == 0) {
@@ -826,7 +843,8 @@ int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer) {
     rh_tile_args ta;
     memset(&ta, 0, sizeof ta);
     ta.p = p; ta.p.n_clusters = n_clusters;
-    ta.list = sorted_vals; ta.tile_start = tile_start; ta.tile_end = tile_end;
+    ta.rec = dev->rec.as<uint8_t>(); ta.ext = dev->ext.as<uint8_t>(); ta.ext_bytes = ext_bytes;
+    ta.tile_start = tile_start; ta.tile_end = tile_end;
     ta.pair_total = pair_total; ta.pair_capacity = (uint32_t)total;
     ta.n_att = (uint32_t)c.attachments.size();
     bool any_clear = false;
@@ -846,7 +864,8 @@ int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer) {
         else if (ta.src_factor == RH_BLEND_ONE && ta.dst_factor == RH_BLEND_ONE) blend_class = 2;
         bool all_rgba8 = true, any_linear = false, any_nearest = false;
         for (const SlotRef& sl : pl->slots) {
-            if (sl.kind == RH_SLOT_TEXTURE && (sl.tex->format != RH_FORMAT_RGBA_U8 || sl.tex->width < 2 || sl.tex->height < 2)) all_rgba8 = false;
+            // (the specialised bodies compute texel offsets in f32: exact up to 16 MiB of texels)
+            if (sl.kind == RH_SLOT_TEXTURE && (sl.tex->format != RH_FORMAT_RGBA_U8 || sl.tex->width < 2 || sl.tex->height < 2 || sl.tex->bytes > ((size_t)1 << 24))) all_rgba8 = false;
             if (sl.kind == RH_SLOT_SAMPLER) { if (sl.filter == RH_FILTER_LINEAR) any_linear = true; else any_nearest = true; }
         }
         if (all_rgba8 && !(any_linear && any_nearest)) tex_class = any_nearest ? 2 : 1;
@@ -855,13 +874,13 @@ int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer) {
     if (timing_mark(dev)) return 1;
     if (pl->samples > 1) {
         // every tile runs: the resolve rewrites the whole target from the multisampled texture (Load included)
-        hipFunction_t fn = pl->fs->tile_ms[pl->samples == 2 ? 0 : (pl->samples == 4 ? 1 : 2)];
-        if (n_launch_tiles > 0 && launch_module_kernel(fn, n_launch_tiles, &ta, sizeof ta, s)) return 1;
+        hipFunction_t fn = pl->fs->tile_ms[ms_index - 1];
+        if (n_launch_tiles > 0 && launch_module_kernel(fn, n_launch_tiles, RH_TILE_THREADS, &ta, sizeof ta, s)) return 1;
     } else if ((total > 0 || any_clear) && n_launch_tiles > 0) {
         bool any_float = false;
         for (const rh_attachment_desc& a : c.attachments) any_float = any_float || a.texture->format == RH_FORMAT_RGBA_F16 || a.texture->format == RH_FORMAT_RGBA_F32;
         hipFunction_t fn = any_float ? pl->fs->tile_wide[c.attachments.size() - 1] : pl->fs->tile[c.attachments.size() - 1];
-        if (launch_module_kernel(fn, n_launch_tiles, &ta, sizeof ta, s)) return 1;
+        if (launch_module_kernel(fn, n_launch_tiles, RH_TILE_THREADS, &ta, sizeof ta, s)) return 1;
     }
     if (timing_mark(dev)) return 1;
 

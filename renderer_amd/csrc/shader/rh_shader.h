@@ -33,9 +33,20 @@ typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));   // 
 
 RH_DEVICE v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 
+// Byte k of a dword as f32 (exact).  Written as the instruction itself: left to the compiler, a difference of two
+// converted bytes becomes an integer subtraction plus a conversion, two instructions outside the f32 add/mul/fma
+// class.  A SIMD issues one instruction of that class beside one of any other kind (from two different waves), so the
+// count outside the class is what bounds the shading pass; the values are the same either way.
+RH_DEVICE float ubyte0(uint32_t v) { float r; asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(r) : "v"(v)); return r; }
+RH_DEVICE float ubyte1(uint32_t v) { float r; asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(r) : "v"(v)); return r; }
+RH_DEVICE float ubyte2(uint32_t v) { float r; asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(r) : "v"(v)); return r; }
+RH_DEVICE float ubyte3(uint32_t v) { float r; asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(r) : "v"(v)); return r; }
+// clamp(x, lo, hi) in one instruction; a NaN x gives lo (as fminf(fmaxf(x, lo), hi) does)
+RH_DEVICE float clampf(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
+
 struct Texture2D {
     const uint8_t* data; uint32_t width, height, layers, format;
-    uint32_t static_rgba8;      // 1: known to be RGBA8 and at least 2x2
+    uint32_t static_rgba8;      // 1: known to be RGBA8, at least 2x2 and at most 16 MiB (texel offsets exact in f32)
 
     // Texel (x, y) of `layer` (generic path, any supported format): 8-bit channels on the 0..255 scale, float channels
     // as they are (a half converts to float exactly).
@@ -76,34 +87,38 @@ struct Texture2D {
             return make_float4(c.x * scale, c.y * scale, c.z * scale, c.w * scale);
         }
         const float u = __builtin_fmaf(uv.x, (float)W, -0.5f), v = __builtin_fmaf(uv.y, (float)H, -0.5f);
-        const float ibf = floorf(fminf(fmaxf(u, 0.0f), (float)(W >= 2 ? W - 2 : 0)));
-        const float jbf = floorf(fminf(fmaxf(v, 0.0f), (float)(H >= 2 ? H - 2 : 0)));
-        const float a = fminf(fmaxf(u - ibf, 0.0f), 1.0f), b = fminf(fmaxf(v - jbf, 0.0f), 1.0f);
-        const int ib = (int)ibf, jb = (int)jbf;
-        float4 t00, t10, t01, t11;
+        const float ibf = floorf(clampf(u, 0.0f, (float)(W >= 2 ? W - 2 : 0)));
+        const float jbf = floorf(clampf(v, 0.0f, (float)(H >= 2 ? H - 2 : 0)));
+        const float a = clampf(u - ibf, 0.0f, 1.0f), b = clampf(v - jbf, 0.0f, 1.0f);
+        float4 r;
         if (static_rgba8 || ((format == FORMAT_RGBA_U8 || format == FORMAT_BGRA_U8) && W >= 2 && H >= 2)) {
             // 4-byte texels: the taps of a row are adjacent and the rows are one pitch apart: two 8-byte loads
-            const uint32_t off = (__umul24(layer * height + (uint32_t)jb, width) + (uint32_t)ib) << 2;
+            uint32_t off;
+            if (static_rgba8) off = layer * (height * (width << 2)) + (uint32_t)__builtin_fmaf(jbf, (float)(W << 2), ibf * 4.0f);   // exact: below 2^24
+            else off = (__umul24(layer * height + (uint32_t)(int)jbf, width) + (uint32_t)(int)ibf) << 2;
             const u32x2_a4 r0 = *reinterpret_cast<const u32x2_a4*>(data + off);
             const u32x2_a4 r1 = *reinterpret_cast<const u32x2_a4*>(data + (width << 2) + off);
-#define RH_UNPACK(t) make_float4((float)((t) & 0xffu), (float)(((t) >> 8) & 0xffu), (float)(((t) >> 16) & 0xffu), (float)((t) >> 24))
-            t00 = RH_UNPACK(r0.x); t10 = RH_UNPACK(r0.y); t01 = RH_UNPACK(r1.x); t11 = RH_UNPACK(r1.y);
-#undef RH_UNPACK
+#define RH_LERP_BYTE(ch, UB) { const float p00 = UB(r0.x), p10 = UB(r0.y), p01 = UB(r1.x), p11 = UB(r1.y); \
+                               const float top = __builtin_fmaf(a, p10 - p00, p00); \
+                               const float bot = __builtin_fmaf(a, p11 - p01, p01); \
+                               r.ch = __builtin_fmaf(b, bot, __builtin_fmaf(-b, top, top)) * scale; }
+            RH_LERP_BYTE(x, ubyte0) RH_LERP_BYTE(y, ubyte1) RH_LERP_BYTE(z, ubyte2) RH_LERP_BYTE(w, ubyte3)
+#undef RH_LERP_BYTE
         } else {
+            const int ib = (int)ibf, jb = (int)jbf;
             const int i1 = min(ib + 1, W - 1), j1 = min(jb + 1, H - 1);
-            t00 = fetch(ib, jb, layer); t10 = fetch(i1, jb, layer); t01 = fetch(ib, j1, layer); t11 = fetch(i1, j1, layer);
+            float4 t00 = fetch(ib, jb, layer), t10 = fetch(i1, jb, layer), t01 = fetch(ib, j1, layer), t11 = fetch(i1, j1, layer);
             if (format == FORMAT_BGRA_U8) {       // fetch() already swizzled: undo so that the common swizzle below applies
                 float x;
                 x = t00.x; t00.x = t00.z; t00.z = x; x = t10.x; t10.x = t10.z; t10.z = x;
                 x = t01.x; t01.x = t01.z; t01.z = x; x = t11.x; t11.x = t11.z; t11.z = x;
             }
-        }
-        float4 r;
 #define RH_LERP2(ch) { const float top = __builtin_fmaf(a, t10.ch - t00.ch, t00.ch); \
                        const float bot = __builtin_fmaf(a, t11.ch - t01.ch, t01.ch); \
                        r.ch = __builtin_fmaf(b, bot, __builtin_fmaf(-b, top, top)) * scale; }
-        RH_LERP2(x) RH_LERP2(y) RH_LERP2(z) RH_LERP2(w)
+            RH_LERP2(x) RH_LERP2(y) RH_LERP2(z) RH_LERP2(w)
 #undef RH_LERP2
+        }
         if (format == FORMAT_BGRA_U8) return make_float4(r.z, r.y, r.x, r.w);
         return r;
     }

@@ -1,31 +1,32 @@
 // Fragment-stage code object: compiled once per (vertex source, fragment source) pair with
 //     hipcc --genco --offload-arch=gfx950 -ffp-contract=off -DRH_VERTEX_SOURCE=... -DRH_FRAGMENT_SOURCE=... rh_stage_fragment.hip
-// Exports rh_tile_<A> (A = 1..4 colour attachments): one workgroup per 64x32 screen tile, one wavefront per 32x16
-// region of it.
-//
-// Per tile:
-//   1. the tile's pixels are brought into LDS (cleared, or loaded with coalesced row reads), one u32 RGBA8 per pixel,
-//      region by region;
-//   2. the tile's ordered cluster list is walked in batches of RH_BATCH_CLUSTERS clusters (a cluster = two consecutive
-//      triangles of one instance, i.e. one quad of a 4-vertex strip).  Threads set clusters up (vertex function, snap,
-//      edge equations with the top-left rule folded into the constant, varying plane equations) into LDS records.
-//      Then every wave walks the batch for its own region: lanes test one cluster each against the region (ballot);
-//      the set bits are visited in ascending order -- which is primitive order.  For every hit the pixels of
-//      (cluster bounding box intersected with the region) are packed linearly onto the lanes, 64 per pass, so small
-//      primitives keep most lanes busy.  A lane evaluates the coverage of both triangles, shades once with the plane
-//      equations of the triangle that covers its pixel, and blends into the LDS pixel (read, blend, re-quantise to
-//      UNORM8, write).  If any pixel of a pass is covered by both triangles of the cluster (overlapping / bow-tie
-//      geometry) the two triangles are shaded one after the other instead.  A region belongs to exactly one wave and
-//      a wave's LDS operations complete in order, so every pixel sees its fragments in primitive order;
-//   3. the tile is written back with coalesced row stores (RGBA or BGRA).
+// Exports
+//   rh_setup (rh_setup_ms2/4/8 for multisampled passes): triangle set-up, one thread per (tile, cluster) pair of the
+//     sorted pair array.  A cluster is two consecutive triangles of one instance, i.e. one quad of a 4-vertex strip.
+//     The thread runs the vertex function for the cluster's vertices, snaps them, and writes the pair's record relative
+//     to the pair's 32x32 tile: clipped bounding box, flags, plane equations of the varyings and -- for clusters that
+//     are not axis-aligned rectangles -- the edge functions with the top-left rule folded into the constant.
+//   rh_tile_<A> (A = 1..4 colour attachments; rh_tile_w<A> when an attachment is RGBA16F/RGBA32F; rh_tile_ms<S>):
+//     ONE WAVEFRONT per 32x32 tile (a workgroup of 64 threads).  Per tile:
+//       1. the tile's pixels are brought into LDS (cleared, or loaded with coalesced row reads), one u32 RGBA8 per pixel;
+//       2. the tile's records are walked in submission order, RH_ROUND_HITS at a time through a small LDS staging area.
+//          For every record the pixels of its box are packed linearly onto the lanes, 64 per pass; a lane finds the
+//          triangle that covers its pixel, evaluates the plane equations, runs the fragment function and blends into
+//          its LDS pixel (read, blend, re-quantise to UNORM8, write).  A tile belongs to one wave and a wave's LDS
+//          operations complete in order, so every pixel sees its fragments in primitive order without any barrier;
+//       3. the tile is written back with coalesced row stores (RGBA or BGRA).
+//     Nothing in a tile waits for another wave: there is no workgroup barrier in the kernel, every lane of the set-up
+//     launch has a pair of its own, and a quad is cut into pieces only where it crosses a tile border.
 //
 // The kernel body exists in several specialisations (template parameters BLEND and TEX, selected per launch by
 // rh_tile_args::variant): with the blend factors and the texture format / filter known at compile time the per-fragment
 // branches on pipeline state fold away; variant 0 reads every state at run time.
 //
-// Cost model this is written against (measured on MI355X): f32 add/mul/fma issue in 2 cycles per wave64, every other
-// VALU instruction (integer, logic, conversion, packed f32) in about 4.  Hence coverage is evaluated in f32 where that
-// is exact, and integer work per fragment is kept to the byte unpacks and the final pack.
+// Cost model this is written against (measured on MI355X, tools/probe_valu4.hip, tools/probe_pass.hip): a wave issues
+// one vector instruction per ~4.3 cycles; a SIMD overlaps instructions of two different waves when at least one of them
+// is an f32 add/mul/fma, at ~2.4 cycles per instruction overall, while instructions of every other kind (integer,
+// logic, conversions, min/max/med3, compares) go one at a time at ~4.2 cycles.  Hence per-fragment work is kept in the
+// f32 add/mul/fma class where that is exact, and everything else is counted.
 #include "rh_shader.h"
 #include RH_VERTEX_SOURCE
 #include RH_FRAGMENT_SOURCE
@@ -35,41 +36,59 @@
 #error "the fragment source must define RH_FRAGMENT_OUTPUTS (number of colour outputs it writes)"
 #endif
 
-extern "C" __device__ const rh_module_info_t rh_module_info = {
-    RH_MODULE_MAGIC, RH_DEVICE_ABI_VERSION, RH_MODULE_STAGE_FRAGMENT, (uint32_t)rh::N_VARYINGS, (uint32_t)RH_FRAGMENT_OUTPUTS,
-    rh::fnv1a(RH_VERTEX_TAG), { 0u, 0u }
-};
-
-// 8 waves per SIMD (64 VGPRs): measured 10 % faster than 5 waves at 85 VGPRs despite a few spilled setup values.
-#ifndef RH_TILE_MIN_WAVES
-#define RH_TILE_MIN_WAVES 8
-#endif
-static_assert(RH_BATCH_CLUSTERS % 64 == 0 && RH_BATCH_CLUSTERS <= 256, "a batch is walked in rounds of 64 clusters; a cluster index fits 8 bits");
-
 namespace rh {
 
 constexpr int NV = N_VARYINGS;
-constexpr int REGION_W = RH_TILE_W / 2, REGION_H = RH_TILE_H / 2;     // a wave owns a 32x16 pixel region of the tile
-constexpr int REGION_STRIDE = REGION_W * REGION_H + 16;                // dwords per region in LDS
-static_assert(RH_TILE_THREADS == 256 && REGION_W == 32 && RH_TILE_W <= 128 && RH_TILE_H <= 128, "four waves, 2x2 regions, 8-bit tile-relative boxes");
+constexpr int TILE = RH_TILE_W, TILE_PX = RH_TILE_W * RH_TILE_H;
+constexpr int ROUND = RH_ROUND_HITS;
+static_assert(RH_TILE_W == 32 && RH_TILE_H == 32 && RH_TILE_THREADS == 64, "one wavefront per 32x32 tile; 8-bit tile-relative boxes");
+static_assert(ROUND == 16 || ROUND == 32 || ROUND == 64, "a round is at most one hit per lane");
+
+// ---- record layout (dwords) -------------------------------------------------------------------------------------------
+// Set-up record, staged through LDS by the tile wave:
+//   [0] box x0 | y0 << 8 | x1 << 16 | y1 << 24 (tile-relative, inclusive; BBOX_EMPTY: contributes nothing)
+//   [1] flags   [2..4] shared diagonal of a rectangle (edge 1 of triangle A): A, B, T   [5..7] unused
+//   then per triangle TRI_WORDS: XR, YR (reference vertex in 24.8 fixed point relative to the tile origin, as f32, exact),
+//   v0[NV], dvdx[NV], dvdy[NV] (gradients per 1/256 pixel)
+// Extended record (global memory, read only by the clusters that need it), per triangle EXT_TRI_WORDS:
+//   A[3], B[3], T[3]: edge e is inside <=> A*lx + B*ly + T >= 0 at tile-relative pixel (lx, ly), as f32 or (FLAG_BIG) i32
+//   q0, qx, qy: the 1/w plane of a perspective triangle
+// followed in a multisampled pass by RH_MS_EXTRA_WORDS(S) dwords: MsRecord<S>.
+constexpr int HDR_WORDS = 8;
+constexpr int TRI_WORDS = (2 + 3 * NV + 3) & ~3;
+constexpr int REC_WORDS = HDR_WORDS + 2 * TRI_WORDS;
+constexpr int EXT_TRI_WORDS = 12;
+constexpr int EXT_WORDS = 2 * EXT_TRI_WORDS;
+constexpr int OFF_XR = 0, OFF_YR = 1, OFF_V0 = 2, OFF_DVDX = 2 + NV, OFF_DVDY = 2 + 2 * NV;
+constexpr int EOFF_A = 0, EOFF_B = 3, EOFF_T = 6, EOFF_Q = 9;
+static_assert(REC_WORDS % 4 == 0 && EXT_WORDS % 4 == 0, "records move as 16-byte pieces");
+
 constexpr uint32_t BBOX_EMPTY = 0x000000ffu;    // x0 = 255 > x1 = 0
 constexpr uint32_t FLAG_PERSP_A = 1u, FLAG_PERSP_B = 2u, FLAG_HAS_A = 4u, FLAG_HAS_B = 8u, FLAG_BIG = 16u, FLAG_RECT = 32u;
 // Edge coefficients below this magnitude (512 px) make f32 edge evaluation exact; see edges_inside_f32.
 constexpr int32_t F32_EDGE_LIMIT = 1 << 17;
 
-// One triangle of a cluster, relative to the tile origin.  Edge e: inside <=> A*lx + B*ly + T >= 0 at tile-relative
-// pixel (lx, ly), top-left rule folded into T.  The same 9 slots hold f32 values (normal case) or i32 values (FLAG_BIG).
-struct alignas(16) TriData {
-    float A[3], B[3], T[3];
-    float XR, YR;                  // reference vertex in 24.8 fixed point relative to the tile origin, as f32 (exact)
-    float v0[NV], dvdx[NV], dvdy[NV];   // gradients per 1/256 pixel
-    float q0, qx, qy;              // 1/w plane (read only when the triangle is perspective)
+} // namespace rh
+
+extern "C" __device__ const rh_module_info_t rh_module_info = {
+    RH_MODULE_MAGIC, RH_DEVICE_ABI_VERSION, RH_MODULE_STAGE_FRAGMENT, (uint32_t)rh::N_VARYINGS, (uint32_t)RH_FRAGMENT_OUTPUTS,
+    rh::fnv1a(RH_VERTEX_TAG), (uint32_t)(rh::REC_WORDS * 4), (uint32_t)(rh::EXT_WORDS * 4)
 };
 
-struct alignas(16) ClusterRecord {
-    TriData t[2];
-    uint32_t flags;
-};
+// Diagnostic builds (-DRH_PHASE_TIMING, tools/phase_timing.sh): a few sample tiles print how many cycles their wave
+// spent [0] loading the tile, [1] bringing records into LDS, [2] shading, [3] storing the tile.
+#ifdef RH_PHASE_TIMING
+#define RH_PHASE_BEGIN unsigned long long ph_t = __builtin_readcyclecounter(), ph_acc[4] = {0, 0, 0, 0};
+#define RH_PHASE_MARK(K) { const unsigned long long now_ = __builtin_readcyclecounter(); ph_acc[K] += now_ - ph_t; ph_t = now_; }
+#define RH_PHASE_END if ((blockIdx.x % 1019u) == 7u && lane == 0) \
+    printf("tile %u records %u: load %llu, stage %llu, shade %llu, store %llu\n", tile, end - start, ph_acc[0], ph_acc[1], ph_acc[2], ph_acc[3]);
+#else
+#define RH_PHASE_BEGIN
+#define RH_PHASE_MARK(K)
+#define RH_PHASE_END
+#endif
+
+namespace rh {
 
 RH_DEVICE uint32_t swap_rb(uint32_t v) { return (v & 0xff00ff00u) | ((v & 0xffu) << 16) | ((v >> 16) & 0xffu); }
 
@@ -104,29 +123,37 @@ RH_DEVICE uint32_t blend(uint32_t dst, float4 s, uint32_t src_factor, uint32_t d
 
 RH_DEVICE int64_t clamp_i64(int64_t v, int64_t lim) { return v < -lim ? -lim : (v > lim ? lim : v); }
 
-// Triangle setup relative to tile origin (ox, oy).  Returns false when the triangle contributes nothing to this tile;
+// ---- triangle set-up ---------------------------------------------------------------------------------------------------
+struct TriSetup {
+    float XR = 0.0f, YR = 0.0f;
+    float v0[NV] = {}, dvdx[NV] = {}, dvdy[NV] = {};
+    float q0 = 0.0f, qx = 0.0f, qy = 0.0f;
+    int32_t ei[9] = {};            // A[3], B[3], T[3] of the edge functions, tile-relative
+    int64_t cf[3] = {};            // per edge: the constant in 1/256 px with the top-left rule folded in
+};
+
+// Triangle set-up relative to tile origin (ox, oy).  Returns false when the triangle contributes nothing to this tile;
 // otherwise fills `t` and grows the tile-relative bbox.  `big` is set when an edge coefficient is too large for the
-// f32 coverage path.
-// `cf` receives, per edge, the constant of the edge function in 1/256 px with the top-left rule folded in
-// (inside at sub-pixel position P <=> A*Px + B*Py + cf >= 0); multisampled kernels derive per-sample constants from it.
+// f32 coverage path.  cf: inside at sub-pixel position P <=> A*Px + B*Py + cf >= 0; multisampled passes derive
+// per-sample constants from it.
 RH_DEVICE bool setup_triangle(const rh_draw_params& p, SnappedVertex a, SnappedVertex b, SnappedVertex c, int ox, int oy,
-                              TriData& t, int32_t ei[9], int64_t cf[3], bool& persp, bool& big, int& bx0, int& by0, int& bx1, int& by1) {
+                              TriSetup& t, bool& persp, bool& big, int& bx0, int& by0, int& bx1, int& by1) {
     int x0, y0, x1, y1;
     if (!tri_pixel_bbox(p, a, b, c, x0, y0, x1, y1)) return false;
-    x0 = max(x0, ox); y0 = max(y0, oy); x1 = min(x1, ox + RH_TILE_W - 1); y1 = min(y1, oy + RH_TILE_H - 1);
+    x0 = max(x0, ox); y0 = max(y0, oy); x1 = min(x1, ox + TILE - 1); y1 = min(y1, oy + TILE - 1);
     if (x0 > x1 || y0 > y1) return false;
     const int64_t area2 = (int64_t)(b.X - a.X) * (c.Y - a.Y) - (int64_t)(c.X - a.X) * (b.Y - a.Y);
     if (area2 == 0) return false;
     if (area2 < 0) { SnappedVertex s = b; b = c; c = s; }      // no culling: both windings are drawn
-    // T is relative to the tile origin and saturated at +-2^30: |A*lx + B*ly| < 2^30 for |A|, |B| < 2^23, lx < 64, ly < 32
+    // T is relative to the tile origin and saturated at +-2^30: |A*lx + B*ly| < 2^30 for |A|, |B| < 2^23, lx, ly < 32
     // keeps the sign (and the sum inside 32 bits).
 #define RH_EDGE(P, Q, K) { \
         const int32_t A_ = P.Y - Q.Y, B_ = Q.X - P.X; \
         const int64_t C_ = -((int64_t)A_ * P.X + (int64_t)B_ * P.Y); \
         const bool tl_ = (A_ > 0) || (A_ == 0 && B_ > 0); \
-        cf[K] = C_ + (tl_ ? 0 : -1); \
-        const int64_t Cq_ = cf[K] >> RH_SUBPIXEL_BITS; \
-        ei[K] = A_; ei[3 + K] = B_; ei[6 + K] = (int32_t)clamp_i64(Cq_ + (int64_t)A_ * ox + (int64_t)B_ * oy, (int64_t)1 << 30); \
+        t.cf[K] = C_ + (tl_ ? 0 : -1); \
+        const int64_t Cq_ = t.cf[K] >> RH_SUBPIXEL_BITS; \
+        t.ei[K] = A_; t.ei[3 + K] = B_; t.ei[6 + K] = (int32_t)clamp_i64(Cq_ + (int64_t)A_ * ox + (int64_t)B_ * oy, (int64_t)1 << 30); \
         if (A_ >= F32_EDGE_LIMIT || A_ <= -F32_EDGE_LIMIT || B_ >= F32_EDGE_LIMIT || B_ <= -F32_EDGE_LIMIT) big = true; }
     RH_EDGE(a, b, 0)
     RH_EDGE(b, c, 1)
@@ -158,17 +185,12 @@ RH_DEVICE bool setup_triangle(const rh_draw_params& p, SnappedVertex a, SnappedV
     return true;
 }
 
-// Stores the 9 edge values of a triangle: as f32 (T saturated at +-2^24) or, for a BIG cluster, as raw i32 bits.
-RH_DEVICE void store_edges(TriData& t, const int32_t ei[9], bool big) {
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        if (big) { t.A[k] = __int_as_float(ei[k]); t.B[k] = __int_as_float(ei[3 + k]); t.T[k] = __int_as_float(ei[6 + k]); }
-        else {
-            const int32_t lim = 1 << 24;
-            const int32_t T = ei[6 + k] < -lim ? -lim : (ei[6 + k] > lim ? lim : ei[6 + k]);
-            t.A[k] = (float)ei[k]; t.B[k] = (float)ei[3 + k]; t.T[k] = (float)T;
-        }
-    }
+// The 9 edge values of a triangle as stored: f32 (T saturated at +-2^24) or, for a BIG cluster, raw i32 bits.
+RH_DEVICE uint32_t edge_word(const TriSetup& t, int i, bool big) {
+    if (big) return (uint32_t)t.ei[i];
+    int32_t v = t.ei[i];
+    if (i >= 6) { const int32_t lim = 1 << 24; v = v < -lim ? -lim : (v > lim ? lim : v); }
+    return __float_as_uint((float)v);
 }
 
 // Standard sample locations (Vulkan 1.3, "Multisampling"), as offsets from the pixel centre in 1/256 px.
@@ -189,26 +211,28 @@ struct MsRecord {
     int32_t A[2][3], B[2][3];
     int32_t T[2][S][3];
 };
+template <int S> constexpr bool ms_words_ok() { return sizeof(MsRecord<S>) == 4u * RH_MS_EXTRA_WORDS(S); }
+static_assert(ms_words_ok<2>() && ms_words_ok<4>() && ms_words_ok<8>(), "host and device agree on the multisampled record size");
 
 template <int S>
-RH_DEVICE void store_ms_edges(MsRecord<S>& m, int t, const int32_t ei[9], const int64_t cf[3], int ox, int oy) {
+RH_DEVICE void store_ms_edges(MsRecord<S>& m, int t, const TriSetup& ts, int ox, int oy) {
 #pragma unroll
     for (int e = 0; e < 3; e++) {
-        const int32_t A = ei[e], B = ei[3 + e];
+        const int32_t A = ts.ei[e], B = ts.ei[3 + e];
         m.A[t][e] = A; m.B[t][e] = B;
 #pragma unroll
         for (int sidx = 0; sidx < S; sidx++) {
             int dx, dy; sample_offset<S>(sidx, dx, dy);
-            const int64_t q = (cf[e] + (int64_t)A * dx + (int64_t)B * dy) >> RH_SUBPIXEL_BITS;
+            const int64_t q = (ts.cf[e] + (int64_t)A * dx + (int64_t)B * dy) >> RH_SUBPIXEL_BITS;
             m.T[t][sidx][e] = (int32_t)clamp_i64(q + (int64_t)A * ox + (int64_t)B * oy, (int64_t)1 << 30);
         }
     }
 }
 
-// Sets up both triangles of `cluster`; returns the packed tile-relative bbox of their union (BBOX_EMPTY if neither
-// triangle touches the tile).  S > 1 (multisampled pass) also fills `ms` and never takes the exact-box shortcut.
-template <int S = 1>
-RH_DEVICE uint32_t setup_cluster(const rh_draw_params& p, uint32_t cluster, int ox, int oy, ClusterRecord& r, MsRecord<S>* ms = nullptr) {
+// Sets up both triangles of `cluster` for the tile at (ox, oy) and writes the pair's records.  S > 1 (multisampled
+// pass) also writes the per-sample constants and never takes the exact-box shortcut.
+template <int S>
+RH_DEVICE void setup_pair(const rh_draw_params& p, uint32_t cluster, int ox, int oy, uint32_t* rec, uint32_t* ext) {
     const uint32_t instance = cluster / p.cpi, local = cluster - instance * p.cpi;
     const uint32_t tri0 = local * 2;
     const bool has_second = tri0 + 1 < p.tpi;
@@ -221,15 +245,14 @@ RH_DEVICE uint32_t setup_cluster(const rh_draw_params& p, uint32_t cluster, int 
     const SnappedVertex v2 = run_vertex(p, first + 2, instance);
     int bx0 = 255, by0 = 255, bx1 = -1, by1 = -1;
     bool persp_a = false, persp_b = false, big = false;
-    int32_t ea[9], eb[9];
-    int64_t cfa[3], cfb[3];
-    const bool has_a = setup_triangle(p, v0, v1, v2, ox, oy, r.t[0], ea, cfa, persp_a, big, bx0, by0, bx1, by1);
+    TriSetup ta, tb;
+    const bool has_a = setup_triangle(p, v0, v1, v2, ox, oy, ta, persp_a, big, bx0, by0, bx1, by1);
     bool has_b = false, rect = false;
     int32_t rminX = 0, rmaxX = 0, rminY = 0, rmaxY = 0;
     if (has_second) {
         const SnappedVertex v3 = run_vertex(p, first + 3, instance);
         if (strip) {
-            has_b = setup_triangle(p, v1, v3, v2, ox, oy, r.t[1], eb, cfb, persp_b, big, bx0, by0, bx1, by1);
+            has_b = setup_triangle(p, v1, v3, v2, ox, oy, tb, persp_b, big, bx0, by0, bx1, by1);
             // a strip quad whose snapped corners form an axis-aligned rectangle split along v1-v2
             const bool columns = v0.X == v1.X && v2.X == v3.X && v0.Y == v2.Y && v1.Y == v3.Y;
             const bool rows = v0.Y == v1.Y && v2.Y == v3.Y && v0.X == v2.X && v1.X == v3.X;
@@ -238,56 +261,90 @@ RH_DEVICE uint32_t setup_cluster(const rh_draw_params& p, uint32_t cluster, int 
         } else {
             const SnappedVertex v4 = run_vertex(p, first + 4, instance);
             const SnappedVertex v5 = run_vertex(p, first + 5, instance);
-            has_b = setup_triangle(p, v3, v4, v5, ox, oy, r.t[1], eb, cfb, persp_b, big, bx0, by0, bx1, by1);
+            has_b = setup_triangle(p, v3, v4, v5, ox, oy, tb, persp_b, big, bx0, by0, bx1, by1);
         }
     }
-    if (S == 1) {
-        if (has_a) store_edges(r.t[0], ea, big);
-        if (has_b) store_edges(r.t[1], eb, big);
-    } else {
-        if (has_a) store_ms_edges<S>(*ms, 0, ea, cfa, ox, oy);
-        if (has_b) store_ms_edges<S>(*ms, 1, eb, cfb, ox, oy);
+    uint32_t flags = (has_a ? FLAG_HAS_A : 0u) | (has_b ? FLAG_HAS_B : 0u) | (persp_a ? FLAG_PERSP_A : 0u) | (persp_b ? FLAG_PERSP_B : 0u) |
+                     (big ? FLAG_BIG : 0u) | (rect ? FLAG_RECT : 0u);
+    uint32_t bbox = BBOX_EMPTY;
+    if (has_a || has_b) {
+        if (rect) {
+            // Exact pixel set of the rectangle under the top-left rule: left and top edges take pixel centres on them,
+            // right and bottom edges do not.  Inside it every pixel belongs to exactly one of the two triangles, decided
+            // by the shared diagonal alone (edge 1 of triangle A).
+            const int ex0 = max(max(p.sc_x0, ox), (rminX + 255) >> 8), ex1 = min(min(p.sc_x1 - 1, ox + TILE - 1), (rmaxX - 1) >> 8);
+            const int ey0 = max(max(p.sc_y0, oy), (rminY + 255) >> 8), ey1 = min(min(p.sc_y1 - 1, oy + TILE - 1), (rmaxY - 1) >> 8);
+            if (ex0 <= ex1 && ey0 <= ey1) bbox = (uint32_t)(ex0 - ox) | ((uint32_t)(ey0 - oy) << 8) | ((uint32_t)(ex1 - ox) << 16) | ((uint32_t)(ey1 - oy) << 24);
+        } else bbox = (uint32_t)bx0 | ((uint32_t)by0 << 8) | ((uint32_t)bx1 << 16) | ((uint32_t)by1 << 24);
     }
-    r.flags = (has_a ? FLAG_HAS_A : 0u) | (has_b ? FLAG_HAS_B : 0u) | (persp_a ? FLAG_PERSP_A : 0u) | (persp_b ? FLAG_PERSP_B : 0u) |
-              (big ? FLAG_BIG : 0u) | (rect ? FLAG_RECT : 0u);
-    if (!has_a && !has_b) return BBOX_EMPTY;
-    if (rect) {
-        // Exact pixel set of the rectangle under the top-left rule: left and top edges take pixel centres on them, right
-        // and bottom edges do not.  Inside it every pixel belongs to exactly one of the two triangles, decided by the
-        // shared diagonal alone (edge 1 of triangle A).
-        const int ex0 = max(max(p.sc_x0, ox), (rminX + 255) >> 8), ex1 = min(min(p.sc_x1 - 1, ox + RH_TILE_W - 1), (rmaxX - 1) >> 8);
-        const int ey0 = max(max(p.sc_y0, oy), (rminY + 255) >> 8), ey1 = min(min(p.sc_y1 - 1, oy + RH_TILE_H - 1), (rmaxY - 1) >> 8);
-        if (ex0 > ex1 || ey0 > ey1) return BBOX_EMPTY;
-        return (uint32_t)(ex0 - ox) | ((uint32_t)(ey0 - oy) << 8) | ((uint32_t)(ex1 - ox) << 16) | ((uint32_t)(ey1 - oy) << 24);
+    if (bbox == BBOX_EMPTY) flags = 0u;
+    // the record (the planes of a missing triangle are zeros: never used, masked by the flags)
+    uint32_t w[REC_WORDS];
+#pragma unroll
+    for (int i = 0; i < REC_WORDS; i++) w[i] = 0u;
+    w[0] = bbox; w[1] = flags;
+    w[2] = edge_word(ta, 1, false); w[3] = edge_word(ta, 4, false); w[4] = edge_word(ta, 7, false);      // the shared diagonal (used when RECT: never BIG)
+    const TriSetup* const ts[2] = { &ta, &tb };
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        uint32_t* o = w + HDR_WORDS + t * TRI_WORDS;
+        o[OFF_XR] = __float_as_uint(ts[t]->XR); o[OFF_YR] = __float_as_uint(ts[t]->YR);
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+            o[OFF_V0 + v] = __float_as_uint(ts[t]->v0[v]); o[OFF_DVDX + v] = __float_as_uint(ts[t]->dvdx[v]); o[OFF_DVDY + v] = __float_as_uint(ts[t]->dvdy[v]);
+        }
     }
-    return (uint32_t)bx0 | ((uint32_t)by0 << 8) | ((uint32_t)bx1 << 16) | ((uint32_t)by1 << 24);
+    uint4* const rec4 = reinterpret_cast<uint4*>(rec);
+#pragma unroll
+    for (int i = 0; i < REC_WORDS / 4; i++) rec4[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+    // the extended record: only for clusters whose fragments read it
+    if (bbox != BBOX_EMPTY && (!rect || persp_a || persp_b)) {
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            uint32_t* o = ext + t * EXT_TRI_WORDS;
+#pragma unroll
+            for (int i = 0; i < 9; i++) o[i] = edge_word(*ts[t], i, big);
+            o[EOFF_Q] = __float_as_uint(ts[t]->q0); o[EOFF_Q + 1] = __float_as_uint(ts[t]->qx); o[EOFF_Q + 2] = __float_as_uint(ts[t]->qy);
+        }
+    }
+    if (S > 1 && bbox != BBOX_EMPTY) {
+        MsRecord<S>& m = *reinterpret_cast<MsRecord<S>*>(ext + EXT_WORDS);
+        if (has_a) store_ms_edges<S>(m, 0, ta, ox, oy);
+        if (has_b) store_ms_edges<S>(m, 1, tb, ox, oy);
+    }
 }
 
-// f32 coverage: with |A|, |B| < 2^17, lx < 64 and ly < 32 every product is an exactly representable integer below 2^23,
+template <int S>
+RH_DEVICE void setup_kernel(const rh_setup_args& a) {
+    uint32_t n = a.n_pairs;
+    if (a.pair_total) { if (*a.pair_total > n) return; n = (uint32_t)*a.pair_total; }   // (n arrives as the room for the pairs)
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t tile = a.tiles[i];
+    const int ox = (int)(tile % a.p.tiles_x) * TILE, oy = (int)(tile / a.p.tiles_x) * TILE;
+    setup_pair<S>(a.p, a.clusters[i], ox, oy, reinterpret_cast<uint32_t*>(a.rec + (size_t)i * (REC_WORDS * 4)),
+                  reinterpret_cast<uint32_t*>(a.ext + (size_t)i * a.ext_bytes));
+}
+
+// f32 coverage: with |A|, |B| < 2^17 and lx, ly < 32 every product is an exactly representable integer below 2^22,
 // T is an exactly representable integer in [-2^24, 2^24], and |A*lx + B*ly| < 2^24.  Whenever the true edge value
 // A*lx + B*ly + T is within a few units of zero every partial sum is below 2^24 and therefore exact, so the sign test
 // agrees with integer arithmetic; when T is saturated the sign is that of T.
-RH_DEVICE bool edges_inside_f32(const TriData& t, float lxf, float lyf) {
-    const float s0 = __builtin_fmaf(t.A[0], lxf, __builtin_fmaf(t.B[0], lyf, t.T[0]));
-    const float s1 = __builtin_fmaf(t.A[1], lxf, __builtin_fmaf(t.B[1], lyf, t.T[1]));
-    const float s2 = __builtin_fmaf(t.A[2], lxf, __builtin_fmaf(t.B[2], lyf, t.T[2]));
+RH_DEVICE bool edges_inside_f32(const float* e, float lxf, float lyf) {
+    const float s0 = __builtin_fmaf(e[EOFF_A + 0], lxf, __builtin_fmaf(e[EOFF_B + 0], lyf, e[EOFF_T + 0]));
+    const float s1 = __builtin_fmaf(e[EOFF_A + 1], lxf, __builtin_fmaf(e[EOFF_B + 1], lyf, e[EOFF_T + 1]));
+    const float s2 = __builtin_fmaf(e[EOFF_A + 2], lxf, __builtin_fmaf(e[EOFF_B + 2], lyf, e[EOFF_T + 2]));
     return ((__float_as_int(s0) | __float_as_int(s1) | __float_as_int(s2)) >= 0);     // no sign bit set (a zero sum is +0)
 }
 
-RH_DEVICE bool edges_inside_i32(const TriData& t, int lx, int ly) {
-    const int s0 = __mul24(__float_as_int(t.A[0]), lx) + __mul24(__float_as_int(t.B[0]), ly) + __float_as_int(t.T[0]);
-    const int s1 = __mul24(__float_as_int(t.A[1]), lx) + __mul24(__float_as_int(t.B[1]), ly) + __float_as_int(t.T[1]);
-    const int s2 = __mul24(__float_as_int(t.A[2]), lx) + __mul24(__float_as_int(t.B[2]), ly) + __float_as_int(t.T[2]);
+RH_DEVICE bool edges_inside_i32(const float* e, int lx, int ly) {
+    const int s0 = __mul24(__float_as_int(e[EOFF_A + 0]), lx) + __mul24(__float_as_int(e[EOFF_B + 0]), ly) + __float_as_int(e[EOFF_T + 0]);
+    const int s1 = __mul24(__float_as_int(e[EOFF_A + 1]), lx) + __mul24(__float_as_int(e[EOFF_B + 1]), ly) + __float_as_int(e[EOFF_T + 1]);
+    const int s2 = __mul24(__float_as_int(e[EOFF_A + 2]), lx) + __mul24(__float_as_int(e[EOFF_B + 2]), ly) + __float_as_int(e[EOFF_T + 2]);
     return (s0 | s1 | s2) >= 0;
 }
 
-constexpr int TRI_FLOATS = (int)(sizeof(TriData) / sizeof(float));
-constexpr int REC_FLOATS = (int)(sizeof(ClusterRecord) / sizeof(float));
 constexpr int PACK_MAX = 4;               // boxes that may share one shading pass
-// float offsets inside TriData of the values a fragment reads from the triangle that covers it
-constexpr int OFF_XR = 9, OFF_YR = 10, OFF_V0 = 11, OFF_DVDX = OFF_V0 + NV, OFF_DVDY = OFF_DVDX + NV, OFF_Q0 = OFF_DVDY + NV;
-static_assert(offsetof(TriData, XR) == OFF_XR * 4 && offsetof(TriData, v0) == OFF_V0 * 4 && offsetof(TriData, q0) == OFF_Q0 * 4,
-              "fragment-side offsets must match TriData");
 
 // ---- attachment pixels --------------------------------------------------------------------------------------------
 // LDS slot of one attachment pixel.  Narrow kernels (every attachment 8-bit UNORM): the packed pixel, r in byte 0 (an R8
@@ -353,27 +410,31 @@ RH_DEVICE void blend_pixel(uint4* px, const rh_attach_dev& at, float4 s, uint32_
     *px = make_uint4(__float_as_uint(o0), __float_as_uint(o1), __float_as_uint(o2), __float_as_uint(o3));
 }
 
-// The LDS of a tile workgroup; declared once per exported kernel and shared by its specialisations.
+// The LDS of a tile wave.
 template <int NA, bool WIDE = false>
 struct TileLds {
-    ClusterRecord rec[RH_BATCH_CLUSTERS];
-    uint32_t rec_bbox[RH_BATCH_CLUSTERS];
-    typename Px<WIDE>::T tile_px[NA][4 * REGION_STRIDE];
+    alignas(16) uint32_t rec[ROUND * REC_WORDS];     // first: record fields are reached with small immediate offsets
+    typename Px<WIDE>::T px[NA][TILE_PX];
 };
+
+// Brings records [first, first + n) into the staging area (16-byte pieces, consecutive lanes consecutive pieces).
+RH_DEVICE void stage_records(uint32_t* lds_rec, const uint8_t* rec, uint32_t first, int n, int lane) {
+    const uint4* const src = reinterpret_cast<const uint4*>(rec + (size_t)first * (REC_WORDS * 4));
+    uint4* const dst = reinterpret_cast<uint4*>(lds_rec);
+    for (int i = lane; i < n * (REC_WORDS / 4); i += 64) dst[i] = src[i];
+    // one wave: its LDS operations complete in issue order, so the reads that follow see these writes
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
 
 template <int NA, int BLEND, int TEX, bool WIDE = false>
 RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
     using PxT = typename Px<WIDE>::T;
-    ClusterRecord* const rec = lds.rec;
-    uint32_t* const rec_bbox = lds.rec_bbox;
-    PxT (* const tile_px)[4 * REGION_STRIDE] = lds.tile_px;
-
     if (a.pair_total && *a.pair_total > a.pair_capacity) return;     // the pair arrays were too small: the host runs the pass again
     const rh_draw_params& p = a.p;
-    const int tid = (int)threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: everything derived from it is wave-uniform
+    const int lane = (int)threadIdx.x;
+    RH_PHASE_BEGIN
     const uint32_t tile = blockIdx.x + p.tile_first;
-    const int ox = (int)(tile % p.tiles_x) * RH_TILE_W, oy = (int)(tile / p.tiles_x) * RH_TILE_H;
+    const int ox = (int)(tile % p.tiles_x) * TILE, oy = (int)(tile / p.tiles_x) * TILE;
     const uint32_t start = a.tile_start[tile], end = a.tile_end[tile];
 
     // 1. bring the tile into LDS
@@ -381,158 +442,142 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
     for (int t = 0; t < NA; t++) {
         const rh_attach_dev& at = a.att[t];
         if (at.load_op == 0u && start == end) continue;          // untouched tile of a Load attachment
-        for (int i = tid; i < RH_TILE_W * RH_TILE_H; i += RH_TILE_THREADS) {
-            const int lx = i & (RH_TILE_W - 1), ly = i / RH_TILE_W;
-            const uint32_t gx = (uint32_t)(ox + lx), gy = (uint32_t)(oy + ly);
+        for (int i = lane; i < TILE_PX; i += 64) {
+            const uint32_t gx = (uint32_t)(ox + (i & (TILE - 1))), gy = (uint32_t)(oy + i / TILE);
             PxT v{};
             if (gx < p.width && gy < p.height)
                 v = at.load_op != 0u ? clear_pixel(at, (PxT*)nullptr) : load_pixel(at, (size_t)gy * at.pitch_px + gx, (PxT*)nullptr);
-            tile_px[t][((ly / REGION_H) * 2 + (lx / REGION_W)) * REGION_STRIDE + (ly % REGION_H) * REGION_W + (lx % REGION_W)] = v;
+            lds.px[t][i] = v;
         }
     }
+    RH_PHASE_MARK(0)
 
     FragmentContext fctx; fctx.p = &p;
     fctx.static_rgba8 = TEX != 0 ? 1u : 0u;
     fctx.static_filter = TEX == 1 ? 1u + FILTER_LINEAR : (TEX == 2 ? 1u + FILTER_NEAREST : 0u);
-
-    // this wave's region, tile-relative, intersected with the scissor
-    const int rx0 = (wave & 1) * REGION_W, ry0 = (wave >> 1) * REGION_H;
-    const int sx0 = max(rx0, p.sc_x0 - ox), sy0 = max(ry0, p.sc_y0 - oy);
-    const int sx1 = min(rx0 + REGION_W - 1, p.sc_x1 - 1 - ox), sy1 = min(ry0 + REGION_H - 1, p.sc_y1 - 1 - oy);
-    const bool region_live = sx0 <= sx1 && sy0 <= sy1;
-    PxT* const region_px = &tile_px[0][wave * REGION_STRIDE];
+    PxT* const tile_px = &lds.px[0][0];
     const float lane_f = (float)lane;
-    const float region_bias = (float)(ry0 * REGION_W + rx0);   // pidx = (ly - ry0) * REGION_W + (lx - rx0)
+    const float* const recf = reinterpret_cast<const float*>(lds.rec);
 
-    // 2. batches of clusters
-    for (uint32_t base = start; base < end; base += RH_BATCH_CLUSTERS) {
-        __syncthreads();                                          // tile loaded / previous batch fully consumed
-        if (tid < RH_BATCH_CLUSTERS) {
-            const uint32_t ci = base + (uint32_t)tid;
-            uint32_t bb = BBOX_EMPTY;
-            if (ci < end) bb = setup_cluster(p, a.list[ci], ox, oy, rec[tid]);
-            rec_bbox[tid] = bb;
+    // 2. rounds of records
+    for (uint32_t base = start; base < end; base += ROUND) {
+        const int n = (int)min((uint32_t)ROUND, end - base);
+        stage_records(lds.rec, a.rec, base, n, lane);
+        RH_PHASE_MARK(1)
+        // lane = record of this round (all wave-parallel)
+        const uint32_t bb = lane < n ? lds.rec[lane * REC_WORDS] : BBOX_EMPTY;
+        const uint32_t fl = lane < n ? lds.rec[lane * REC_WORDS + 1] : 0u;
+        const int hx0 = (int)(bb & 0xffu), hy0 = (int)((bb >> 8) & 0xffu), hx1 = (int)((bb >> 16) & 0xffu), hy1 = (int)(bb >> 24);
+        const bool hit = hx0 <= hx1;
+        const int npx = (hx1 - hx0 + 1) * (hy1 - hy0 + 1);
+        const unsigned long long mask = __ballot(hit);
+        const int nh = __popcll(mask);
+        if (nh == 0) continue;
+        // Small axis-aligned quads may share one pass (see below); anything else runs alone, 64 pixels per pass.
+        const bool small = (fl & (FLAG_RECT | FLAG_PERSP_A | FLAG_PERSP_B)) == FLAG_RECT && npx <= 64;
+        // Compact the hits, in submission order, into the first nh lanes (a lane permutation, no memory):
+        //   box = the box, info = record of the round | flags << 8 | pixels << 16 | small << 31
+        uint32_t box_v, info_v;
+        {
+            const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+            const int dest = hit ? below : nh + lane - below;
+            const uint32_t info = (uint32_t)lane | (fl << 8) | ((uint32_t)npx << 16) | (small ? 0x80000000u : 0u);
+            box_v = (uint32_t)__builtin_amdgcn_ds_permute(dest << 2, (int)bb);
+            info_v = (uint32_t)__builtin_amdgcn_ds_permute(dest << 2, (int)(hit ? info : 0u));
         }
-        __syncthreads();
-        if (!region_live) continue;
-
-        for (int round = 0; round < RH_BATCH_CLUSTERS / 64; round++) {
-            // lane = cluster of this round: its box clipped to the region (all wave-parallel)
-            const uint32_t bb = rec_bbox[round * 64 + lane];
-            const uint32_t fl = rec[round * 64 + lane].flags;            // (stale for an empty slot: never a hit)
-            const int hx0 = max((int)(bb & 0xffu), sx0), hy0 = max((int)((bb >> 8) & 0xffu), sy0);
-            const int hx1 = min((int)((bb >> 16) & 0xffu), sx1), hy1 = min((int)(bb >> 24), sy1);
-            const bool hit = hx0 <= hx1 && hy0 <= hy1;
-            const int npx = (hx1 - hx0 + 1) * (hy1 - hy0 + 1);
-            const unsigned long long mask = __ballot(hit);
-            const int nh = __popcll(mask);
-            if (nh == 0) continue;
-            // Small axis-aligned quads may share one pass (see below); anything else runs alone, 64 pixels per pass.
-            const bool small = (fl & (FLAG_RECT | FLAG_PERSP_A | FLAG_PERSP_B)) == FLAG_RECT && npx <= 64;
-            // Compact the hits, in submission order, into the first nh lanes (a lane permutation, no memory):
-            //   box = clipped box, info = cluster | flags << 8 | pixels << 16 | small << 31
-            uint32_t box_v, info_v;
-            {
-                const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                const int dest = hit ? below : nh + lane - below;
-                const uint32_t box = (uint32_t)hx0 | ((uint32_t)hy0 << 8) | ((uint32_t)hx1 << 16) | ((uint32_t)hy1 << 24);
-                const uint32_t info = (uint32_t)(round * 64 + lane) | (fl << 8) | ((uint32_t)npx << 16) | (small ? 0x80000000u : 0u);
-                box_v = (uint32_t)__builtin_amdgcn_ds_permute(dest << 2, (int)box);
-                info_v = (uint32_t)__builtin_amdgcn_ds_permute(dest << 2, (int)(hit ? info : 0u));
+        // A pack = up to PACK_MAX consecutive small hits whose boxes are pairwise disjoint and whose pixels fit
+        // the 64 lanes of ONE pass (disjoint boxes cannot touch the same pixel, so their relative order is
+        // immaterial).  Every lane works out the pack that would start at its hit:
+        //   run = length | pixels << 3 | lane at which member 1, 2, 3 starts << 10, 17, 24 (127 = no such member)
+        uint32_t run_v;
+        {
+            const uint32_t n0 = (info_v >> 16) & 0x7ffu;
+            uint32_t len = 1u, total = n0, c1 = 127u, c2 = 127u, c3 = 127u;
+            const unsigned long long sm = __ballot((info_v >> 31) != 0u);
+            if (sm & (sm >> 1)) {
+                static_assert(PACK_MAX == 4, "written for four members");
+                // the three hits after this one (lanes past the end wrap around: excluded by the bound checks)
+                auto after = [&](int d) { const int src = ((lane + d) & 63) << 2;
+                                          return make_uint2((uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)box_v), (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)info_v)); };
+                const uint2 m1 = after(1), m2 = after(2), m3 = after(3);
+                auto apart = [](uint32_t p, uint32_t q) {
+                    return (p & 0xffu) > ((q >> 16) & 0xffu) || ((p >> 16) & 0xffu) < (q & 0xffu) ||
+                           ((p >> 8) & 0xffu) > (q >> 24) || (p >> 24) < ((q >> 8) & 0xffu);
+                };
+                const uint32_t n1 = (m1.y >> 16) & 0x7ffu, n2 = (m2.y >> 16) & 0x7ffu, n3 = (m3.y >> 16) & 0x7ffu;
+                const bool ok1 = (info_v >> 31) != 0u && lane + 1 < nh && (m1.y >> 31) != 0u && n0 + n1 <= 64u && apart(box_v, m1.x);
+                const bool ok2 = ok1 && lane + 2 < nh && (m2.y >> 31) != 0u && n0 + n1 + n2 <= 64u && apart(box_v, m2.x) && apart(m1.x, m2.x);
+                const bool ok3 = ok2 && lane + 3 < nh && (m3.y >> 31) != 0u && n0 + n1 + n2 + n3 <= 64u &&
+                                 apart(box_v, m3.x) && apart(m1.x, m3.x) && apart(m2.x, m3.x);
+                len = 1u + (ok1 ? 1u : 0u) + (ok2 ? 1u : 0u) + (ok3 ? 1u : 0u);
+                c1 = ok1 ? n0 : 127u; c2 = ok2 ? n0 + n1 : 127u; c3 = ok3 ? n0 + n1 + n2 : 127u;
+                total = n0 + (ok1 ? n1 : 0u) + (ok2 ? n2 : 0u) + (ok3 ? n3 : 0u);
             }
-            // A pack = up to PACK_MAX consecutive small hits whose boxes are pairwise disjoint and whose pixels fit
-            // the 64 lanes of ONE pass (disjoint boxes cannot touch the same pixel, so their relative order is
-            // immaterial).  Every lane works out the pack that would start at its hit:
-            //   run = length | pixels << 3 | lane at which member 1, 2, 3 starts << 10, 17, 24 (127 = no such member)
-            uint32_t run_v;
-            {
-                const uint32_t n0 = (info_v >> 16) & 0x3ffu;
-                uint32_t len = 1u, total = n0, c1 = 127u, c2 = 127u, c3 = 127u;
-                const unsigned long long sm = __ballot((info_v >> 31) != 0u);
-                if (sm & (sm >> 1)) {
-                    static_assert(PACK_MAX == 4, "written for four members");
-                    // the three hits after this one (lanes past the end wrap around: excluded by the bound checks)
-                    auto after = [&](int d) { const int src = ((lane + d) & 63) << 2;
-                                              return make_uint2((uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)box_v), (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)info_v)); };
-                    const uint2 m1 = after(1), m2 = after(2), m3 = after(3);
-                    auto apart = [](uint32_t p, uint32_t q) {
-                        return (p & 0xffu) > ((q >> 16) & 0xffu) || ((p >> 16) & 0xffu) < (q & 0xffu) ||
-                               ((p >> 8) & 0xffu) > (q >> 24) || (p >> 24) < ((q >> 8) & 0xffu);
-                    };
-                    const uint32_t n1 = (m1.y >> 16) & 0x3ffu, n2 = (m2.y >> 16) & 0x3ffu, n3 = (m3.y >> 16) & 0x3ffu;
-                    const bool ok1 = (info_v >> 31) != 0u && lane + 1 < nh && (m1.y >> 31) != 0u && n0 + n1 <= 64u && apart(box_v, m1.x);
-                    const bool ok2 = ok1 && lane + 2 < nh && (m2.y >> 31) != 0u && n0 + n1 + n2 <= 64u && apart(box_v, m2.x) && apart(m1.x, m2.x);
-                    const bool ok3 = ok2 && lane + 3 < nh && (m3.y >> 31) != 0u && n0 + n1 + n2 + n3 <= 64u &&
-                                     apart(box_v, m3.x) && apart(m1.x, m3.x) && apart(m2.x, m3.x);
-                    len = 1u + (ok1 ? 1u : 0u) + (ok2 ? 1u : 0u) + (ok3 ? 1u : 0u);
-                    c1 = ok1 ? n0 : 127u; c2 = ok2 ? n0 + n1 : 127u; c3 = ok3 ? n0 + n1 + n2 : 127u;
-                    total = n0 + (ok1 ? n1 : 0u) + (ok2 ? n2 : 0u) + (ok3 ? n3 : 0u);
-                }
-                run_v = len | (total << 3) | (c1 << 10) | (c2 << 17) | (c3 << 24);
+            run_v = len | (total << 3) | (c1 << 10) | (c2 << 17) | (c3 << 24);
+        }
+        // Hits in order; k and everything read with readlane is wave-uniform and lives on the scalar unit.
+        int k = 0;
+        while (k < nh) {
+            const uint32_t info = __builtin_amdgcn_readlane(info_v, k);
+            // per-lane inputs of the passes of this hit (or pack): record, box, first pixel index, pixel count
+            uint32_t flags;
+            const float* rf;
+            const float* ef = nullptr;                       // extended record (one hit per pass only)
+            float hx0f, hy0f, wf, idx0_f, limit_f;
+            int npass;
+            if (info >> 31) {
+                const uint32_t run = __builtin_amdgcn_readlane(run_v, k);
+                const int c1 = (int)((run >> 10) & 127u), c2 = (int)((run >> 17) & 127u), c3 = (int)(run >> 24);
+                const bool g1 = lane >= c1, g2 = lane >= c2, g3 = lane >= c3;
+                const int slot = (g1 ? 1 : 0) + (g2 ? 1 : 0) + (g3 ? 1 : 0);
+                const int st = g3 ? c3 : (g2 ? c2 : (g1 ? c1 : 0));
+                const int src = (k + slot) << 2;
+                const uint2 m = make_uint2((uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)box_v), (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)info_v));
+                hx0f = (float)(m.x & 0xffu); hy0f = (float)((m.x >> 8) & 0xffu);
+                wf = (float)(int)(((m.x >> 16) & 0xffu) - (m.x & 0xffu) + 1u);
+                idx0_f = (float)(lane - st);
+                limit_f = (float)((int)((run >> 3) & 127u) - st);         // lane < total <=> lane - st < total - st
+                npass = 1;
+                rf = recf + (int)(m.y & 0xffu) * REC_WORDS;
+                flags = FLAG_RECT | FLAG_HAS_A | FLAG_HAS_B;
+                k += (int)(run & 7u);
+            } else {
+                const uint32_t box = __builtin_amdgcn_readlane(box_v, k);
+                const int w = (int)((box >> 16) & 0xffu) - (int)(box & 0xffu) + 1, npix = (int)((info >> 16) & 0x7ffu);
+                hx0f = (float)(box & 0xffu); hy0f = (float)((box >> 8) & 0xffu); wf = (float)w;
+                idx0_f = lane_f;
+                limit_f = (float)npix;
+                npass = (npix + 63) >> 6;
+                rf = recf + (int)(info & 0xffu) * REC_WORDS;
+                flags = (info >> 8) & 0x3fu;
+                if ((flags & (FLAG_RECT | FLAG_PERSP_A | FLAG_PERSP_B)) != FLAG_RECT)
+                    ef = reinterpret_cast<const float*>(a.ext + (size_t)(base + (info & 0xffu)) * a.ext_bytes);
+                k++;
             }
-            // Hits in order; k and everything read with readlane is wave-uniform and lives on the scalar unit.
-            int k = 0;
-            while (k < nh) {
-                const uint32_t info = __builtin_amdgcn_readlane(info_v, k);
-                // per-lane inputs of the passes of this hit (or pack): cluster record, box, first pixel index, pixel count
-                uint32_t flags;
-                const float* rf;
-                float hx0f, hy0f, wf, idx0_f, limit_f;
-                int npass;
-                if (info >> 31) {
-                    const uint32_t run = __builtin_amdgcn_readlane(run_v, k);
-                    const int c1 = (int)((run >> 10) & 127u), c2 = (int)((run >> 17) & 127u), c3 = (int)(run >> 24);
-                    const bool g1 = lane >= c1, g2 = lane >= c2, g3 = lane >= c3;
-                    const int slot = (g1 ? 1 : 0) + (g2 ? 1 : 0) + (g3 ? 1 : 0);
-                    const int st = g3 ? c3 : (g2 ? c2 : (g1 ? c1 : 0));
-                    const int src = (k + slot) << 2;
-                    const uint2 m = make_uint2((uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)box_v), (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)info_v));
-                    hx0f = (float)(m.x & 0xffu); hy0f = (float)((m.x >> 8) & 0xffu);
-                    wf = (float)(int)(((m.x >> 16) & 0xffu) - (m.x & 0xffu) + 1u);
-                    idx0_f = (float)(lane - st);
-                    limit_f = (float)((int)((run >> 3) & 127u) - st);         // lane < total <=> lane - st < total - st
-                    npass = 1;
-                    rf = reinterpret_cast<const float*>(rec) + (int)(m.y & 0xffu) * REC_FLOATS;
-                    flags = FLAG_RECT | FLAG_HAS_A | FLAG_HAS_B;
-                    k += (int)(run & 7u);
-                } else {
-                    const uint32_t box = __builtin_amdgcn_readlane(box_v, k);
-                    const int w = (int)((box >> 16) & 0xffu) - (int)(box & 0xffu) + 1, n = (int)((info >> 16) & 0x3ffu);
-                    hx0f = (float)(box & 0xffu); hy0f = (float)((box >> 8) & 0xffu); wf = (float)w;
-                    idx0_f = lane_f;
-                    limit_f = (float)n;
-                    npass = (n + 63) >> 6;
-                    rf = reinterpret_cast<const float*>(rec) + (int)(info & 0xffu) * REC_FLOATS;
-                    flags = (info >> 8) & 0x3fu;
-                    k++;
-                }
-                const float invw = __builtin_amdgcn_rcpf(wf), half_invw = 0.5f * invw;
-                for (int pass = 0; pass < npass; pass++) {
-                const float idx_f = idx0_f + (float)(pass * 64);
+            const float invw = __builtin_amdgcn_rcpf(wf), half_invw = 0.5f * invw;
+            const bool has_a = (flags & FLAG_HAS_A) != 0u, has_b = (flags & FLAG_HAS_B) != 0u;
+            const bool any_persp = (flags & (FLAG_PERSP_A | FLAG_PERSP_B)) != 0u;
+            float idx_f = idx0_f;
+            for (int pass = 0; pass < npass; pass++, idx_f += 64.0f) {
                 const bool live = idx_f < limit_f;
-                const bool has_a = (flags & FLAG_HAS_A) != 0u, has_b = (flags & FLAG_HAS_B) != 0u;
-                const bool any_persp = (flags & (FLAG_PERSP_A | FLAG_PERSP_B)) != 0u;
-                const TriData& tri_a = *reinterpret_cast<const TriData*>(rf);
-                const TriData& tri_b = *reinterpret_cast<const TriData*>(rf + TRI_FLOATS);
                 // floor((idx + 0.5) / w): the half keeps the quotient at least 1/128 away from an integer
                 const float row_f = floorf(__builtin_fmaf(idx_f, invw, half_invw));
                 const float col_f = __builtin_fmaf(-row_f, wf, idx_f);
                 const float lxf = hx0f + col_f, lyf = hy0f + row_f;          // tile-relative pixel, exact small integers
-                // region-relative LDS index of the pixel
-                const int pidx = (int)__builtin_fmaf(lyf, (float)REGION_W, lxf - region_bias);
+                const int pidx = (int)__builtin_fmaf(lyf, (float)TILE, lxf);
                 bool cov_a, cov_b, overlap = false;
                 if (flags & FLAG_RECT) {
                     // every pixel of the box is covered; the shared diagonal (edge 1 of A) says by which triangle
-                    const bool in_a = __float_as_int(__builtin_fmaf(tri_a.A[1], lxf, __builtin_fmaf(tri_a.B[1], lyf, tri_a.T[1]))) >= 0;
+                    const bool in_a = __float_as_int(__builtin_fmaf(rf[2], lxf, __builtin_fmaf(rf[3], lyf, rf[4]))) >= 0;
                     cov_a = live && in_a; cov_b = live && !in_a;
                 } else {
-                    // (a missing triangle's record holds stale values: masked by has_*)
+                    // (a missing triangle's record holds zeros: masked by has_*)
                     bool in_a, in_b;
                     if (flags & FLAG_BIG) {
                         const int lx = (int)lxf, ly = (int)lyf;
-                        in_a = edges_inside_i32(tri_a, lx, ly); in_b = edges_inside_i32(tri_b, lx, ly);
+                        in_a = edges_inside_i32(ef, lx, ly); in_b = edges_inside_i32(ef + EXT_TRI_WORDS, lx, ly);
                     } else {
-                        in_a = edges_inside_f32(tri_a, lxf, lyf); in_b = edges_inside_f32(tri_b, lxf, lyf);
+                        in_a = edges_inside_f32(ef, lxf, lyf); in_b = edges_inside_f32(ef + EXT_TRI_WORDS, lxf, lyf);
                     }
                     cov_a = live && has_a && in_a; cov_b = live && has_b && in_b;
                     overlap = __any(cov_a && cov_b);
@@ -541,14 +586,15 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
                 // the plane equations of the triangle that covers it.  Otherwise A's fragments, then B's.
                 auto shade = [&](bool cov, bool use_b) {
                     // per-lane choice of the triangle = per-lane LDS address (one copy of the shading code)
-                    const float* const tp = rf + (use_b ? TRI_FLOATS : 0);
+                    const float* const tp = rf + HDR_WORDS + (use_b ? TRI_WORDS : 0);
                     const float dx = __builtin_fmaf(lxf, 256.0f, -tp[OFF_XR]), dy = __builtin_fmaf(lyf, 256.0f, -tp[OFF_YR]);   // exact
                     Varyings var; float* vf = reinterpret_cast<float*>(&var);
 #pragma unroll
                     for (int v = 0; v < NV; v++) vf[v] = __builtin_fmaf(tp[OFF_DVDY + v], dy, __builtin_fmaf(tp[OFF_DVDX + v], dx, tp[OFF_V0 + v]));
                     if (any_persp) {
                         const bool persp = use_b ? (flags & FLAG_PERSP_B) != 0u : (flags & FLAG_PERSP_A) != 0u;
-                        const float q = __builtin_fmaf(tp[OFF_Q0 + 2], dy, __builtin_fmaf(tp[OFF_Q0 + 1], dx, tp[OFF_Q0]));
+                        const float* const eq = ef + (use_b ? EXT_TRI_WORDS : 0) + EOFF_Q;
+                        const float q = __builtin_fmaf(eq[2], dy, __builtin_fmaf(eq[1], dx, eq[0]));
 #pragma unroll
                         for (int v = 0; v < NV; v++) vf[v] = persp ? vf[v] / q : vf[v];
                     }
@@ -556,9 +602,9 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
                         Outputs out;
                         fragment_main(fctx, var, out);
 #pragma unroll
-                        for (int n = 0; n < NA; n++) {
-                            blend_pixel<BLEND>(region_px + n * (4 * REGION_STRIDE) + pidx, a.att[n],
-                                               out.color[n < RH_FRAGMENT_OUTPUTS ? n : RH_FRAGMENT_OUTPUTS - 1], a.src_factor, a.dst_factor);
+                        for (int t = 0; t < NA; t++) {
+                            blend_pixel<BLEND>(tile_px + t * TILE_PX + pidx, a.att[t],
+                                               out.color[t < RH_FRAGMENT_OUTPUTS ? t : RH_FRAGMENT_OUTPUTS - 1], a.src_factor, a.dst_factor);
                         }
                     }
                 };
@@ -568,41 +614,36 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
 #pragma nounroll
                     for (int phase = 0; phase < 2; phase++) shade(phase ? cov_b : cov_a, phase != 0);
                 }
-                }       // passes of the hit
-            }
+            }       // passes of the hit
         }
+        RH_PHASE_MARK(2)
     }
-    __syncthreads();
 
     // 3. write the tile back
 #pragma unroll
     for (int t = 0; t < NA; t++) {
         const rh_attach_dev& at = a.att[t];
         if (at.load_op == 0u && start == end) continue;
-        for (int i = tid; i < RH_TILE_W * RH_TILE_H; i += RH_TILE_THREADS) {
-            const int lx = i & (RH_TILE_W - 1), ly = i / RH_TILE_W;
-            const uint32_t gx = (uint32_t)(ox + lx), gy = (uint32_t)(oy + ly);
-            if (gx < p.width && gy < p.height) {
-                store_pixel(at, (size_t)gy * at.pitch_px + gx,
-                            tile_px[t][((ly / REGION_H) * 2 + (lx / REGION_W)) * REGION_STRIDE + (ly % REGION_H) * REGION_W + (lx % REGION_W)]);
-            }
+        for (int i = lane; i < TILE_PX; i += 64) {
+            const uint32_t gx = (uint32_t)(ox + (i & (TILE - 1))), gy = (uint32_t)(oy + i / TILE);
+            if (gx < p.width && gy < p.height) store_pixel(at, (size_t)gy * at.pitch_px + gx, lds.px[t][i]);
         }
     }
+    RH_PHASE_MARK(3)
+    RH_PHASE_END
 }
 
 // ---- multisampled passes -----------------------------------------------------------------------------------------
-// Same structure as tile_kernel (one workgroup per tile, one wave per region, LDS-resident tile, clusters in order),
-// with S colour samples per pixel: coverage is evaluated per sample at the standard sample locations with the same
-// integer edge functions and top-left rule, the fragment function runs once per pixel and triangle with its inputs
-// interpolated at the pixel centre, and its colour is blended into every covered sample.  The tile's samples go back to
-// the multisampled texture and their mean (round to nearest, ties to even; the sum is exact) to the resolve target.
+// Same structure as tile_kernel (one wave per tile, LDS-resident tile, records in order), with S colour samples per
+// pixel: coverage is evaluated per sample at the standard sample locations with the same integer edge functions and
+// top-left rule, the fragment function runs once per pixel and triangle with its inputs interpolated at the pixel
+// centre, and its colour is blended into every covered sample.  The tile's samples go back to the multisampled texture
+// and their mean (round to nearest, ties to even; the sum is exact) to the resolve target.
 // One attachment; every state is read at run time.
 template <int S>
 struct TileLdsMs {
-    ClusterRecord rec[RH_BATCH_CLUSTERS];
-    MsRecord<S> ms[RH_BATCH_CLUSTERS];
-    uint32_t rec_bbox[RH_BATCH_CLUSTERS];
-    uint32_t px[S][4 * REGION_STRIDE];               // one plane per sample index
+    alignas(16) uint32_t rec[ROUND * REC_WORDS];
+    uint32_t px[S][TILE_PX];               // one plane per sample index
 };
 
 template <int S>
@@ -611,17 +652,14 @@ RH_DEVICE void tile_kernel_ms(const rh_tile_args& a) {
     if (a.pair_total && *a.pair_total > a.pair_capacity) return;     // the pair arrays were too small: the host runs the pass again
     const rh_draw_params& p = a.p;
     const rh_attach_dev& at = a.att[0];
-    const int tid = (int)threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = (int)threadIdx.x;
     const uint32_t tile = blockIdx.x + p.tile_first;
-    const int ox = (int)(tile % p.tiles_x) * RH_TILE_W, oy = (int)(tile / p.tiles_x) * RH_TILE_H;
+    const int ox = (int)(tile % p.tiles_x) * TILE, oy = (int)(tile / p.tiles_x) * TILE;
     const uint32_t start = a.tile_start[tile], end = a.tile_end[tile];
-    auto lds_index = [](int lx, int ly) { return ((ly / REGION_H) * 2 + (lx / REGION_W)) * REGION_STRIDE + (ly % REGION_H) * REGION_W + (lx % REGION_W); };
 
     // 1. the tile's samples into LDS (every tile: the resolve below rewrites the whole target)
-    for (int i = tid; i < RH_TILE_W * RH_TILE_H; i += RH_TILE_THREADS) {
-        const int lx = i & (RH_TILE_W - 1), ly = i / RH_TILE_W;
-        const uint32_t gx = (uint32_t)(ox + lx), gy = (uint32_t)(oy + ly);
+    for (int i = lane; i < TILE_PX; i += 64) {
+        const uint32_t gx = (uint32_t)(ox + (i & (TILE - 1))), gy = (uint32_t)(oy + i / TILE);
         const bool inside = gx < p.width && gy < p.height;
         const uint32_t* src = reinterpret_cast<const uint32_t*>(at.ptr) + ((size_t)gy * at.pitch_px + gx) * S;
 #pragma unroll
@@ -631,114 +669,99 @@ RH_DEVICE void tile_kernel_ms(const rh_tile_args& a) {
                 if (at.load_op != 0u) v = at.clear_rgba8;
                 else { v = src[sidx]; if (at.format == FORMAT_BGRA_U8) v = swap_rb(v); }
             }
-            lds.px[sidx][lds_index(lx, ly)] = v;
+            lds.px[sidx][i] = v;
         }
     }
 
     FragmentContext fctx; fctx.p = &p; fctx.static_rgba8 = 0u; fctx.static_filter = 0u;
-    const int rx0 = (wave & 1) * REGION_W, ry0 = (wave >> 1) * REGION_H;
-    const int sx0 = max(rx0, p.sc_x0 - ox), sy0 = max(ry0, p.sc_y0 - oy);
-    const int sx1 = min(rx0 + REGION_W - 1, p.sc_x1 - 1 - ox), sy1 = min(ry0 + REGION_H - 1, p.sc_y1 - 1 - oy);
-    const bool region_live = sx0 <= sx1 && sy0 <= sy1;
     const float lane_f = (float)lane;
+    const float* const recf = reinterpret_cast<const float*>(lds.rec);
 
-    // 2. batches of clusters
-    for (uint32_t base = start; base < end; base += RH_BATCH_CLUSTERS) {
-        __syncthreads();
-        if (tid < RH_BATCH_CLUSTERS) {
-            const uint32_t ci = base + (uint32_t)tid;
-            uint32_t bb = BBOX_EMPTY;
-            if (ci < end) bb = setup_cluster<S>(p, a.list[ci], ox, oy, lds.rec[tid], &lds.ms[tid]);
-            lds.rec_bbox[tid] = bb;
-        }
-        __syncthreads();
-        if (!region_live) continue;
-        for (int round = 0; round < RH_BATCH_CLUSTERS / 64; round++) {
-            const uint32_t bb = lds.rec_bbox[round * 64 + lane];
-            const bool hit = (int)(bb & 0xffu) <= sx1 && (int)((bb >> 16) & 0xffu) >= sx0 && (int)((bb >> 8) & 0xffu) <= sy1 && (int)(bb >> 24) >= sy0;
-            unsigned long long mask = __ballot(hit);
-            while (mask) {
-                const int ci = round * 64 + __builtin_ctzll(mask);
-                mask &= mask - 1;
-                const ClusterRecord& r = lds.rec[ci];
-                const MsRecord<S>& m = lds.ms[ci];
-                const float* const rf = reinterpret_cast<const float*>(&r);
-                const uint32_t flags = __builtin_amdgcn_readfirstlane(r.flags);
-                const uint32_t hb = __builtin_amdgcn_readfirstlane(lds.rec_bbox[ci]);
-                const bool has_a = (flags & FLAG_HAS_A) != 0u, has_b = (flags & FLAG_HAS_B) != 0u;
-                const bool any_persp = (flags & (FLAG_PERSP_A | FLAG_PERSP_B)) != 0u;
-                const int hx0 = max((int)(hb & 0xffu), sx0), hy0 = max((int)((hb >> 8) & 0xffu), sy0);
-                const int hx1 = min((int)((hb >> 16) & 0xffu), sx1), hy1 = min((int)(hb >> 24), sy1);
-                const int w = hx1 - hx0 + 1, npx = w * (hy1 - hy0 + 1);
-                const float wf = (float)w, invw = __builtin_amdgcn_rcpf(wf);
-                for (int first = 0; first < npx; first += 64) {
-                    const float idx_f = lane_f + (float)first;
-                    const float row_f = floorf(__builtin_fmaf(idx_f, invw, 0.5f * invw));
-                    const float col_f = __builtin_fmaf(-row_f, wf, idx_f);
-                    const float lxf = (float)hx0 + col_f, lyf = (float)hy0 + row_f;
-                    const bool live = idx_f < (float)npx;
-                    const int lx = (int)lxf, ly = (int)lyf;
-                    const int pidx = live ? lds_index(lx, ly) : 0;
-                    // sample masks of the two triangles (a missing triangle's record holds stale values: masked by has_*)
-                    uint32_t mask_a = 0u, mask_b = 0u;
+    // 2. rounds of records
+    for (uint32_t base = start; base < end; base += ROUND) {
+        const int n = (int)min((uint32_t)ROUND, end - base);
+        stage_records(lds.rec, a.rec, base, n, lane);
+        const uint32_t bb = lane < n ? lds.rec[lane * REC_WORDS] : BBOX_EMPTY;
+        unsigned long long mask = __ballot((bb & 0xffu) <= ((bb >> 16) & 0xffu));
+        while (mask) {
+            const int ci = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            const float* const rf = recf + ci * REC_WORDS;
+            const uint32_t flags = __builtin_amdgcn_readfirstlane(lds.rec[ci * REC_WORDS + 1]);
+            const uint32_t hb = __builtin_amdgcn_readfirstlane(lds.rec[ci * REC_WORDS]);
+            const float* const ef = reinterpret_cast<const float*>(a.ext + (size_t)(base + (uint32_t)ci) * a.ext_bytes);
+            const MsRecord<S>& m = *reinterpret_cast<const MsRecord<S>*>(ef + EXT_WORDS);
+            const bool has_a = (flags & FLAG_HAS_A) != 0u, has_b = (flags & FLAG_HAS_B) != 0u;
+            const bool any_persp = (flags & (FLAG_PERSP_A | FLAG_PERSP_B)) != 0u;
+            const int hx0 = (int)(hb & 0xffu), hy0 = (int)((hb >> 8) & 0xffu), hx1 = (int)((hb >> 16) & 0xffu), hy1 = (int)(hb >> 24);
+            const int w = hx1 - hx0 + 1, npx = w * (hy1 - hy0 + 1);
+            const float wf = (float)w, invw = __builtin_amdgcn_rcpf(wf);
+            for (int first = 0; first < npx; first += 64) {
+                const float idx_f = lane_f + (float)first;
+                const float row_f = floorf(__builtin_fmaf(idx_f, invw, 0.5f * invw));
+                const float col_f = __builtin_fmaf(-row_f, wf, idx_f);
+                const float lxf = (float)hx0 + col_f, lyf = (float)hy0 + row_f;
+                const bool live = idx_f < (float)npx;
+                const int lx = (int)lxf, ly = (int)lyf;
+                const int pidx = live ? ly * TILE + lx : 0;
+                // sample masks of the two triangles (a missing triangle's constants are unset: masked by has_*)
+                uint32_t mask_a = 0u, mask_b = 0u;
 #pragma unroll
-                    for (int sidx = 0; sidx < S; sidx++) {
-                        int ia = 0, ib = 0;
+                for (int sidx = 0; sidx < S; sidx++) {
+                    int ia = 0, ib = 0;
 #pragma unroll
-                        for (int e = 0; e < 3; e++) {
-                            ia |= __mul24(m.A[0][e], lx) + __mul24(m.B[0][e], ly) + m.T[0][sidx][e];
-                            ib |= __mul24(m.A[1][e], lx) + __mul24(m.B[1][e], ly) + m.T[1][sidx][e];
-                        }
-                        mask_a |= ia >= 0 ? 1u << sidx : 0u;
-                        mask_b |= ib >= 0 ? 1u << sidx : 0u;
+                    for (int e = 0; e < 3; e++) {
+                        ia |= __mul24(m.A[0][e], lx) + __mul24(m.B[0][e], ly) + m.T[0][sidx][e];
+                        ib |= __mul24(m.A[1][e], lx) + __mul24(m.B[1][e], ly) + m.T[1][sidx][e];
                     }
-                    if (!(live && has_a)) mask_a = 0u;
-                    if (!(live && has_b)) mask_b = 0u;
-                    auto shade = [&](uint32_t cov, bool use_b) {
-                        const float* const tp = rf + (use_b ? TRI_FLOATS : 0);
-                        const float dx = __builtin_fmaf(lxf, 256.0f, -tp[OFF_XR]), dy = __builtin_fmaf(lyf, 256.0f, -tp[OFF_YR]);
-                        Varyings var; float* vf = reinterpret_cast<float*>(&var);
-#pragma unroll
-                        for (int v = 0; v < NV; v++) vf[v] = __builtin_fmaf(tp[OFF_DVDY + v], dy, __builtin_fmaf(tp[OFF_DVDX + v], dx, tp[OFF_V0 + v]));
-                        if (any_persp) {
-                            const bool persp = use_b ? (flags & FLAG_PERSP_B) != 0u : (flags & FLAG_PERSP_A) != 0u;
-                            const float q = __builtin_fmaf(tp[OFF_Q0 + 2], dy, __builtin_fmaf(tp[OFF_Q0 + 1], dx, tp[OFF_Q0]));
-#pragma unroll
-                            for (int v = 0; v < NV; v++) vf[v] = persp ? vf[v] / q : vf[v];
-                        }
-                        if (cov) {
-                            Outputs out;
-                            fragment_main(fctx, var, out);
-#pragma unroll
-                            for (int sidx = 0; sidx < S; sidx++)
-                                if (cov & (1u << sidx)) {
-                                    uint32_t* px = &lds.px[sidx][pidx];
-                                    *px = blend<0>(*px, out.color[0], a.src_factor, a.dst_factor);
-                                }
-                        }
-                    };
-                    // triangle A's fragment first; a pixel with samples in both triangles gets a second invocation for B
-                    const bool first_is_b = mask_a == 0u;
-                    shade(first_is_b ? mask_b : mask_a, first_is_b);
-                    const uint32_t second = mask_a != 0u ? mask_b : 0u;
-                    if (__any(second != 0u)) shade(second, true);
+                    mask_a |= ia >= 0 ? 1u << sidx : 0u;
+                    mask_b |= ib >= 0 ? 1u << sidx : 0u;
                 }
+                if (!(live && has_a)) mask_a = 0u;
+                if (!(live && has_b)) mask_b = 0u;
+                auto shade = [&](uint32_t cov, bool use_b) {
+                    const float* const tp = rf + HDR_WORDS + (use_b ? TRI_WORDS : 0);
+                    const float dx = __builtin_fmaf(lxf, 256.0f, -tp[OFF_XR]), dy = __builtin_fmaf(lyf, 256.0f, -tp[OFF_YR]);
+                    Varyings var; float* vf = reinterpret_cast<float*>(&var);
+#pragma unroll
+                    for (int v = 0; v < NV; v++) vf[v] = __builtin_fmaf(tp[OFF_DVDY + v], dy, __builtin_fmaf(tp[OFF_DVDX + v], dx, tp[OFF_V0 + v]));
+                    if (any_persp) {
+                        const bool persp = use_b ? (flags & FLAG_PERSP_B) != 0u : (flags & FLAG_PERSP_A) != 0u;
+                        const float* const eq = ef + (use_b ? EXT_TRI_WORDS : 0) + EOFF_Q;
+                        const float q = __builtin_fmaf(eq[2], dy, __builtin_fmaf(eq[1], dx, eq[0]));
+#pragma unroll
+                        for (int v = 0; v < NV; v++) vf[v] = persp ? vf[v] / q : vf[v];
+                    }
+                    if (cov) {
+                        Outputs out;
+                        fragment_main(fctx, var, out);
+#pragma unroll
+                        for (int sidx = 0; sidx < S; sidx++)
+                            if (cov & (1u << sidx)) {
+                                uint32_t* px = &lds.px[sidx][pidx];
+                                *px = blend<0>(*px, out.color[0], a.src_factor, a.dst_factor);
+                            }
+                    }
+                };
+                // triangle A's fragment first; a pixel with samples in both triangles gets a second invocation for B
+                const bool first_is_b = mask_a == 0u;
+                shade(first_is_b ? mask_b : mask_a, first_is_b);
+                const uint32_t second = mask_a != 0u ? mask_b : 0u;
+                if (__any(second != 0u)) shade(second, true);
             }
         }
     }
-    __syncthreads();
 
     // 3. samples back to the multisampled texture, their mean to the resolve target
     const float inv_s = 1.0f / (float)S;
-    for (int i = tid; i < RH_TILE_W * RH_TILE_H; i += RH_TILE_THREADS) {
-        const int lx = i & (RH_TILE_W - 1), ly = i / RH_TILE_W;
-        const uint32_t gx = (uint32_t)(ox + lx), gy = (uint32_t)(oy + ly);
+    for (int i = lane; i < TILE_PX; i += 64) {
+        const uint32_t gx = (uint32_t)(ox + (i & (TILE - 1))), gy = (uint32_t)(oy + i / TILE);
         if (!(gx < p.width && gy < p.height)) continue;
         uint32_t* dst = reinterpret_cast<uint32_t*>(at.ptr) + ((size_t)gy * at.pitch_px + gx) * S;
         uint32_t sum[4] = { 0u, 0u, 0u, 0u };
 #pragma unroll
         for (int sidx = 0; sidx < S; sidx++) {
-            const uint32_t v = lds.px[sidx][lds_index(lx, ly)];
+            const uint32_t v = lds.px[sidx][i];
             sum[0] += v & 0xffu; sum[1] += (v >> 8) & 0xffu; sum[2] += (v >> 16) & 0xffu; sum[3] += v >> 24;
             if (at.load_op != 0u || start != end) dst[sidx] = at.format == FORMAT_BGRA_U8 ? swap_rb(v) : v;
         }
@@ -780,6 +803,13 @@ RH_DEVICE void tile_dispatch_wide(const rh_tile_args& a) {
 
 } // namespace rh
 
+#ifndef RH_TILE_MIN_WAVES
+#define RH_TILE_MIN_WAVES 8        // 64 registers per lane: eight tile waves per SIMD
+#endif
+extern "C" __global__ __launch_bounds__(256) void rh_setup(rh_setup_args a) { rh::setup_kernel<1>(a); }
+extern "C" __global__ __launch_bounds__(256) void rh_setup_ms2(rh_setup_args a) { rh::setup_kernel<2>(a); }
+extern "C" __global__ __launch_bounds__(256) void rh_setup_ms4(rh_setup_args a) { rh::setup_kernel<4>(a); }
+extern "C" __global__ __launch_bounds__(256) void rh_setup_ms8(rh_setup_args a) { rh::setup_kernel<8>(a); }
 extern "C" __global__ __launch_bounds__(RH_TILE_THREADS, RH_TILE_MIN_WAVES) void rh_tile_1(rh_tile_args a) { rh::tile_dispatch<1>(a); }
 extern "C" __global__ __launch_bounds__(RH_TILE_THREADS, RH_TILE_MIN_WAVES) void rh_tile_2(rh_tile_args a) { rh::tile_dispatch<2>(a); }
 extern "C" __global__ __launch_bounds__(RH_TILE_THREADS, RH_TILE_MIN_WAVES) void rh_tile_3(rh_tile_args a) { rh::tile_dispatch<3>(a); }

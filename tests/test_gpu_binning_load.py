@@ -29,7 +29,7 @@ def draw_both_forms(scene, what):
 
 
 def test_100k_alpha_quads_on_1024_tiles(oracle):
-    """2048x1024 target (32 x 32 tiles of 64x32): tile numbers need 10 bits; ~12 layers of pre-multiplied alpha, so
+    """2048x1024 target (64 x 32 tiles of 32x32): tile numbers need 11 bits; ~12 layers of pre-multiplied alpha, so
     every pixel depends on the order of its quads."""
     scene = scenes.random_quads_scene(100_000, 16, 2048, 1024, seed=101)
     stats = draw_both_forms(scene, "100k quads / 1024 tiles")
@@ -38,12 +38,12 @@ def test_100k_alpha_quads_on_1024_tiles(oracle):
 
 @pytest.mark.parametrize("blend", ["additive", "premultiplied"])
 def test_300k_tiny_quads_at_4k(oracle, blend):
-    """BASELINE configs[2] shape at a size the oracle draws in a second: 2..8 px quads at 3840x2160 (4080 tiles, 12 bits);
+    """BASELINE configs[2] shape at a size the oracle draws in a second: 2..8 px quads at 3840x2160 (8160 tiles, 13 bits);
     additive as the configuration has it, and pre-multiplied so that the order inside a tile shows."""
     scene = scenes.tiny_quads_scene(300_000, 3840, 2160, seed=102)
     scene["blend"] = blend
     stats = draw_both_forms(scene, f"300k tiny quads at 4K / {blend}")
-    assert stats["tiles_x"] * stats["tiles_y"] == 60 * 68
+    assert stats["tiles_x"] * stats["tiles_y"] == 120 * 68
 
 
 def test_headline_shape_200k_quads_at_4k(oracle):
@@ -54,8 +54,8 @@ def test_headline_shape_200k_quads_at_4k(oracle):
 
 
 def test_more_than_65536_tiles(oracle):
-    """16384 x 8224 target: 256 x 257 = 65792 tiles, tile numbers need 17 bits (BASELINE configs[3] has 16384^2)."""
-    scene = scenes.random_quads_scene(6000, 48, 16384, 8224, seed=104)
+    """8192 x 8224 target: 256 x 257 = 65792 tiles, tile numbers need 17 bits (BASELINE configs[3]: 16384^2, 18 bits)."""
+    scene = scenes.random_quads_scene(6000, 48, 8192, 8224, seed=104)
     # a few columns of overlapping quads so that some tiles hold deep, order-sensitive lists
     rng = np.random.default_rng(104)
     stack = scene["instances"][:1500]

@@ -1,0 +1,9 @@
+#!/bin/bash
+# Builds the hello fragment code object with extra compiler flags into /tmp/<name>.frag.co (kernel experiments; run
+# with RH_FRAG_CO_OVERRIDE=/tmp/<name>.frag.co).  usage: tools/build_frag_variant.sh <name> [flags...]
+set -e
+NAME=$1; shift
+D=renderer_amd/csrc/shader; S=renderer_amd/shaders
+/opt/rocm/bin/hipcc --genco --no-gpu-bundle-output --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -Wno-pass-failed \
+  -I $D "$@" "-DRH_VERTEX_SOURCE=\"$PWD/$S/hello.vert.hip\"" '-DRH_VERTEX_TAG="hello"' "-DRH_FRAGMENT_SOURCE=\"$PWD/$S/hello.frag.hip\"" \
+  $D/rh_stage_fragment.hip -o /tmp/$NAME.frag.co

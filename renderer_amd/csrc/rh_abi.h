@@ -41,7 +41,16 @@ struct rh_slot_dev {
     uint32_t format;         // RH_FORMAT_*
     uint32_t filter;         // RH_FILTER_* (for texture slots: the filter of the sampler that follows)
     uint32_t size_bytes;     // buffers: capacity in bytes (whole buffer is bound, reference src/instanced.rs:18)
+    // Textures: null, or RH_POLY_COPIES copies of the texture made for bilinear sampling.  An item of a copy is the
+    // whole 2x2 footprint of a texel, 16 bytes: t(x, y), t(x+1, y), t(x, y+1), t(x+1, y+1) (clamped to the layer), so a
+    // fragment fetches its four taps with ONE load.  Copy k regroups the items of every row by their phase modulo
+    // S = 2^k: item x sits at column (x mod S) * (width / S) + x / S.  A minified draw samples texels S apart; in the
+    // copy for its S they are neighbours, so the lanes of a wave share cache lines instead of fetching one line per
+    // fragment (a CU fills its L1 at 64 B per clock: at one 128-byte line per fragment that is the whole frame time).
+    // Copy 0 is the plain order.
+    const void* poly;
 };
+#define RH_POLY_COPIES 6
 
 struct rh_draw_params {
     const float* attr[RH_DEV_MAX_ATTRIBUTES];        // indexed by shader location

@@ -112,6 +112,11 @@ struct rh_texture {
     uint32_t bpt = 0;
     void* dptr = nullptr;          // layer-major, tightly packed rows
     size_t bytes = 0;
+    // phase-regrouped copies for minified sampling (rh_slot_dev::poly): made when a pass first samples the texture with
+    // the specialised bilinear body, and again whenever the texels may have changed since
+    void* poly = nullptr;
+    bool poly_valid = false;
+    bool poly_always = false;      // the texels can change behind the library's back (render target, device pointer handed out)
 };
 
 struct rh_sampler { rh_device* dev; uint32_t filter; };
@@ -435,6 +440,7 @@ int rh_texture_create(rh_device* dev, uint32_t width, uint32_t height, uint32_t 
     rh_texture* t = new rh_texture();
     t->dev = dev; t->width = width; t->height = height; t->layers = layers; t->format = format; t->samples = samples; t->usage = usage;
     t->bpt = bpt; t->bytes = (size_t)width * height * layers * bpt * samples;      // the samples of a pixel are adjacent
+    t->poly_always = (usage & RH_TEXTURE_RENDER_ATTACHMENT) != 0;
     if (device_alloc(dev, t->bytes, &t->dptr)) { delete t; return 1; }
     device_retain(dev);
     // wgpu textures start zero-initialised
@@ -456,6 +462,7 @@ int rh_texture_write(rh_texture* tex, uint32_t x, uint32_t y, uint32_t layer, ui
     if (data_len < (size_t)bytes_per_row * (height - 1) + row_bytes) return fail("rh_texture_write: %zu bytes of data are too few for %u rows", data_len, height);
     if (set_device(tex->dev)) return 1;
     uint8_t* dst = (uint8_t*)tex->dptr + (((size_t)layer * tex->height + y) * tex->width + x) * tex->bpt;
+    tex->poly_valid = false;
     RH_HIP(hipMemcpy2DAsync(dst, (size_t)tex->width * tex->bpt, data, bytes_per_row, row_bytes, height, hipMemcpyHostToDevice, tex->dev->stream));
     return 0;
 }
@@ -481,7 +488,7 @@ int rh_texture_size(rh_texture* tex, uint32_t* width, uint32_t* height, uint32_t
     return 0;
 }
 
-void* rh_texture_device_ptr(rh_texture* tex) { return tex ? tex->dptr : nullptr; }
+void* rh_texture_device_ptr(rh_texture* tex) { if (tex) tex->poly_always = true; return tex ? tex->dptr : nullptr; }
 void rh_texture_retain(rh_texture* tex) { if (tex) tex->refs.fetch_add(1); }
 void rh_texture_release(rh_texture* tex) {
     if (!tex) return;
@@ -489,6 +496,7 @@ void rh_texture_release(rh_texture* tex) {
     rh_device* dev = tex->dev;
     (void)hipSetDevice(dev->ordinal);
     device_free(dev, tex->bytes, tex->dptr);
+    if (tex->poly) device_free(dev, tex->bytes * 4 * RH_POLY_COPIES, tex->poly);
     delete tex;
     device_release(dev);
 }
@@ -870,6 +878,22 @@ int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer) {
         }
         if (all_rgba8 && !(any_linear && any_nearest)) tex_class = any_nearest ? 2 : 1;
         ta.variant = (blend_class && tex_class && !dev->general_kernels) ? 1 + (blend_class - 1) * 2 + (tex_class - 1) : 0;
+        // The specialised bilinear body reads minified textures through phase-regrouped copies (rh_slot_dev::poly): made
+        // here, on the pass's stream, when the texels may have changed since the copies were made.
+        if (ta.variant != 0 && tex_class == 1 && pl->samples == 1 && total > 0) {
+            for (size_t i = 0; i < pl->slots.size(); i++) {
+                rh_texture* t = pl->slots[i].tex;
+                // (item offsets are computed in f32: 16 bytes a texel, exact up to 2^20 texels)
+                if (!t || pl->slots[i].kind != RH_SLOT_TEXTURE || t->width % 32u != 0 || t->bytes > ((size_t)4 << 20)) continue;
+                if (!t->poly) { if (device_alloc(dev, t->bytes * 4 * RH_POLY_COPIES, &t->poly)) return 1; t->poly_valid = false; }
+                if (!t->poly_valid || t->poly_always) {
+                    rhk::polyphase_build(t->dptr, t->poly, t->width, t->height, t->layers, s);
+                    RH_HIP(hipGetLastError());
+                    t->poly_valid = true;
+                }
+                ta.p.slots[i].poly = t->poly;
+            }
+        }
     }
     if (timing_mark(dev)) return 1;
     if (pl->samples > 1) {

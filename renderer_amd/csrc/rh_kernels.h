@@ -22,6 +22,9 @@ int radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint3
 void tile_ranges(const uint32_t* keys, uint32_t n, uint32_t* tile_start, uint32_t* tile_end, uint32_t n_tiles, hipStream_t s,
                  const unsigned long long* pair_total = nullptr);
 
+// Fills the RH_POLY_COPIES footprint copies of an RGBA8 texture (dst: RH_POLY_COPIES * width * height * layers items of 16 bytes).
+void polyphase_build(const void* src, void* dst, uint32_t width, uint32_t height, uint32_t layers, hipStream_t s);
+
 void copy_texture_to_buffer(const uint8_t* tex, uint32_t tex_pitch_bytes, uint32_t ox, uint32_t oy, uint32_t bpt, uint32_t w, uint32_t h,
                             uint8_t* dst, uint32_t dst_pitch, hipStream_t s);
 

@@ -257,6 +257,26 @@ extern "C" __global__ __launch_bounds__(256) void rh_copy_texture_to_buffer(cons
     }
 }
 
+// ---- footprint copies of a texture, regrouped by phase (rh_slot_dev::poly) ----------------------------------------------------
+// One thread per texel: item (x, y) of a layer = the four taps of a bilinear sample whose base texel is (x, y); copy k
+// (S = 2^k) gets the item at column (x mod S) * (width / S) + x / S of its row.  width is a multiple of 32.
+extern "C" __global__ __launch_bounds__(256) void rh_polyphase_build(const uint32_t* src, uint4* dst, uint32_t width, uint32_t height, uint32_t layers) {
+    const size_t texels = (size_t)width * height * layers;
+    const size_t i = (size_t)blockIdx.x * WG + threadIdx.x;
+    if (i >= texels) return;
+    const uint32_t x = (uint32_t)(i % width);
+    const size_t row = i / width;
+    const uint32_t y = (uint32_t)(row % height);
+    const size_t dx = x + 1 < width ? 1 : 0, dy = y + 1 < height ? width : 0;
+    const uint4 v = make_uint4(src[i], src[i + dx], src[i + dy], src[i + dy + dx]);
+    const size_t row_base = row * width;
+#pragma unroll
+    for (uint32_t k = 0; k < RH_POLY_COPIES; k++) {
+        const uint32_t S = 1u << k;
+        dst[k * texels + row_base + (x & (S - 1u)) * (width >> k) + (x >> k)] = v;
+    }
+}
+
 // ---- host-callable launchers ----------------------------------------------------------------------------------------------
 namespace rhk {
 
@@ -310,6 +330,12 @@ void tile_ranges(const uint32_t* keys, uint32_t n, uint32_t* tile_start, uint32_
     (void)hipMemsetAsync(tile_start, 0, (size_t)n_tiles * 8, s);
     if (n == 0) return;
     hipLaunchKernelGGL(rh_tile_ranges, dim3(div_up(n, WG)), dim3(WG), 0, s, keys, n, tile_start, tile_end, pair_total);
+}
+
+void polyphase_build(const void* src, void* dst, uint32_t width, uint32_t height, uint32_t layers, hipStream_t s) {
+    const size_t texels = (size_t)width * height * layers;
+    if (texels == 0) return;
+    hipLaunchKernelGGL(rh_polyphase_build, dim3(div_up(texels, WG)), dim3(WG), 0, s, (const uint32_t*)src, (uint4*)dst, width, height, layers);
 }
 
 void copy_texture_to_buffer(const uint8_t* tex, uint32_t tex_pitch_bytes, uint32_t ox, uint32_t oy, uint32_t bpt, uint32_t w, uint32_t h,

@@ -47,6 +47,8 @@ RH_DEVICE float clampf(float x, float lo, float hi) { return __builtin_amdgcn_fm
 struct Texture2D {
     const uint8_t* data; uint32_t width, height, layers, format;
     uint32_t static_rgba8;      // 1: known to be RGBA8, at least 2x2 and at most 16 MiB (texel offsets exact in f32)
+    const uint8_t* poly;        // footprint copies of the texture regrouped by phase (rh_slot_dev::poly) or null
+    int grad_log2;              // floor(log2) of the largest |d varying / dx| per pixel of the primitive being shaded: picks the copy
 
     // Texel (x, y) of `layer` (generic path, any supported format): 8-bit channels on the 0..255 scale, float channels
     // as they are (a half converts to float exactly).
@@ -93,12 +95,30 @@ struct Texture2D {
         float4 r;
         if (static_rgba8 || ((format == FORMAT_RGBA_U8 || format == FORMAT_BGRA_U8) && W >= 2 && H >= 2)) {
             // 4-byte texels: the taps of a row are adjacent and the rows are one pitch apart: two 8-byte loads
-            uint32_t off;
-            if (static_rgba8) off = layer * (height * (width << 2)) + (uint32_t)__builtin_fmaf(jbf, (float)(W << 2), ibf * 4.0f);   // exact: below 2^24
-            else off = (__umul24(layer * height + (uint32_t)(int)jbf, width) + (uint32_t)(int)ibf) << 2;
-            const u32x2_a4 r0 = *reinterpret_cast<const u32x2_a4*>(data + off);
-            const u32x2_a4 r1 = *reinterpret_cast<const u32x2_a4*>(data + (width << 2) + off);
-#define RH_LERP_BYTE(ch, UB) { const float p00 = UB(r0.x), p10 = UB(r0.y), p01 = UB(r1.x), p11 = UB(r1.y); \
+            uint32_t t00, t10, t01, t11;
+            if (static_rgba8 && poly) {
+                // texels per pixel along x -> copy k with S = 2^k about that many (k = 0: plain order).  k comes from the
+                // primitive, not from the lane: uniform, and built with scalar integer operations only.  Any k gives the
+                // same texels; the choice only decides how many cache lines a wave touches.
+                int k = grad_log2 + (31 - __builtin_clz(width));
+                k = __builtin_amdgcn_readfirstlane(k < 0 ? 0 : (k > RH_POLY_COPIES - 1 ? RH_POLY_COPIES - 1 : k));
+                const float Sf = __uint_as_float((uint32_t)(127 + k) << 23), invS = __uint_as_float((uint32_t)(127 - k) << 23);   // 2^k, 2^-k
+                const float WSf = (float)W * invS;
+                const float xqf = floorf(ibf * invS), phf = __builtin_fmaf(xqf, -Sf, ibf);        // x = xq * S + ph, exact
+                const float permf = __builtin_fmaf(phf, WSf, xqf);
+                const uint32_t off = (uint32_t)__builtin_fmaf(jbf, (float)(W << 4), permf * 16.0f);   // exact: below 2^24
+                const uint8_t* const base = poly + ((size_t)k * layers + layer) * (height * (width << 4));
+                const uint4 f = *reinterpret_cast<const uint4*>(base + off);                      // the four taps
+                t00 = f.x; t10 = f.y; t01 = f.z; t11 = f.w;
+            } else {
+                uint32_t off;
+                if (static_rgba8) off = layer * (height * (width << 2)) + (uint32_t)__builtin_fmaf(jbf, (float)(W << 2), ibf * 4.0f);   // exact: below 2^24
+                else off = (__umul24(layer * height + (uint32_t)(int)jbf, width) + (uint32_t)(int)ibf) << 2;
+                const u32x2_a4 r0 = *reinterpret_cast<const u32x2_a4*>(data + off);
+                const u32x2_a4 r1 = *reinterpret_cast<const u32x2_a4*>(data + (width << 2) + off);
+                t00 = r0.x; t10 = r0.y; t01 = r1.x; t11 = r1.y;
+            }
+#define RH_LERP_BYTE(ch, UB) { const float p00 = UB(t00), p10 = UB(t10), p01 = UB(t01), p11 = UB(t11); \
                                const float top = __builtin_fmaf(a, p10 - p00, p00); \
                                const float bot = __builtin_fmaf(a, p11 - p01, p01); \
                                r.ch = __builtin_fmaf(b, bot, __builtin_fmaf(-b, top, top)) * scale; }
@@ -127,6 +147,7 @@ struct Texture2D {
 struct BindingContext {
     const rh_draw_params* p;
     uint32_t static_rgba8 = 0, static_filter = 0;
+    int grad_log2 = -126;        // see Texture2D::grad_log2 (set per primitive by the tile kernel)
     template <typename T> RH_DEVICE const T* storage(uint32_t set, uint32_t binding) const {
         return reinterpret_cast<const T*>(p->slots[set * 4 + binding].ptr);
     }
@@ -135,7 +156,8 @@ struct BindingContext {
     }
     RH_DEVICE Texture2D texture2d(uint32_t set, uint32_t binding) const {
         const rh_slot_dev& s = p->slots[set * 4 + binding];
-        return Texture2D{ reinterpret_cast<const uint8_t*>(s.ptr), s.width, s.height, s.layers, s.format, static_rgba8 };
+        return Texture2D{ reinterpret_cast<const uint8_t*>(s.ptr), s.width, s.height, s.layers, s.format, static_rgba8,
+                          reinterpret_cast<const uint8_t*>(s.poly), grad_log2 };
     }
     RH_DEVICE Sampler sampler(uint32_t set, uint32_t binding) const {
         return Sampler{ p->slots[set * 4 + binding].filter, static_filter };

@@ -47,7 +47,10 @@ static_assert(ROUND == 16 || ROUND == 32 || ROUND == 64, "a round is at most one
 // ---- record layout (dwords) -------------------------------------------------------------------------------------------
 // Set-up record, staged through LDS by the tile wave:
 //   [0] box x0 | y0 << 8 | x1 << 16 | y1 << 24 (tile-relative, inclusive; BBOX_EMPTY: contributes nothing)
-//   [1] flags   [2..4] shared diagonal of a rectangle (edge 1 of triangle A): A, B, T   [5..7] unused
+//   [1] flags
+//   [2] floor(log2(1.41 * largest |d varying / dx| per pixel)) over the cluster's planes, as an integer: how far apart
+//       neighbouring fragments sample a texture, in units of its size   [3] unused
+//   [4..6] shared diagonal of a rectangle (edge 1 of triangle A): A, B, T   [7] unused
 //   then per triangle TRI_WORDS: XR, YR (reference vertex in 24.8 fixed point relative to the tile origin, as f32, exact),
 //   v0[NV], dvdx[NV], dvdy[NV] (gradients per 1/256 pixel)
 // Extended record (global memory, read only by the clusters that need it), per triangle EXT_TRI_WORDS:
@@ -283,7 +286,13 @@ RH_DEVICE void setup_pair(const rh_draw_params& p, uint32_t cluster, int ox, int
 #pragma unroll
     for (int i = 0; i < REC_WORDS; i++) w[i] = 0u;
     w[0] = bbox; w[1] = flags;
-    w[2] = edge_word(ta, 1, false); w[3] = edge_word(ta, 4, false); w[4] = edge_word(ta, 7, false);      // the shared diagonal (used when RECT: never BIG)
+    w[4] = edge_word(ta, 1, false); w[5] = edge_word(ta, 4, false); w[6] = edge_word(ta, 7, false);      // the shared diagonal (used when RECT: never BIG)
+    {   float g = 0.0f;
+        const TriSetup& tg = has_a ? ta : tb;
+#pragma unroll
+        for (int v = 0; v < NV; v++) g = fmaxf(g, fabsf(tg.dvdx[v]));
+        w[2] = (uint32_t)((int)((__float_as_uint(g * (256.0f * 1.41421356f)) >> 23) & 0xffu) - 127);
+    }
     const TriSetup* const ts[2] = { &ta, &tb };
 #pragma unroll
     for (int t = 0; t < 2; t++) {
@@ -540,6 +549,7 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
                 npass = 1;
                 rf = recf + (int)(m.y & 0xffu) * REC_WORDS;
                 flags = FLAG_RECT | FLAG_HAS_A | FLAG_HAS_B;
+                fctx.grad_log2 = (int)lds.rec[(int)(info & 0xffu) * REC_WORDS + 2];      // (the first member's: a hint only)
                 k += (int)(run & 7u);
             } else {
                 const uint32_t box = __builtin_amdgcn_readlane(box_v, k);
@@ -550,14 +560,47 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
                 npass = (npix + 63) >> 6;
                 rf = recf + (int)(info & 0xffu) * REC_WORDS;
                 flags = (info >> 8) & 0x3fu;
+                fctx.grad_log2 = (int)lds.rec[(int)(info & 0xffu) * REC_WORDS + 2];
                 if ((flags & (FLAG_RECT | FLAG_PERSP_A | FLAG_PERSP_B)) != FLAG_RECT)
                     ef = reinterpret_cast<const float*>(a.ext + (size_t)(base + (info & 0xffu)) * a.ext_bytes);
                 k++;
             }
             const float invw = __builtin_amdgcn_rcpf(wf), half_invw = 0.5f * invw;
+            float idx_f = idx0_f;
+            if ((flags & (FLAG_RECT | FLAG_PERSP_A | FLAG_PERSP_B)) == FLAG_RECT) {
+                // Axis-aligned rectangle with affine varyings (what the reference's quads are): every pixel of the box is
+                // covered and the shared diagonal alone says by which triangle.  The SIMD issues one instruction of ANY
+                // kind per ~2.3 cycles (scalar ones and branches included), so this loop is kept free of per-pass tests.
+                const float4 dg = *reinterpret_cast<const float4*>(rf + 4);                 // diagonal A, B, T
+                const float pbase_f = __builtin_fmaf(hy0f, (float)(TILE * 4), hx0f * 4.0f);  // byte offset of the box origin in the tile
+                uint8_t* const px_bytes = reinterpret_cast<uint8_t*>(tile_px);
+                for (int pass = 0; pass < npass; pass++, idx_f += 64.0f) {
+                    // floor((idx + 0.5) / w): the half keeps the quotient at least 1/128 away from an integer
+                    const float row_f = floorf(__builtin_fmaf(idx_f, invw, half_invw));
+                    const float col_f = __builtin_fmaf(-row_f, wf, idx_f);
+                    if (idx_f < limit_f) {
+                        const float lxf = hx0f + col_f, lyf = hy0f + row_f;          // tile-relative pixel, exact small integers
+                        const uint32_t pb = (uint32_t)__builtin_fmaf(row_f, (float)(TILE * 4), __builtin_fmaf(col_f, 4.0f, pbase_f));
+                        // triangle B where the diagonal's edge function is negative: its planes sit TRI_WORDS further on
+                        const uint32_t in_b = __float_as_uint(__builtin_fmaf(dg.x, lxf, __builtin_fmaf(dg.y, lyf, dg.z))) >> 31;
+                        const float* const tp = rf + HDR_WORDS + in_b * (uint32_t)TRI_WORDS;
+                        const float dx = __builtin_fmaf(lxf, 256.0f, -tp[OFF_XR]), dy = __builtin_fmaf(lyf, 256.0f, -tp[OFF_YR]);   // exact
+                        Varyings var; float* vf = reinterpret_cast<float*>(&var);
+#pragma unroll
+                        for (int v = 0; v < NV; v++) vf[v] = __builtin_fmaf(tp[OFF_DVDY + v], dy, __builtin_fmaf(tp[OFF_DVDX + v], dx, tp[OFF_V0 + v]));
+                        Outputs out;
+                        fragment_main(fctx, var, out);
+#pragma unroll
+                        for (int t = 0; t < NA; t++) {
+                            blend_pixel<BLEND>(reinterpret_cast<PxT*>(px_bytes + (size_t)t * (TILE_PX * sizeof(PxT)) + (size_t)pb * (sizeof(PxT) / 4)), a.att[t],
+                                               out.color[t < RH_FRAGMENT_OUTPUTS ? t : RH_FRAGMENT_OUTPUTS - 1], a.src_factor, a.dst_factor);
+                        }
+                    }
+                }
+                continue;
+            }
             const bool has_a = (flags & FLAG_HAS_A) != 0u, has_b = (flags & FLAG_HAS_B) != 0u;
             const bool any_persp = (flags & (FLAG_PERSP_A | FLAG_PERSP_B)) != 0u;
-            float idx_f = idx0_f;
             for (int pass = 0; pass < npass; pass++, idx_f += 64.0f) {
                 const bool live = idx_f < limit_f;
                 // floor((idx + 0.5) / w): the half keeps the quotient at least 1/128 away from an integer
@@ -568,7 +611,7 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
                 bool cov_a, cov_b, overlap = false;
                 if (flags & FLAG_RECT) {
                     // every pixel of the box is covered; the shared diagonal (edge 1 of A) says by which triangle
-                    const bool in_a = __float_as_int(__builtin_fmaf(rf[2], lxf, __builtin_fmaf(rf[3], lyf, rf[4]))) >= 0;
+                    const bool in_a = __float_as_int(__builtin_fmaf(rf[4], lxf, __builtin_fmaf(rf[5], lyf, rf[6]))) >= 0;
                     cov_a = live && in_a; cov_b = live && !in_a;
                 } else {
                     // (a missing triangle's record holds zeros: masked by has_*)

@@ -40,7 +40,8 @@ struct rh_slot_dev {
     uint32_t width, height, layers;
     uint32_t format;         // RH_FORMAT_*
     uint32_t filter;         // RH_FILTER_* (for texture slots: the filter of the sampler that follows)
-    uint32_t size_bytes;     // buffers: capacity in bytes (whole buffer is bound, reference src/instanced.rs:18)
+    uint32_t size_bytes;     // buffers: capacity in bytes (whole buffer is bound, reference src/instanced.rs:18);
+                             // textures with `poly`: bytes of one footprint copy
     // Textures: null, or RH_POLY_COPIES copies of the texture made for bilinear sampling.  An item of a copy is the
     // whole 2x2 footprint of a texel, 16 bytes: t(x, y), t(x+1, y), t(x, y+1), t(x+1, y+1) (clamped to the layer), so a
     // fragment fetches its four taps with ONE load.  Copy k regroups the items of every row by their phase modulo
@@ -120,8 +121,9 @@ struct rh_tile_args {
     uint32_t n_att;
     uint32_t src_factor, dst_factor;
     // Which specialisation of the kernel body to run: 0 = every state read at run time; otherwise
-    // 1 + (blend_class - 1) * 2 + (texture_class - 1) with blend_class 1 = (One, OneMinusSrcAlpha), 2 = (One, One) and
-    // texture_class 1 = every bound texture RGBA8, at least 2x2 and at most 16 MiB, with linear samplers, 2 = the same with nearest samplers.
+    // 1 + (blend_class - 1) * 3 + (texture_class - 1) with blend_class 1 = (One, OneMinusSrcAlpha), 2 = (One, One) and
+    // texture_class 1 = every bound texture RGBA8, at least 2x2 and at most 16 MiB, with linear samplers, 2 = the same with
+    // nearest samplers, 3 = class 1 and every bound texture has footprint copies (rh_slot_dev::poly).
     uint32_t variant;
     // The pass may be queued before the host knows how many (tile, cluster) pairs it has: the kernels size their work
     // from *pair_total, and when that exceeds `pair_capacity` (the room the host gave the pair arrays) nobody writes

@@ -44,8 +44,10 @@ uint32_t bytes_per_texel(uint32_t format) {
 // Growable device scratch area.
 struct Scratch {
     void* ptr = nullptr; size_t cap = 0;
+    bool fixed = false;             // a slice of the library's static device array: never grown, never freed
     int ensure(size_t bytes) {
         if (bytes <= cap) return 0;
+        if (fixed) return fail("the pass needs a scratch area of %zu bytes; the entry point that allocates nothing holds %zu", bytes, cap);
         if (ptr) (void)hipFree(ptr);
         ptr = nullptr; cap = 0;
         size_t want = bytes + bytes / 2 + 4096;
@@ -53,7 +55,7 @@ struct Scratch {
         cap = want;
         return 0;
     }
-    void release() { if (ptr) (void)hipFree(ptr); ptr = nullptr; cap = 0; }
+    void release() { if (ptr && !fixed) (void)hipFree(ptr); ptr = nullptr; cap = 0; }
     template <typename T> T* as() { return reinterpret_cast<T*>(ptr); }
 };
 
@@ -69,9 +71,10 @@ struct rh_device {
     uint32_t strip_row0 = 0, strip_row1 = 0;       // sort-first strip restriction; row1 == 0: none
     int general_kernels = 0;                       // RH_OPTION_GENERAL_KERNELS
     std::string name;
-    // scratch for binning
-    Scratch ranges, block_sums, chunk_tmp, keys_a, vals_a, keys_b, vals_b, hist, tile_start;
-    Scratch rec, ext;                              // set-up records of the sorted (tile, cluster) pairs
+    // scratch of a render pass: binning arrays and the set-up records of the sorted (tile, cluster) pairs.  `grown` is
+    // allocated on demand; `held` is carved out of the library's static device array (rh_submit_static)
+    struct PassScratch { Scratch ranges, block_sums, chunk_tmp, keys_a, vals_a, keys_b, vals_b, hist, tile_start, rec, ext; };
+    PassScratch grown, held;
     Scratch png_slots, png_rows, png_out;          // GPU PNG encoder scratch
     void* png_host = nullptr; size_t png_host_cap = 0;   // pinned
     unsigned long long* d_total = nullptr;
@@ -267,8 +270,9 @@ void device_release(rh_device* dev) {
     if (dev->refs.fetch_sub(1) != 1) return;
     (void)hipSetDevice(dev->ordinal);
     (void)hipStreamSynchronize(dev->stream);
-    Scratch* all[] = { &dev->ranges, &dev->block_sums, &dev->chunk_tmp, &dev->keys_a, &dev->vals_a, &dev->keys_b, &dev->vals_b,
-                       &dev->hist, &dev->tile_start, &dev->rec, &dev->ext, &dev->png_slots, &dev->png_rows, &dev->png_out };
+    rh_device::PassScratch& g = dev->grown;
+    Scratch* all[] = { &g.ranges, &g.block_sums, &g.chunk_tmp, &g.keys_a, &g.vals_a, &g.keys_b, &g.vals_b,
+                       &g.hist, &g.tile_start, &g.rec, &g.ext, &dev->png_slots, &dev->png_rows, &dev->png_out };
     for (Scratch* s : all) s->release();
     for (hipEvent_t e : dev->event_pool) (void)hipEventDestroy(e);
     for (hipEvent_t e : dev->timing_events) (void)hipEventDestroy(e);
@@ -730,7 +734,9 @@ int launch_module_kernel(hipFunction_t fn, uint32_t grid, uint32_t block, void* 
     return 0;
 }
 
-int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer) {
+// `ss`: the scratch areas the pass works in; `no_alloc`: called from rh_submit_static, which must not allocate -- timing
+// marks (they create events) and footprint copies that do not exist yet are left out.
+int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer, rh_device::PassScratch& ss, bool no_alloc) {
     rh_pipeline* pl = c.pipeline;
     const rh_texture* t0 = c.attachments[0].texture;
     const uint32_t W = t0->width, H = t0->height;
@@ -788,24 +794,24 @@ int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer) {
     const uint32_t n_clusters = empty_scissor ? 0u : p.n_clusters;
 
     hipStream_t s = dev->stream;
-    if (dev->tile_start.ensure((size_t)n_tiles * 8)) return 1;                    // [start of every tile | end of every tile]
-    uint32_t* const tile_start = dev->tile_start.as<uint32_t>(); uint32_t* const tile_end = tile_start + n_tiles;
+    if (ss.tile_start.ensure((size_t)n_tiles * 8)) return 1;                    // [start of every tile | end of every tile]
+    uint32_t* const tile_start = ss.tile_start.as<uint32_t>(); uint32_t* const tile_end = tile_start + n_tiles;
     uint64_t total = 0;                          // pairs, or the room for them when the count has not come back yet
     bool deferred = false;
     const unsigned long long* pair_total = nullptr;
     const int ms_index = pl->samples == 1 ? 0 : (pl->samples == 2 ? 1 : (pl->samples == 4 ? 2 : 3));
     const uint32_t rec_bytes = pl->fs->info.rec_bytes;
     const uint32_t ext_bytes = pl->fs->info.ext_bytes + (pl->samples > 1 ? 4u * RH_MS_EXTRA_WORDS(pl->samples) : 0u);
-    if (timing_mark(dev)) return 1;
+    if (!no_alloc && timing_mark(dev)) return 1;
     if (n_clusters > 0) {
         const uint32_t n_blocks = (n_clusters + 255) / 256;
-        if (dev->ranges.ensure((size_t)n_clusters * sizeof(rh_tile_range)) || dev->block_sums.ensure((size_t)n_blocks * 4) ||
-            dev->chunk_tmp.ensure((size_t)rhk::scan_chunks_for(n_blocks) * 4)) return 1;
+        if (ss.ranges.ensure((size_t)n_clusters * sizeof(rh_tile_range)) || ss.block_sums.ensure((size_t)n_blocks * 4) ||
+            ss.chunk_tmp.ensure((size_t)rhk::scan_chunks_for(n_blocks) * 4)) return 1;
         rh_bin_count_args ba;
         ba.p = p; ba.p.n_clusters = n_clusters;
-        ba.ranges = dev->ranges.as<rh_tile_range>(); ba.block_sums = dev->block_sums.as<uint32_t>();
+        ba.ranges = ss.ranges.as<rh_tile_range>(); ba.block_sums = ss.block_sums.as<uint32_t>();
         if (launch_module_kernel(pl->vs->bin_count, n_blocks, 256, &ba, sizeof ba, s)) return 1;
-        rhk::exclusive_scan(dev->block_sums.as<uint32_t>(), n_blocks, dev->chunk_tmp.as<uint32_t>(), dev->d_total, s, dev->general_kernels != 0);
+        rhk::exclusive_scan(ss.block_sums.as<uint32_t>(), n_blocks, ss.chunk_tmp.as<uint32_t>(), dev->d_total, s, dev->general_kernels != 0);
         RH_HIP(hipMemcpyAsync(dev->h_total, dev->d_total, 8, hipMemcpyDeviceToHost, s));
         // Once a pass has been seen the rest is queued without waiting for the count, with room for `pair_guess`
         // pairs; the kernels read the count on the device.  (The option that forces the general kernels also forces
@@ -824,22 +830,22 @@ int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer) {
         if (total > 0) {
             const uint32_t n = (uint32_t)total;
             const uint32_t sort_blocks = rhk::sort_blocks_for(n);
-            if (dev->keys_a.ensure((size_t)n * 4) || dev->vals_a.ensure((size_t)n * 4) || dev->keys_b.ensure((size_t)n * 4) || dev->vals_b.ensure((size_t)n * 4) ||
-                dev->hist.ensure((size_t)sort_blocks * 256 * 4) || dev->chunk_tmp.ensure((size_t)rhk::scan_chunks_for(sort_blocks * 256) * 4)) return 1;
-            rhk::bin_emit(dev->ranges.as<rh_tile_range>(), n_clusters, p.tiles_x, dev->block_sums.as<uint32_t>(),
-                          dev->keys_a.as<uint32_t>(), dev->vals_a.as<uint32_t>(), s, pair_total, n);
-            int where = rhk::radix_sort_pairs(dev->keys_a.as<uint32_t>(), dev->vals_a.as<uint32_t>(), dev->keys_b.as<uint32_t>(), dev->vals_b.as<uint32_t>(),
-                                              n, bits_for(n_tiles), dev->hist.as<uint32_t>(), dev->chunk_tmp.as<uint32_t>(), s, dev->general_kernels != 0, pair_total);
-            uint32_t* sorted_keys = where ? dev->keys_b.as<uint32_t>() : dev->keys_a.as<uint32_t>();
-            uint32_t* sorted_vals = where ? dev->vals_b.as<uint32_t>() : dev->vals_a.as<uint32_t>();
+            if (ss.keys_a.ensure((size_t)n * 4) || ss.vals_a.ensure((size_t)n * 4) || ss.keys_b.ensure((size_t)n * 4) || ss.vals_b.ensure((size_t)n * 4) ||
+                ss.hist.ensure((size_t)sort_blocks * 256 * 4) || ss.chunk_tmp.ensure((size_t)rhk::scan_chunks_for(sort_blocks * 256) * 4)) return 1;
+            rhk::bin_emit(ss.ranges.as<rh_tile_range>(), n_clusters, p.tiles_x, ss.block_sums.as<uint32_t>(),
+                          ss.keys_a.as<uint32_t>(), ss.vals_a.as<uint32_t>(), s, pair_total, n);
+            int where = rhk::radix_sort_pairs(ss.keys_a.as<uint32_t>(), ss.vals_a.as<uint32_t>(), ss.keys_b.as<uint32_t>(), ss.vals_b.as<uint32_t>(),
+                                              n, bits_for(n_tiles), ss.hist.as<uint32_t>(), ss.chunk_tmp.as<uint32_t>(), s, dev->general_kernels != 0, pair_total);
+            uint32_t* sorted_keys = where ? ss.keys_b.as<uint32_t>() : ss.keys_a.as<uint32_t>();
+            uint32_t* sorted_vals = where ? ss.vals_b.as<uint32_t>() : ss.vals_a.as<uint32_t>();
             rhk::tile_ranges(sorted_keys, n, tile_start, tile_end, n_tiles, s, pair_total);
             // triangle set-up: one record per pair, in list order
-            if (dev->rec.ensure((size_t)n * rec_bytes) || dev->ext.ensure((size_t)n * ext_bytes)) return 1;
+            if (ss.rec.ensure((size_t)n * rec_bytes) || ss.ext.ensure((size_t)n * ext_bytes)) return 1;
             rh_setup_args sa;
             memset(&sa, 0, sizeof sa);
             sa.p = p; sa.p.n_clusters = n_clusters;
             sa.clusters = sorted_vals; sa.tiles = sorted_keys;
-            sa.rec = dev->rec.as<uint8_t>(); sa.ext = dev->ext.as<uint8_t>(); sa.ext_bytes = ext_bytes;
+            sa.rec = ss.rec.as<uint8_t>(); sa.ext = ss.ext.as<uint8_t>(); sa.ext_bytes = ext_bytes;
             sa.n_pairs = n; sa.pair_total = pair_total;
             if (launch_module_kernel(pl->fs->setup[ms_index], (n + 255) / 256, 256, &sa, sizeof sa, s)) return 1;
         }
@@ -851,7 +857,7 @@ int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer) {
     rh_tile_args ta;
     memset(&ta, 0, sizeof ta);
     ta.p = p; ta.p.n_clusters = n_clusters;
-    ta.rec = dev->rec.as<uint8_t>(); ta.ext = dev->ext.as<uint8_t>(); ta.ext_bytes = ext_bytes;
+    ta.rec = ss.rec.as<uint8_t>(); ta.ext = ss.ext.as<uint8_t>(); ta.ext_bytes = ext_bytes;
     ta.tile_start = tile_start; ta.tile_end = tile_end;
     ta.pair_total = pair_total; ta.pair_capacity = (uint32_t)total;
     ta.n_att = (uint32_t)c.attachments.size();
@@ -877,25 +883,30 @@ int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer) {
             if (sl.kind == RH_SLOT_SAMPLER) { if (sl.filter == RH_FILTER_LINEAR) any_linear = true; else any_nearest = true; }
         }
         if (all_rgba8 && !(any_linear && any_nearest)) tex_class = any_nearest ? 2 : 1;
-        ta.variant = (blend_class && tex_class && !dev->general_kernels) ? 1 + (blend_class - 1) * 2 + (tex_class - 1) : 0;
-        // The specialised bilinear body reads minified textures through phase-regrouped copies (rh_slot_dev::poly): made
-        // here, on the pass's stream, when the texels may have changed since the copies were made.
-        if (ta.variant != 0 && tex_class == 1 && pl->samples == 1 && total > 0) {
+        // The specialised bilinear body can read its textures through footprint copies regrouped by phase
+        // (rh_slot_dev::poly): made here, on the pass's stream, when the texels may have changed since they were made.
+        // (Item offsets are computed in f32: 16 bytes a texel, exact up to 2^20 texels.)
+        bool all_poly = blend_class && tex_class == 1 && !dev->general_kernels && pl->samples == 1 && total > 0;
+        for (const SlotRef& sl : pl->slots)
+            if (sl.kind == RH_SLOT_TEXTURE && (sl.tex->width % 32u != 0 || sl.tex->bytes > ((size_t)4 << 20) || (no_alloc && !sl.tex->poly))) all_poly = false;
+        if (all_poly) {
             for (size_t i = 0; i < pl->slots.size(); i++) {
                 rh_texture* t = pl->slots[i].tex;
-                // (item offsets are computed in f32: 16 bytes a texel, exact up to 2^20 texels)
-                if (!t || pl->slots[i].kind != RH_SLOT_TEXTURE || t->width % 32u != 0 || t->bytes > ((size_t)4 << 20)) continue;
-                if (!t->poly) { if (device_alloc(dev, t->bytes * 4 * RH_POLY_COPIES, &t->poly)) return 1; t->poly_valid = false; }
+                if (!t || pl->slots[i].kind != RH_SLOT_TEXTURE) continue;
+                if (!t->poly) { if (device_alloc(dev, t->bytes * 4 * RH_POLY_COPIES, &t->poly)) return 1; t->poly_valid = false; }     // (no_alloc: every copy exists, see all_poly)
                 if (!t->poly_valid || t->poly_always) {
                     rhk::polyphase_build(t->dptr, t->poly, t->width, t->height, t->layers, s);
                     RH_HIP(hipGetLastError());
                     t->poly_valid = true;
                 }
                 ta.p.slots[i].poly = t->poly;
+                ta.p.slots[i].size_bytes = (uint32_t)(t->bytes * 4);
             }
+            tex_class = 3;
         }
+        ta.variant = (blend_class && tex_class && !dev->general_kernels) ? 1 + (blend_class - 1) * 3 + (tex_class - 1) : 0;
     }
-    if (timing_mark(dev)) return 1;
+    if (!no_alloc && timing_mark(dev)) return 1;
     if (pl->samples > 1) {
         // every tile runs: the resolve rewrites the whole target from the multisampled texture (Load included)
         hipFunction_t fn = pl->fs->tile_ms[ms_index - 1];
@@ -906,7 +917,7 @@ int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer) {
         hipFunction_t fn = any_float ? pl->fs->tile_wide[c.attachments.size() - 1] : pl->fs->tile[c.attachments.size() - 1];
         if (launch_module_kernel(fn, n_launch_tiles, RH_TILE_THREADS, &ta, sizeof ta, s)) return 1;
     }
-    if (timing_mark(dev)) return 1;
+    if (!no_alloc && timing_mark(dev)) return 1;
 
     if (deferred) { dev->pending_pass = &c; dev->pending_capacity = (uint32_t)total; }
     dev->stats.clusters = n_clusters; dev->stats.bin_entries = deferred ? 0 : total;
@@ -933,7 +944,7 @@ int resolve_pending(rh_device* dev) {
     // the attempt that wrote nothing is not a pass of its own: its timing marks go back to the pool
     for (int k = 0; k < 3 && dev->timing && !dev->timing_events.empty(); k++) { dev->event_pool.push_back(dev->timing_events.back()); dev->timing_events.pop_back(); }
     dev->stats.reruns++;
-    return execute_pass(dev, c, false);
+    return execute_pass(dev, c, false, dev->grown, false);
 }
 
 int execute_copy(rh_device* dev, const CopyCmd& c) {
@@ -957,7 +968,7 @@ int rh_submit(rh_device* dev, rh_cmdbuf* const* list, size_t n) {
         if (!rc) {
             for (const Cmd& c : cb->cmds) {
                 rc = resolve_pending(dev);
-                if (!rc) rc = c.kind == 0 ? execute_pass(dev, c.pass, true) : execute_copy(dev, c.copy);
+                if (!rc) rc = c.kind == 0 ? execute_pass(dev, c.pass, true, dev->grown, false) : execute_copy(dev, c.copy);
                 if (rc) break;
             }
             if (!rc) rc = resolve_pending(dev);       // (the commands go away with the buffer)

@@ -47,8 +47,9 @@ RH_DEVICE float clampf(float x, float lo, float hi) { return __builtin_amdgcn_fm
 struct Texture2D {
     const uint8_t* data; uint32_t width, height, layers, format;
     uint32_t static_rgba8;      // 1: known to be RGBA8, at least 2x2 and at most 16 MiB (texel offsets exact in f32)
-    const uint8_t* poly;        // footprint copies of the texture regrouped by phase (rh_slot_dev::poly) or null
-    int grad_log2;              // floor(log2) of the largest |d varying / dx| per pixel of the primitive being shaded: picks the copy
+    // Footprint copies regrouped by phase (rh_slot_dev::poly), when the kernel body was built for them: the copy picked for
+    // the primitive being shaded (PolyCopy, prepared once per primitive by the tile kernel), else null.
+    const uint8_t* poly_base; float poly_S, poly_invS, poly_WS;
 
     // Texel (x, y) of `layer` (generic path, any supported format): 8-bit channels on the 0..255 scale, float channels
     // as they are (a half converts to float exactly).
@@ -96,19 +97,12 @@ struct Texture2D {
         if (static_rgba8 || ((format == FORMAT_RGBA_U8 || format == FORMAT_BGRA_U8) && W >= 2 && H >= 2)) {
             // 4-byte texels: the taps of a row are adjacent and the rows are one pitch apart: two 8-byte loads
             uint32_t t00, t10, t01, t11;
-            if (static_rgba8 && poly) {
-                // texels per pixel along x -> copy k with S = 2^k about that many (k = 0: plain order).  k comes from the
-                // primitive, not from the lane: uniform, and built with scalar integer operations only.  Any k gives the
-                // same texels; the choice only decides how many cache lines a wave touches.
-                int k = grad_log2 + (31 - __builtin_clz(width));
-                k = __builtin_amdgcn_readfirstlane(k < 0 ? 0 : (k > RH_POLY_COPIES - 1 ? RH_POLY_COPIES - 1 : k));
-                const float Sf = __uint_as_float((uint32_t)(127 + k) << 23), invS = __uint_as_float((uint32_t)(127 - k) << 23);   // 2^k, 2^-k
-                const float WSf = (float)W * invS;
+            if (static_rgba8 && poly_base) {
+                const float Sf = poly_S, invS = poly_invS, WSf = poly_WS;
                 const float xqf = floorf(ibf * invS), phf = __builtin_fmaf(xqf, -Sf, ibf);        // x = xq * S + ph, exact
                 const float permf = __builtin_fmaf(phf, WSf, xqf);
                 const uint32_t off = (uint32_t)__builtin_fmaf(jbf, (float)(W << 4), permf * 16.0f);   // exact: below 2^24
-                const uint8_t* const base = poly + ((size_t)k * layers + layer) * (height * (width << 4));
-                const uint4 f = *reinterpret_cast<const uint4*>(base + off);                      // the four taps
+                const uint4 f = *reinterpret_cast<const uint4*>(poly_base + (size_t)layer * (height * (width << 4)) + off);   // the four taps
                 t00 = f.x; t10 = f.y; t01 = f.z; t11 = f.w;
             } else {
                 uint32_t off;
@@ -144,10 +138,26 @@ struct Texture2D {
     }
 };
 
+// The footprint copy of one texture slot picked for a primitive: copy k holds the items of every row regrouped by their
+// phase modulo S = 2^k, with S about the distance in texels between the samples of neighbouring fragments.  Any k gives
+// the same texels; the choice only decides how many cache lines a wave touches.
+struct PolyCopy {
+    const uint8_t* base = nullptr; float S = 1.0f, invS = 1.0f, WS = 0.0f;
+    // grad_log2 = floor(log2(1.41 * |d coordinate / dx| per pixel)); scalar integer work only (everything is uniform)
+    RH_DEVICE void pick(const rh_slot_dev& slot, int grad_log2) {
+        if (!slot.poly) { base = nullptr; return; }
+        int k = grad_log2 + (31 - __builtin_clz(slot.width | 1u));
+        k = k < 0 ? 0 : (k > RH_POLY_COPIES - 1 ? RH_POLY_COPIES - 1 : k);
+        base = reinterpret_cast<const uint8_t*>(slot.poly) + (size_t)((uint32_t)k * slot.size_bytes);    // size_bytes of a texture slot: bytes of one copy
+        S = __uint_as_float((uint32_t)(127 + k) << 23); invS = __uint_as_float((uint32_t)(127 - k) << 23);   // 2^k, 2^-k
+        WS = (float)slot.width * invS;
+    }
+};
+
 struct BindingContext {
     const rh_draw_params* p;
-    uint32_t static_rgba8 = 0, static_filter = 0;
-    int grad_log2 = -126;        // see Texture2D::grad_log2 (set per primitive by the tile kernel)
+    uint32_t static_rgba8 = 0, static_filter = 0, static_poly = 0;
+    PolyCopy poly[RH_DEV_MAX_SLOTS];     // (static_poly) per texture slot; slots a shader does not sample cost nothing
     template <typename T> RH_DEVICE const T* storage(uint32_t set, uint32_t binding) const {
         return reinterpret_cast<const T*>(p->slots[set * 4 + binding].ptr);
     }
@@ -156,8 +166,9 @@ struct BindingContext {
     }
     RH_DEVICE Texture2D texture2d(uint32_t set, uint32_t binding) const {
         const rh_slot_dev& s = p->slots[set * 4 + binding];
+        const PolyCopy& c = poly[set * 4 + binding];
         return Texture2D{ reinterpret_cast<const uint8_t*>(s.ptr), s.width, s.height, s.layers, s.format, static_rgba8,
-                          reinterpret_cast<const uint8_t*>(s.poly), grad_log2 };
+                          static_poly ? c.base : nullptr, c.S, c.invS, c.WS };
     }
     RH_DEVICE Sampler sampler(uint32_t set, uint32_t binding) const {
         return Sampler{ p->slots[set * 4 + binding].filter, static_filter };

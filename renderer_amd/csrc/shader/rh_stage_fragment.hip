@@ -463,7 +463,8 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
 
     FragmentContext fctx; fctx.p = &p;
     fctx.static_rgba8 = TEX != 0 ? 1u : 0u;
-    fctx.static_filter = TEX == 1 ? 1u + FILTER_LINEAR : (TEX == 2 ? 1u + FILTER_NEAREST : 0u);
+    fctx.static_filter = (TEX == 1 || TEX == 3) ? 1u + FILTER_LINEAR : (TEX == 2 ? 1u + FILTER_NEAREST : 0u);
+    fctx.static_poly = TEX == 3 ? 1u : 0u;
     PxT* const tile_px = &lds.px[0][0];
     const float lane_f = (float)lane;
     const float* const recf = reinterpret_cast<const float*>(lds.rec);
@@ -533,7 +534,7 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
             const float* rf;
             const float* ef = nullptr;                       // extended record (one hit per pass only)
             float hx0f, hy0f, wf, idx0_f, limit_f;
-            int npass;
+            int npass, grad_log2;
             if (info >> 31) {
                 const uint32_t run = __builtin_amdgcn_readlane(run_v, k);
                 const int c1 = (int)((run >> 10) & 127u), c2 = (int)((run >> 17) & 127u), c3 = (int)(run >> 24);
@@ -549,7 +550,7 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
                 npass = 1;
                 rf = recf + (int)(m.y & 0xffu) * REC_WORDS;
                 flags = FLAG_RECT | FLAG_HAS_A | FLAG_HAS_B;
-                fctx.grad_log2 = (int)lds.rec[(int)(info & 0xffu) * REC_WORDS + 2];      // (the first member's: a hint only)
+                grad_log2 = (int)lds.rec[(int)(info & 0xffu) * REC_WORDS + 2];      // (the first member's: a hint only)
                 k += (int)(run & 7u);
             } else {
                 const uint32_t box = __builtin_amdgcn_readlane(box_v, k);
@@ -560,10 +561,16 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
                 npass = (npix + 63) >> 6;
                 rf = recf + (int)(info & 0xffu) * REC_WORDS;
                 flags = (info >> 8) & 0x3fu;
-                fctx.grad_log2 = (int)lds.rec[(int)(info & 0xffu) * REC_WORDS + 2];
+                grad_log2 = (int)lds.rec[(int)(info & 0xffu) * REC_WORDS + 2];
                 if ((flags & (FLAG_RECT | FLAG_PERSP_A | FLAG_PERSP_B)) != FLAG_RECT)
                     ef = reinterpret_cast<const float*>(a.ext + (size_t)(base + (info & 0xffu)) * a.ext_bytes);
                 k++;
+            }
+            if (TEX == 3) {
+                // the footprint copy of every texture slot for this primitive (uniform; unused slots fold away)
+                const int g = __builtin_amdgcn_readfirstlane(grad_log2);
+#pragma unroll
+                for (int i = 0; i < RH_DEV_MAX_SLOTS; i++) fctx.poly[i].pick(p.slots[i], g);
             }
             const float invw = __builtin_amdgcn_rcpf(wf), half_invw = 0.5f * invw;
             float idx_f = idx0_f;
@@ -829,8 +836,10 @@ RH_DEVICE void tile_dispatch(const rh_tile_args& a) {
         switch (a.variant) {
             case 1: tile_kernel<NA, 1, 1>(a, lds); return;
             case 2: tile_kernel<NA, 1, 2>(a, lds); return;
-            case 3: tile_kernel<NA, 2, 1>(a, lds); return;
-            case 4: tile_kernel<NA, 2, 2>(a, lds); return;
+            case 3: tile_kernel<NA, 1, 3>(a, lds); return;
+            case 4: tile_kernel<NA, 2, 1>(a, lds); return;
+            case 5: tile_kernel<NA, 2, 2>(a, lds); return;
+            case 6: tile_kernel<NA, 2, 3>(a, lds); return;
             default: break;
         }
     }

@@ -209,6 +209,17 @@ void rh_cmdbuf_release(rh_cmdbuf* cb);
  * releases them.  Also polls pending map callbacks. */
 int rh_submit(rh_device* dev, rh_cmdbuf* const* list, size_t n);
 
+/* No counterpart in the reference.  For callers that cannot allocate device memory (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc): executes the command buffers like rh_submit but calls no hipMalloc,
+ * hipFree or other allocating routine.  The scratch of a render pass (binning arrays, set-up records) lives in a static
+ * device array of 40 MiB that every GPU the library runs on holds until the process ends; a pass is limited to 65536
+ * triangle pairs, 131072 (tile, triangle pair) pairs, 16384 tiles of 32x32 pixels and 16 MiB of set-up records, and is
+ * rejected with an error beyond that.  Differences from rh_submit: the command buffers are NOT consumed (release them
+ * with rh_cmdbuf_release once the work has finished; they may be submitted again), map callbacks are not driven, no
+ * timings are recorded, and textures are sampled through footprint copies only where an earlier rh_submit made them.
+ * Calls on one GPU share that GPU's array: calls that overlap on one GPU race. */
+int rh_submit_static(rh_device* dev, rh_cmdbuf* const* list, size_t n);
+
 /* ---- statistics of the most recent render pass executed (diagnostics for benchmarks) ------------------------------- */
 typedef struct rh_pass_stats {
     uint64_t clusters;        /* binning units (pairs of consecutive triangles) */

@@ -117,6 +117,7 @@ SIGNATURES = {
     "rh_cmd_finish": (C.c_int, [_P, _PP]),
     "rh_cmdbuf_release": (None, [_P]),
     "rh_submit": (C.c_int, [_P, _PP, C.c_size_t]),
+    "rh_submit_static": (C.c_int, [_P, _PP, C.c_size_t]),
     "rh_device_last_pass_stats": (C.c_int, [_P, C.POINTER(PassStats)]),
     "rh_device_drain_timings": (C.c_int, [_P, C.POINTER(Timings)]),
     "rh_compressor_create": (C.c_int, [_P, C.c_uint32, C.c_int, _PP]),

@@ -246,6 +246,23 @@ int rh_device_create(int hip_ordinal, uint32_t width, uint32_t height, rh_device
     }
     if (rh_texture_create(dev, width, height, 1, RH_FORMAT_BGRA_U8, 1,
                           RH_TEXTURE_RENDER_ATTACHMENT | RH_TEXTURE_COPY_SRC | RH_TEXTURE_BINDING, &dev->screen)) { delete dev; return 1; }
+    // rh_submit_static's scratch: this device's copy of the library's static device array, cut into the areas of a pass
+    {   void* base = nullptr; size_t bytes = 0;
+        hipError_t se = rhk::static_scratch(&base, &bytes);
+        if (se != hipSuccess) { rh_device_destroy(dev); return fail("rh_device_create: hipGetSymbolAddress of the static scratch array failed: %s", hipGetErrorString(se)); }
+        uint8_t* at = (uint8_t*)base;
+        auto carve = [&](Scratch& sc, size_t n_bytes) { sc.ptr = at; sc.cap = n_bytes; sc.fixed = true; at += (n_bytes + 255) & ~(size_t)255; };
+        rh_device::PassScratch& h = dev->held;
+        carve(h.ranges, (size_t)RH_STATIC_MAX_CLUSTERS * sizeof(rh_tile_range));
+        carve(h.block_sums, (size_t)(RH_STATIC_MAX_CLUSTERS / 256 + 1) * 4);
+        carve(h.chunk_tmp, 64 * 1024);
+        carve(h.keys_a, (size_t)RH_STATIC_MAX_PAIRS * 4); carve(h.vals_a, (size_t)RH_STATIC_MAX_PAIRS * 4);
+        carve(h.keys_b, (size_t)RH_STATIC_MAX_PAIRS * 4); carve(h.vals_b, (size_t)RH_STATIC_MAX_PAIRS * 4);
+        carve(h.hist, (size_t)(RH_STATIC_MAX_PAIRS / 4096 + 1) * 256 * 4);
+        carve(h.tile_start, (size_t)RH_STATIC_MAX_TILES * 8);
+        carve(h.rec, (size_t)RH_STATIC_RECORD_BYTES); carve(h.ext, (size_t)RH_STATIC_RECORD_BYTES);
+        if ((size_t)(at - (uint8_t*)base) > bytes) { rh_device_destroy(dev); return fail("rh_device_create: the static scratch array is smaller than its areas"); }
+    }
     *out = dev;
     return 0;
 }
@@ -978,6 +995,21 @@ int rh_submit(rh_device* dev, rh_cmdbuf* const* list, size_t n) {
     }
     if (!rc) rc = rh_poll(dev, 0);
     return rc;
+}
+
+int rh_submit_static(rh_device* dev, rh_cmdbuf* const* list, size_t n) {
+    if (!dev || (!list && n)) return fail("rh_submit_static: bad argument");
+    if (!dev->held.rec.ptr) return fail("rh_submit_static: the static scratch array of this device is not available");
+    if (set_device(dev)) return 1;
+    for (size_t i = 0; i < n; i++) {
+        const rh_cmdbuf* cb = list[i];
+        if (!cb) continue;
+        for (const Cmd& c : cb->cmds) {
+            // every pass waits for its pair count (that is a synchronisation, not an allocation) and works in the held areas
+            if (c.kind == 0 ? execute_pass(dev, c.pass, false, dev->held, true) : execute_copy(dev, c.copy)) return 1;
+        }
+    }
+    return 0;
 }
 
 int rh_device_drain_timings(rh_device* dev, rh_timings* out) {

@@ -4,7 +4,18 @@
 #include <stdint.h>
 #include "rh_abi.h"
 
+// Limits of the entry point that allocates nothing (rh_submit_static): its passes work in a static device array.
+#define RH_STATIC_MAX_CLUSTERS (64u * 1024u)            // triangle pairs of one pass
+#define RH_STATIC_MAX_PAIRS (128u * 1024u)              // (tile, cluster) pairs of one pass
+#define RH_STATIC_MAX_TILES (16u * 1024u)               // 32x32 tiles of the target (3840x2160 has 8160)
+#define RH_STATIC_RECORD_BYTES (16u * 1024u * 1024u)    // set-up records / extended records of one pass, each
+#define RH_STATIC_SCRATCH_BYTES (40u * 1024u * 1024u)
+
 namespace rhk {
+
+// Device address and size of the library's static scratch array on the CURRENT device (every GPU holds its own copy at
+// its own address).
+hipError_t static_scratch(void** ptr, size_t* bytes);
 
 uint32_t scan_chunks_for(uint32_t n);
 uint32_t sort_blocks_for(uint32_t n);

@@ -5,6 +5,11 @@
 #include "rh_abi.h"
 #include "rh_kernels.h"
 
+// Scratch of rh_submit_static (the entry point that allocates nothing): binning arrays and set-up records of one pass.
+// Every GPU the library runs on holds its own copy until the process ends.  In host code the name is only a stand-in:
+// the device address comes from hipGetSymbolAddress (rhk::static_scratch), once per device.
+static __device__ __align__(256) unsigned char scratch[RH_STATIC_SCRATCH_BYTES];
+
 namespace {
 
 constexpr int WG = 256;
@@ -281,6 +286,14 @@ extern "C" __global__ __launch_bounds__(256) void rh_polyphase_build(const uint3
 namespace rhk {
 
 static inline uint32_t div_up(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+
+hipError_t static_scratch(void** ptr, size_t* bytes) {
+    void* p = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return e;
+    *ptr = p; *bytes = (size_t)RH_STATIC_SCRATCH_BYTES;
+    return hipSuccess;
+}
 
 uint32_t scan_chunks_for(uint32_t n) { return div_up(n, SCAN_CHUNK); }
 uint32_t sort_blocks_for(uint32_t n) { return div_up(n, SORT_CHUNK); }

@@ -98,6 +98,20 @@ class Renderer:
         self.flushes += 1
         _ffi.check(_ffi.lib().rh_submit(self.device, arr, n))
 
+    def flush_static(self):
+        """flush() through rh_submit_static, the entry point that allocates nothing: the command buffers are not consumed
+        by the call and are released here once the work has finished."""
+        n = len(self.commands)
+        arr = (C.c_void_p * max(1, n))(*[c.value for c in self.commands])
+        commands, self.commands = self.commands, []
+        self.flushes += 1
+        try:
+            _ffi.check(_ffi.lib().rh_submit_static(self.device, arr, n))
+            self.synchronize()
+        finally:
+            for c in commands:
+                _ffi.lib().rh_cmdbuf_release(c)
+
     def synchronize(self):
         _ffi.check(_ffi.lib().rh_device_synchronize(self.device))
 

@@ -1,0 +1,72 @@
+"""rh_submit_static, the entry point that allocates nothing (its passes work in a static device array), against
+rh_submit: same command buffers, bit-identical targets, two calls in a row on one device, the second with a smaller
+input; and the limits are enforced with an error."""
+import numpy as np
+import pytest
+
+import scenes
+from test_gpu_parity import assert_same
+
+pytestmark = pytest.mark.gpu
+
+
+def draw_both(r, scene):
+    hs = scenes.HipScene(scene, renderer=r)
+    out = {}
+    for name in ("submit", "static"):
+        hs.renderer.render(hs.pipeline, hs.clear, hs.viewport, hs.count)
+        if name == "submit":
+            hs.renderer.finish_frame()
+        else:
+            hs.renderer.flush_static()
+        out[name] = {"color": hs.read_color()}
+        if scene.get("record"):
+            out[name]["recording"] = hs.read_recording()
+        # scribble over the target so that the second way has to draw every pixel again
+        hs.set_initial(np.full_like(out[name]["color"], 0x5a))
+    return out
+
+
+def test_static_submit_equals_submit_twice_in_a_row(oracle):
+    from renderer_amd import Renderer
+    W, H = 640, 360
+    r = Renderer(W, H)
+    try:
+        big = scenes.random_quads_scene(30_000, 14, W, H, seed=71)
+        got = draw_both(r, big)
+        assert_same(got["static"]["color"], got["submit"]["color"], "first call")
+        assert_same(got["static"]["color"], scenes.draw_oracle(big)["color"], "first call against the oracle")
+        # second call: a smaller input (fewer pairs, fewer records: the array keeps the first call's contents)
+        small = scenes.tiny_quads_scene(900, W, H, seed=72)
+        small["blend"] = "premultiplied"
+        got = draw_both(r, small)
+        assert_same(got["static"]["color"], got["submit"]["color"], "second, smaller call")
+        assert_same(got["static"]["color"], scenes.draw_oracle(small)["color"], "second call against the oracle")
+        # a recorded frame (two attachments) and the example's letterboxed viewport
+        ex = scenes.example_scene(37, W, H, record=True)
+        r2 = Renderer(W, H)
+        try:
+            got = draw_both(r2, ex)
+            assert_same(got["static"]["color"], got["submit"]["color"], "example frame")
+            assert_same(got["static"]["recording"], got["submit"]["recording"], "recording attachment")
+        finally:
+            r2.close()
+    finally:
+        r.close()
+
+
+def test_static_submit_rejects_a_pass_beyond_its_limits(oracle):
+    from renderer_amd import Renderer, RendererError
+    W, H = 640, 360
+    r = Renderer(W, H)
+    try:
+        scene = scenes.random_quads_scene(70_000, 4, W, H, seed=73)          # more than 65536 triangle pairs
+        hs = scenes.HipScene(scene, renderer=r)
+        r.render(hs.pipeline, hs.clear, hs.viewport, hs.count)
+        with pytest.raises(RendererError, match="allocates nothing"):
+            r.flush_static()
+        # the device goes on working
+        hs.draw()
+        assert_same(hs.read_color(), scenes.draw_oracle(scene)["color"], "after the rejected call")
+    finally:
+        r.close()

@@ -234,6 +234,7 @@ def main():
         b_min = args.quads * scene["instances"].shape[1] * 4 + args.width * args.height * 4 + tex_bytes
         tile_ms = timings["tile_ms"] / max(1, timings["passes"])
         bin_ms = timings["bin_ms"] / max(1, timings["passes"])
+        setup_ms = timings["setup_ms"] / max(1, timings["passes"])
         achieved = b_alg / (tile_ms * 1e-3) / 1e9 if tile_ms > 0 else 0.0
         c2_profiled = (args.workload == "c2" and args.quads == 10_000_000 and (args.width, args.height) == (3840, 2160))
         traffic = pmc_traffic_bytes("c1") if default_workload else (pmc_traffic_bytes("c2") if c2_profiled else None)
@@ -252,7 +253,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "rh_tile_1", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": b_alg, "compulsory_bytes_per_launch": b_min,
-                         "kernel_ms": tile_ms, "binning_ms": bin_ms,
+                         "kernel_ms": tile_ms, "binning_ms": bin_ms, "setup_ms": setup_ms,
                          "fragments_per_s": n_frag / (tile_ms * 1e-3) if tile_ms > 0 else 0.0},
         }
         if n_gpus == 1 and not args.no_cpu_baseline:

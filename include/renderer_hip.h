@@ -64,6 +64,9 @@ enum {
                                          filters at run time instead of the body specialised for the pipeline's state,
                                          and the prefix-sum form that serves any length instead of the short forms
                                          (identical results; for testing); default 0 */
+    RH_OPTION_BINNING_TICKETS = 5,    /* 1: the workgroups of the binning chain always take their place in the chain from
+                                         a ticket counter, as launches too large to fit the device at once do (identical
+                                         results; for testing); default 0 */
 };
 
 #define RH_MAX_ATTRIBUTES 8
@@ -235,8 +238,10 @@ int rh_device_last_pass_stats(rh_device* dev, rh_pass_stats* out);
  * passes to finish. */
 typedef struct rh_timings {
     uint32_t passes;          /* render passes covered */
-    double bin_ms;            /* vertex/binning phase: count, scan, emit, sort, tile ranges (incl. the host round trip) */
-    double tile_ms;           /* tile kernel (setup + coverage + shading + blend + store) */
+    double bin_ms;            /* vertex stage and binning: the (tile, primitive pair) array built and sorted (the form that
+                               * waits for the pair count includes that host round trip) */
+    double tile_ms;           /* tile kernel (coverage + shading + blend + store) */
+    double setup_ms;          /* triangle set-up: one record per (tile, primitive pair), tile list bounds */
 } rh_timings;
 int rh_device_drain_timings(rh_device* dev, rh_timings* out);
 

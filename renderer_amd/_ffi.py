@@ -22,6 +22,7 @@ OPTION_CLIP_TO_VIEWPORT = 0
 OPTION_TIMING = 1
 OPTION_STRIP_ROW0, OPTION_STRIP_ROW1 = 2, 3
 OPTION_GENERAL_KERNELS = 4
+OPTION_BINNING_TICKETS = 5
 COPY_BYTES_PER_ROW_ALIGNMENT = 256
 MAX_COLOR_TARGETS = 4
 
@@ -67,7 +68,7 @@ class PassStats(C.Structure):
 
 
 class Timings(C.Structure):
-    _fields_ = [("passes", C.c_uint32), ("bin_ms", C.c_double), ("tile_ms", C.c_double)]
+    _fields_ = [("passes", C.c_uint32), ("bin_ms", C.c_double), ("tile_ms", C.c_double), ("setup_ms", C.c_double)]
 
 
 MAP_CALLBACK = C.CFUNCTYPE(None, C.c_void_p, C.c_int)

@@ -4,7 +4,7 @@
 #pragma once
 #include <stdint.h>
 
-#define RH_DEVICE_ABI_VERSION 10u
+#define RH_DEVICE_ABI_VERSION 11u
 #define RH_MODULE_MAGIC 0x52484d4fu   // "RHMO"
 
 #define RH_DEV_MAX_ATTRIBUTES 8
@@ -81,6 +81,46 @@ struct rh_bin_count_args {
     uint32_t* block_sums;       // [ceil(n_clusters / 256)]
 };
 
+// ---- binning queued in three launches ------------------------------------------------------------------------------------
+// Once the host has a guess of how many (tile, cluster) pairs a pass makes, the pair array is built and sorted without
+// a host round trip and without global scans: every kernel of the chain hands its workgroups their position in the
+// output through a chained look-back (a workgroup publishes the count of its own part at once, adds up the counts
+// published by its predecessors until it meets one that already knows its prefix, then publishes its own prefix).
+// Workgroups take their place in the chain from a ticket counter, so a workgroup only ever waits for workgroups that
+// have started before it.  The state below is cleared before every pass.
+#define RH_SORT_MAX_PASSES 4            /* 8 bits of the tile number per pass */
+#define RH_LOOKBACK_SPINS (1u << 22)    /* polls of one predecessor before a workgroup gives up and reports a fault */
+#define RH_PAIR_THREADS 1024            /* rh_bin_pairs: threads of a workgroup, */
+#define RH_PAIR_PER_THREAD 2            /* consecutive clusters per thread, */
+#define RH_PAIR_PART (RH_PAIR_THREADS * RH_PAIR_PER_THREAD)    /* clusters per workgroup */
+#define RH_DIGIT_COPIES 8               /* copies of the digit counts the workgroups of rh_bin_pairs spread their adds over */
+struct rh_bin_state {
+    unsigned long long total;           // pairs of the pass (all of them, also when they do not fit the arrays)
+    uint32_t ticket[1 + RH_SORT_MAX_PASSES];    // [0] pair kernel, [1 + i] sorting pass i
+    uint32_t fault;                     // set when a look-back gave up (the results of the pass are then undefined)
+    uint32_t reserved[8];
+    uint32_t digit_count[RH_SORT_MAX_PASSES][RH_DIGIT_COPIES][256];    // pairs per value of every 8-bit digit of the tile number (sum of the copies)
+};
+// status words of the look-back chains: 2 flag bits on top, the count below
+#define RH_STATUS_PARTIAL 1u            /* the count of the workgroup's own part */
+#define RH_STATUS_PREFIX 2u             /* the count of everything up to and including the workgroup's part */
+
+// rh_bin_pairs (vertex-stage code object): one thread per cluster; runs the vertex function, finds the tiles the
+// cluster's bounding box touches, and writes its (tile, cluster) pairs in cluster order at the position the look-back
+// gives, while counting the digits of the tile numbers for the sorting passes.  Pairs beyond `capacity` are not
+// written; the last workgroup of the chain stores the total in state->total and in *host_total (pinned host memory).
+struct rh_bin_pairs_args {
+    rh_draw_params p;
+    rh_bin_state* state;
+    unsigned long long* cluster_status;     // [ceil(n_clusters / RH_PAIR_PART)], cleared
+    uint32_t* keys;                         // [capacity] tile of every pair
+    uint32_t* vals;                         // [capacity] cluster of every pair
+    uint32_t capacity;
+    uint32_t sort_passes;
+    uint32_t ticketed;                      // 0: all the workgroups fit the device at once and take their index as their place in the chain
+    unsigned long long* host_total;         // pinned host memory: [0] receives the total as well, [1] is set on a fault
+};
+
 // Triangle set-up (its own launch, one thread per (tile, cluster) pair of the sorted pair array): runs the vertex
 // function for the cluster's vertices and writes the pair's record: what a fragment needs to find its pixels and its
 // varyings, relative to the pair's tile.  Records are in list order, so a tile reads its records as one contiguous run.
@@ -94,6 +134,10 @@ struct rh_setup_args {
     uint32_t ext_bytes;
     uint32_t n_pairs;           // pairs, or the room for them when `pair_total` is set
     const unsigned long long* pair_total;
+    // [tiles] first pair and [tiles] one past the last pair of every tile, cleared beforehand: the threads at the ends of
+    // a tile's run write them
+    uint32_t* tile_start;
+    uint32_t* tile_end;
 };
 
 struct rh_attach_dev {

@@ -41,6 +41,8 @@ uint32_t bytes_per_texel(uint32_t format) {
     }
 }
 
+constexpr size_t STATE_HEADER_BYTES = (sizeof(rh_bin_state) + 255) & ~(size_t)255;
+
 // Growable device scratch area.
 struct Scratch {
     void* ptr = nullptr; size_t cap = 0;
@@ -70,6 +72,7 @@ struct rh_device {
     int clip_to_viewport = 1;
     uint32_t strip_row0 = 0, strip_row1 = 0;       // sort-first strip restriction; row1 == 0: none
     int general_kernels = 0;                       // RH_OPTION_GENERAL_KERNELS
+    int binning_tickets = 0;                       // RH_OPTION_BINNING_TICKETS
     std::string name;
     // scratch of a render pass: binning arrays and the set-up records of the sorted (tile, cluster) pairs.  `grown` is
     // allocated on demand; `held` is carved out of the library's static device array (rh_submit_static)
@@ -78,11 +81,12 @@ struct rh_device {
     Scratch png_slots, png_rows, png_out;          // GPU PNG encoder scratch
     void* png_host = nullptr; size_t png_host_cap = 0;   // pinned
     unsigned long long* d_total = nullptr;
-    unsigned long long* h_total = nullptr;      // pinned
+    unsigned long long* h_total = nullptr;      // pinned: [0] pair count of the last pass, [1] set by a binning kernel that gave up
     // A pass is queued whole, sized by `pair_guess`, before its pair count has come back; the count is looked at
     // before the next command runs (resolve_pending) and the pass runs again, waiting for the count, if it did not fit.
+    uint32_t compute_units = 0, resident_sort_parts = 0;   // (workgroups of a chained sorting pass the device holds at once)
     uint64_t pair_guess = 0;                    // room given to the pair arrays of a queued pass; 0: no pass seen yet
-    hipEvent_t counted = nullptr;               // recorded behind the copy of the count to h_total
+    hipEvent_t counted = nullptr;               // recorded once the count is in h_total and the pairs are sorted
     const void* pending_pass = nullptr;         // (a PassCmd of the command buffer being submitted)
     uint32_t pending_capacity = 0;
     // allocation caches (exact-size reuse; capture buffers come and go every frame)
@@ -93,7 +97,7 @@ struct rh_device {
     // optional per-pass HIP-event timing
     int timing = 0;
     std::vector<hipEvent_t> event_pool;            // unused events
-    std::vector<hipEvent_t> timing_events;         // 3 per recorded pass: start, before tile kernel, end
+    std::vector<hipEvent_t> timing_events;         // 4 per recorded pass: start, before set-up, before tile kernel, end
 };
 
 struct rh_buffer {
@@ -129,7 +133,8 @@ struct rh_module {
     rh_device* dev = nullptr;
     hipModule_t module = nullptr;
     rh_module_info_t info{};
-    hipFunction_t bin_count = nullptr;
+    hipFunction_t bin_count = nullptr, bin_pairs = nullptr;
+    uint32_t resident_pair_parts = 0;           // workgroups of rh_bin_pairs the device holds at once
     hipFunction_t setup[4] = {nullptr, nullptr, nullptr, nullptr};   // 1, 2, 4, 8 samples
     hipFunction_t tile[RH_MAX_COLOR_TARGETS] = {nullptr, nullptr, nullptr, nullptr};
     hipFunction_t tile_ms[3] = {nullptr, nullptr, nullptr};        // 2, 4, 8 samples
@@ -240,10 +245,13 @@ int rh_device_create(int hip_ordinal, uint32_t width, uint32_t height, rh_device
     dev->name = std::string(prop.name) + " (" + prop.gcnArchName + ")";
     hipError_t e = hipStreamCreateWithFlags(&dev->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete dev; return fail("hipStreamCreate failed: %s", hipGetErrorString(e)); }
-    if (hipMalloc((void**)&dev->d_total, 8) != hipSuccess || hipHostMalloc((void**)&dev->h_total, 8, hipHostMallocDefault) != hipSuccess ||
+    if (hipMalloc((void**)&dev->d_total, 8) != hipSuccess || hipHostMalloc((void**)&dev->h_total, 16, hipHostMallocDefault) != hipSuccess ||
         hipEventCreateWithFlags(&dev->counted, hipEventDisableTiming) != hipSuccess) {
         delete dev; return fail("rh_device_create: allocation failed");
     }
+    dev->h_total[0] = 0; dev->h_total[1] = 0;
+    dev->compute_units = (uint32_t)prop.multiProcessorCount;
+    dev->resident_sort_parts = rhk::sort_pass_resident_parts(dev->compute_units);
     if (rh_texture_create(dev, width, height, 1, RH_FORMAT_BGRA_U8, 1,
                           RH_TEXTURE_RENDER_ATTACHMENT | RH_TEXTURE_COPY_SRC | RH_TEXTURE_BINDING, &dev->screen)) { delete dev; return 1; }
     // rh_submit_static's scratch: this device's copy of the library's static device array, cut into the areas of a pass
@@ -259,7 +267,7 @@ int rh_device_create(int hip_ordinal, uint32_t width, uint32_t height, rh_device
         carve(h.keys_a, (size_t)RH_STATIC_MAX_PAIRS * 4); carve(h.vals_a, (size_t)RH_STATIC_MAX_PAIRS * 4);
         carve(h.keys_b, (size_t)RH_STATIC_MAX_PAIRS * 4); carve(h.vals_b, (size_t)RH_STATIC_MAX_PAIRS * 4);
         carve(h.hist, (size_t)(RH_STATIC_MAX_PAIRS / 4096 + 1) * 256 * 4);
-        carve(h.tile_start, (size_t)RH_STATIC_MAX_TILES * 8);
+        carve(h.tile_start, STATE_HEADER_BYTES + (size_t)RH_STATIC_MAX_TILES * 8);
         carve(h.rec, (size_t)RH_STATIC_RECORD_BYTES); carve(h.ext, (size_t)RH_STATIC_RECORD_BYTES);
         if ((size_t)(at - (uint8_t*)base) > bytes) { rh_device_destroy(dev); return fail("rh_device_create: the static scratch array is smaller than its areas"); }
     }
@@ -316,6 +324,7 @@ int rh_device_set_option(rh_device* dev, int option, int value) {
     if (!dev) return fail("rh_device_set_option: null device");
     if (option == RH_OPTION_CLIP_TO_VIEWPORT) { dev->clip_to_viewport = value ? 1 : 0; return 0; }
     if (option == RH_OPTION_GENERAL_KERNELS) { dev->general_kernels = value ? 1 : 0; return 0; }
+    if (option == RH_OPTION_BINNING_TICKETS) { dev->binning_tickets = value ? 1 : 0; return 0; }
     if (option == RH_OPTION_TIMING) { dev->timing = value ? 1 : 0; return 0; }
     if (option == RH_OPTION_STRIP_ROW0 || option == RH_OPTION_STRIP_ROW1) {
         if (value < 0) return fail("rh_device_set_option: negative strip row");
@@ -550,7 +559,12 @@ int rh_module_load(rh_device* dev, const void* code_object, size_t size, rh_modu
         return fail("rh_module_load: code object built for device ABI %u, library expects %u; re-run the shader build", v, RH_DEVICE_ABI_VERSION);
     }
     if (m->info.stage == RH_MODULE_STAGE_VERTEX) {
-        if (hipModuleGetFunction(&m->bin_count, m->module, "rh_bin_count") != hipSuccess) { (void)hipModuleUnload(m->module); delete m; return fail("rh_module_load: vertex code object lacks rh_bin_count"); }
+        if (hipModuleGetFunction(&m->bin_count, m->module, "rh_bin_count") != hipSuccess || hipModuleGetFunction(&m->bin_pairs, m->module, "rh_bin_pairs") != hipSuccess) {
+            (void)hipModuleUnload(m->module); delete m; return fail("rh_module_load: vertex code object lacks rh_bin_count / rh_bin_pairs");
+        }
+        int per_cu = 0;
+        if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, m->bin_pairs, RH_PAIR_THREADS, 0) == hipSuccess && per_cu > 0)
+            m->resident_pair_parts = (uint32_t)per_cu * dev->compute_units;
     } else if (m->info.stage == RH_MODULE_STAGE_FRAGMENT) {
         const char* names[RH_MAX_COLOR_TARGETS] = { "rh_tile_1", "rh_tile_2", "rh_tile_3", "rh_tile_4" };
         for (int i = 0; i < RH_MAX_COLOR_TARGETS; i++)
@@ -811,65 +825,88 @@ int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer, rh_device::Pa
     const uint32_t n_clusters = empty_scissor ? 0u : p.n_clusters;
 
     hipStream_t s = dev->stream;
-    if (ss.tile_start.ensure((size_t)n_tiles * 8)) return 1;                    // [start of every tile | end of every tile]
-    uint32_t* const tile_start = ss.tile_start.as<uint32_t>(); uint32_t* const tile_end = tile_start + n_tiles;
     uint64_t total = 0;                          // pairs, or the room for them when the count has not come back yet
-    bool deferred = false;
     const unsigned long long* pair_total = nullptr;
     const int ms_index = pl->samples == 1 ? 0 : (pl->samples == 2 ? 1 : (pl->samples == 4 ? 2 : 3));
     const uint32_t rec_bytes = pl->fs->info.rec_bytes;
     const uint32_t ext_bytes = pl->fs->info.ext_bytes + (pl->samples > 1 ? 4u * RH_MS_EXTRA_WORDS(pl->samples) : 0u);
+    // Once a pass has been seen the next ones are queued whole, without waiting for the pair count, with room for
+    // `pair_guess` pairs: the kernels read the count on the device.  (The option that forces the general kernels also
+    // forces the waiting form, so that tests cover both.)
+    const uint32_t key_bits = bits_for(n_tiles), sort_passes = (key_bits + 7) / 8;
+    const bool deferred = may_defer && n_clusters > 0 && dev->pair_guess > 0 && dev->pair_guess < (1ull << 30) && !dev->general_kernels &&
+                          sort_passes <= RH_SORT_MAX_PASSES;
+    const uint32_t n_parts = (n_clusters + 255) / 256, n_pair_parts = (n_clusters + RH_PAIR_PART - 1) / RH_PAIR_PART;
+    // one area, cleared by one fill: [binning state | start of every tile | end of every tile | look-back status words]
+    const size_t cluster_status_at = STATE_HEADER_BYTES + (size_t)n_tiles * 8;
+    const size_t sort_status_at = cluster_status_at + (deferred ? (size_t)n_pair_parts * 8 : 0);
+    const size_t state_bytes = sort_status_at + (deferred ? (size_t)sort_passes * rhk::sort_status_words((uint32_t)dev->pair_guess) * 4 : 0);
+    if (ss.tile_start.ensure(state_bytes)) return 1;
+    uint8_t* const state_base = ss.tile_start.as<uint8_t>();
+    rh_bin_state* const state = reinterpret_cast<rh_bin_state*>(state_base);
+    uint32_t* const tile_start = reinterpret_cast<uint32_t*>(state_base + STATE_HEADER_BYTES); uint32_t* const tile_end = tile_start + n_tiles;
     if (!no_alloc && timing_mark(dev)) return 1;
-    if (n_clusters > 0) {
-        const uint32_t n_blocks = (n_clusters + 255) / 256;
-        if (ss.ranges.ensure((size_t)n_clusters * sizeof(rh_tile_range)) || ss.block_sums.ensure((size_t)n_blocks * 4) ||
-            ss.chunk_tmp.ensure((size_t)rhk::scan_chunks_for(n_blocks) * 4)) return 1;
+    RH_HIP(hipMemsetAsync(state_base, 0, state_bytes, s));
+    uint32_t* sorted_keys = nullptr; uint32_t* sorted_vals = nullptr;
+    if (deferred) {
+        const uint32_t n = (uint32_t)dev->pair_guess;
+        if (ss.keys_a.ensure((size_t)n * 4) || ss.vals_a.ensure((size_t)n * 4) || ss.keys_b.ensure((size_t)n * 4) || ss.vals_b.ensure((size_t)n * 4)) return 1;
+        rh_bin_pairs_args ba;
+        memset(&ba, 0, sizeof ba);
+        ba.p = p; ba.p.n_clusters = n_clusters;
+        ba.state = state; ba.cluster_status = reinterpret_cast<unsigned long long*>(state_base + cluster_status_at);
+        ba.keys = ss.keys_a.as<uint32_t>(); ba.vals = ss.vals_a.as<uint32_t>();
+        ba.capacity = n; ba.sort_passes = sort_passes; ba.host_total = dev->h_total;
+        ba.ticketed = (dev->binning_tickets || n_pair_parts > pl->vs->resident_pair_parts) ? 1u : 0u;
+        if (launch_module_kernel(pl->vs->bin_pairs, n_pair_parts, RH_PAIR_THREADS, &ba, sizeof ba, s)) return 1;
+        const int where = rhk::sort_passes_chained(ss.keys_a.as<uint32_t>(), ss.vals_a.as<uint32_t>(), ss.keys_b.as<uint32_t>(), ss.vals_b.as<uint32_t>(),
+                                                   n, key_bits, state, reinterpret_cast<uint32_t*>(state_base + sort_status_at), dev->h_total, dev->binning_tickets ? 0u : dev->resident_sort_parts, s);
+        RH_HIP(hipGetLastError());
+        RH_HIP(hipEventRecord(dev->counted, s));
+        sorted_keys = where ? ss.keys_b.as<uint32_t>() : ss.keys_a.as<uint32_t>();
+        sorted_vals = where ? ss.vals_b.as<uint32_t>() : ss.vals_a.as<uint32_t>();
+        total = n;
+        pair_total = &state->total;
+    } else if (n_clusters > 0) {
+        if (ss.ranges.ensure((size_t)n_clusters * sizeof(rh_tile_range)) || ss.block_sums.ensure((size_t)n_parts * 4) ||
+            ss.chunk_tmp.ensure((size_t)rhk::scan_chunks_for(n_parts) * 4)) return 1;
         rh_bin_count_args ba;
         ba.p = p; ba.p.n_clusters = n_clusters;
         ba.ranges = ss.ranges.as<rh_tile_range>(); ba.block_sums = ss.block_sums.as<uint32_t>();
-        if (launch_module_kernel(pl->vs->bin_count, n_blocks, 256, &ba, sizeof ba, s)) return 1;
-        rhk::exclusive_scan(ss.block_sums.as<uint32_t>(), n_blocks, ss.chunk_tmp.as<uint32_t>(), dev->d_total, s, dev->general_kernels != 0);
+        if (launch_module_kernel(pl->vs->bin_count, n_parts, 256, &ba, sizeof ba, s)) return 1;
+        rhk::exclusive_scan(ss.block_sums.as<uint32_t>(), n_parts, ss.chunk_tmp.as<uint32_t>(), dev->d_total, s, dev->general_kernels != 0);
         RH_HIP(hipMemcpyAsync(dev->h_total, dev->d_total, 8, hipMemcpyDeviceToHost, s));
-        // Once a pass has been seen the rest is queued without waiting for the count, with room for `pair_guess`
-        // pairs; the kernels read the count on the device.  (The option that forces the general kernels also forces
-        // the waiting form, so that tests cover both.)
-        deferred = may_defer && dev->pair_guess > 0 && !dev->general_kernels;
-        if (deferred) {
-            RH_HIP(hipEventRecord(dev->counted, s));
-            total = dev->pair_guess;
-            pair_total = dev->d_total;
-        } else {
-            RH_HIP(hipStreamSynchronize(s));
-            total = *dev->h_total;
-            if (total >= 0x7fffffffull) return fail("render pass: %llu (tile, cluster) pairs exceed the 31-bit pair index", (unsigned long long)total);
-            dev->pair_guess = std::max<uint64_t>(dev->pair_guess, std::min<uint64_t>(total + total / 4 + 4096, 0x7ffffffeull));
-        }
+        RH_HIP(hipStreamSynchronize(s));
+        total = dev->h_total[0];
+        if (total >= 0x7fffffffull) return fail("render pass: %llu (tile, cluster) pairs exceed the 31-bit pair index", (unsigned long long)total);
+        dev->pair_guess = std::max<uint64_t>(dev->pair_guess, std::min<uint64_t>(total + total / 4 + 4096, 0x7ffffffeull));
         if (total > 0) {
             const uint32_t n = (uint32_t)total;
             const uint32_t sort_blocks = rhk::sort_blocks_for(n);
             if (ss.keys_a.ensure((size_t)n * 4) || ss.vals_a.ensure((size_t)n * 4) || ss.keys_b.ensure((size_t)n * 4) || ss.vals_b.ensure((size_t)n * 4) ||
                 ss.hist.ensure((size_t)sort_blocks * 256 * 4) || ss.chunk_tmp.ensure((size_t)rhk::scan_chunks_for(sort_blocks * 256) * 4)) return 1;
             rhk::bin_emit(ss.ranges.as<rh_tile_range>(), n_clusters, p.tiles_x, ss.block_sums.as<uint32_t>(),
-                          ss.keys_a.as<uint32_t>(), ss.vals_a.as<uint32_t>(), s, pair_total, n);
-            int where = rhk::radix_sort_pairs(ss.keys_a.as<uint32_t>(), ss.vals_a.as<uint32_t>(), ss.keys_b.as<uint32_t>(), ss.vals_b.as<uint32_t>(),
-                                              n, bits_for(n_tiles), ss.hist.as<uint32_t>(), ss.chunk_tmp.as<uint32_t>(), s, dev->general_kernels != 0, pair_total);
-            uint32_t* sorted_keys = where ? ss.keys_b.as<uint32_t>() : ss.keys_a.as<uint32_t>();
-            uint32_t* sorted_vals = where ? ss.vals_b.as<uint32_t>() : ss.vals_a.as<uint32_t>();
-            rhk::tile_ranges(sorted_keys, n, tile_start, tile_end, n_tiles, s, pair_total);
-            // triangle set-up: one record per pair, in list order
-            if (ss.rec.ensure((size_t)n * rec_bytes) || ss.ext.ensure((size_t)n * ext_bytes)) return 1;
-            rh_setup_args sa;
-            memset(&sa, 0, sizeof sa);
-            sa.p = p; sa.p.n_clusters = n_clusters;
-            sa.clusters = sorted_vals; sa.tiles = sorted_keys;
-            sa.rec = ss.rec.as<uint8_t>(); sa.ext = ss.ext.as<uint8_t>(); sa.ext_bytes = ext_bytes;
-            sa.n_pairs = n; sa.pair_total = pair_total;
-            if (launch_module_kernel(pl->fs->setup[ms_index], (n + 255) / 256, 256, &sa, sizeof sa, s)) return 1;
+                          ss.keys_a.as<uint32_t>(), ss.vals_a.as<uint32_t>(), s);
+            const int where = rhk::radix_sort_pairs(ss.keys_a.as<uint32_t>(), ss.vals_a.as<uint32_t>(), ss.keys_b.as<uint32_t>(), ss.vals_b.as<uint32_t>(),
+                                                    n, key_bits, ss.hist.as<uint32_t>(), ss.chunk_tmp.as<uint32_t>(), s, dev->general_kernels != 0);
+            sorted_keys = where ? ss.keys_b.as<uint32_t>() : ss.keys_a.as<uint32_t>();
+            sorted_vals = where ? ss.vals_b.as<uint32_t>() : ss.vals_a.as<uint32_t>();
         }
     }
-    if (total == 0) {
-        RH_HIP(hipMemsetAsync(tile_start, 0, (size_t)n_tiles * 8, s));
-    }
+    if (total > 0) {
+        // triangle set-up: one record per pair, in list order; also finds where the list of every tile starts and ends
+        const uint32_t n = (uint32_t)total;
+        if (ss.rec.ensure((size_t)n * rec_bytes) || ss.ext.ensure((size_t)n * ext_bytes)) return 1;
+        rh_setup_args sa;
+        memset(&sa, 0, sizeof sa);
+        sa.p = p; sa.p.n_clusters = n_clusters;
+        sa.clusters = sorted_vals; sa.tiles = sorted_keys;
+        sa.rec = ss.rec.as<uint8_t>(); sa.ext = ss.ext.as<uint8_t>(); sa.ext_bytes = ext_bytes;
+        sa.n_pairs = n; sa.pair_total = pair_total;
+        sa.tile_start = tile_start; sa.tile_end = tile_end;
+        if (!no_alloc && timing_mark(dev)) return 1;
+        if (launch_module_kernel(pl->fs->setup[ms_index], (n + 255) / 256, 256, &sa, sizeof sa, s)) return 1;
+    } else if (!no_alloc && timing_mark(dev)) return 1;
 
     rh_tile_args ta;
     memset(&ta, 0, sizeof ta);
@@ -951,7 +988,8 @@ int resolve_pending(rh_device* dev) {
     const uint64_t capacity = dev->pending_capacity;
     dev->pending_pass = nullptr;
     RH_HIP(hipEventSynchronize(dev->counted));
-    const uint64_t total = *dev->h_total;
+    const uint64_t total = dev->h_total[0];
+    if (dev->h_total[1]) { dev->h_total[1] = 0; return fail("render pass: a binning workgroup gave up waiting for its predecessors; the results of the pass are undefined"); }
     if (total >= 0x7fffffffull) return fail("render pass: %llu (tile, cluster) pairs exceed the 31-bit pair index", (unsigned long long)total);
     dev->stats.bin_entries = total;
     if (total <= capacity) {
@@ -959,7 +997,7 @@ int resolve_pending(rh_device* dev) {
         return 0;
     }
     // the attempt that wrote nothing is not a pass of its own: its timing marks go back to the pool
-    for (int k = 0; k < 3 && dev->timing && !dev->timing_events.empty(); k++) { dev->event_pool.push_back(dev->timing_events.back()); dev->timing_events.pop_back(); }
+    for (int k = 0; k < 4 && dev->timing && !dev->timing_events.empty(); k++) { dev->event_pool.push_back(dev->timing_events.back()); dev->timing_events.pop_back(); }
     dev->stats.reruns++;
     return execute_pass(dev, c, false, dev->grown, false);
 }
@@ -1015,15 +1053,16 @@ int rh_submit_static(rh_device* dev, rh_cmdbuf* const* list, size_t n) {
 int rh_device_drain_timings(rh_device* dev, rh_timings* out) {
     if (!dev || !out) return fail("rh_device_drain_timings: bad argument");
     if (set_device(dev)) return 1;
-    out->passes = 0; out->bin_ms = 0.0; out->tile_ms = 0.0;
-    const size_t n = dev->timing_events.size() / 3;
+    out->passes = 0; out->bin_ms = 0.0; out->setup_ms = 0.0; out->tile_ms = 0.0;
+    const size_t n = dev->timing_events.size() / 4;
     for (size_t i = 0; i < n; i++) {
-        hipEvent_t e0 = dev->timing_events[3 * i], e1 = dev->timing_events[3 * i + 1], e2 = dev->timing_events[3 * i + 2];
-        RH_HIP(hipEventSynchronize(e2));
-        float a = 0.0f, b = 0.0f;
+        hipEvent_t e0 = dev->timing_events[4 * i], e1 = dev->timing_events[4 * i + 1], e2 = dev->timing_events[4 * i + 2], e3 = dev->timing_events[4 * i + 3];
+        RH_HIP(hipEventSynchronize(e3));
+        float a = 0.0f, b = 0.0f, c = 0.0f;
         RH_HIP(hipEventElapsedTime(&a, e0, e1));
         RH_HIP(hipEventElapsedTime(&b, e1, e2));
-        out->passes++; out->bin_ms += a; out->tile_ms += b;
+        RH_HIP(hipEventElapsedTime(&c, e2, e3));
+        out->passes++; out->bin_ms += a; out->setup_ms += b; out->tile_ms += c;
     }
     for (hipEvent_t e : dev->timing_events) dev->event_pool.push_back(e);
     dev->timing_events.clear();

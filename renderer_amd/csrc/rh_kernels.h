@@ -24,14 +24,20 @@ uint32_t sort_blocks_for(uint32_t n);
 void exclusive_scan(uint32_t* data, uint32_t n, uint32_t* chunk_tmp, unsigned long long* total_out, hipStream_t s, bool general = false);
 
 void bin_emit(const rh_tile_range* ranges, uint32_t n_clusters, uint32_t tiles_x, const uint32_t* block_bases,
-              uint32_t* keys, uint32_t* vals, hipStream_t s, const unsigned long long* pair_total = nullptr, uint32_t capacity = 0);
+              uint32_t* keys, uint32_t* vals, hipStream_t s);
 
 int radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, uint32_t n, uint32_t key_bits,
-                     uint32_t* hist, uint32_t* chunk_tmp, hipStream_t s, bool general = false, const unsigned long long* pair_total = nullptr);
+                     uint32_t* hist, uint32_t* chunk_tmp, hipStream_t s, bool general = false);
 
-// tile_end must be tile_start + n_tiles (one allocation, cleared by one fill).
-void tile_ranges(const uint32_t* keys, uint32_t n, uint32_t* tile_start, uint32_t* tile_end, uint32_t n_tiles, hipStream_t s,
-                 const unsigned long long* pair_total = nullptr);
+// The same sort queued as one launch per pass, for pair arrays built by rh_bin_pairs (the digit counts are in `state`):
+// status needs passes * sort_status_words(capacity) cleared words; capacity below 2^30.
+uint32_t sort_parts_for(uint32_t n);
+size_t sort_status_words(uint32_t capacity);
+int sort_passes_chained(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, uint32_t capacity, uint32_t key_bits,
+                        rh_bin_state* state, uint32_t* status, unsigned long long* host_total, uint32_t resident_parts, hipStream_t s);
+// How many workgroups of a sorting pass the device holds at once (launches of no more than that need no tickets: see
+// rh_sort_pass); 0 when unknown.
+uint32_t sort_pass_resident_parts(uint32_t compute_units);
 
 // Fills the RH_POLY_COPIES footprint copies of an RGBA8 texture (dst: RH_POLY_COPIES * width * height * layers items of 16 bytes).
 void polyphase_build(const void* src, void* dst, uint32_t width, uint32_t height, uint32_t layers, hipStream_t s);

@@ -108,13 +108,9 @@ extern "C" __global__ __launch_bounds__(256) void rh_scan_apply(uint32_t* data, 
 // One thread per cluster (same 256-cluster partition as rh_bin_count).  Cluster c writes its (tile, c) pairs at
 // block_base + exclusive prefix within the block, tiles in row-major order, so the pair array is ordered by cluster.
 // Clusters that touch more than 32 tiles are written cooperatively by the whole workgroup.
-// `pair_total` / `capacity` (here and in the kernels below): the number of pairs is read on the device, and a pass whose
-// pairs do not fit the arrays writes nothing (see rh_tile_args::pair_total); a null pointer means "n is exact".
 extern "C" __global__ __launch_bounds__(256) void rh_bin_emit(const rh_tile_range* ranges, uint32_t n_clusters, uint32_t tiles_x,
-                                                             const uint32_t* block_bases, uint32_t* keys, uint32_t* vals,
-                                                             const unsigned long long* pair_total, uint32_t capacity) {
+                                                             const uint32_t* block_bases, uint32_t* keys, uint32_t* vals) {
     __shared__ uint32_t lds4[4];
-    if (pair_total && *pair_total > capacity) return;
     __shared__ uint32_t big_n;
     __shared__ uint32_t big_cluster[WG], big_off[WG];
     if (threadIdx.x == 0) big_n = 0;
@@ -149,10 +145,8 @@ extern "C" __global__ __launch_bounds__(256) void rh_bin_emit(const rh_tile_rang
 
 // ---- stable LSD radix sort, 8 bits per pass ------------------------------------------------------------------------------
 // histogram: hist[digit * n_blocks + block]
-extern "C" __global__ __launch_bounds__(256) void rh_sort_hist(const uint32_t* keys, uint32_t n, uint32_t shift, uint32_t* hist, uint32_t n_blocks,
-                                                              const unsigned long long* pair_total) {
+extern "C" __global__ __launch_bounds__(256) void rh_sort_hist(const uint32_t* keys, uint32_t n, uint32_t shift, uint32_t* hist, uint32_t n_blocks) {
     __shared__ uint32_t h[256];
-    if (pair_total) { if (*pair_total > n) return; n = (uint32_t)*pair_total; }          // (n arrives as the capacity)
     h[threadIdx.x] = 0;
     __syncthreads();
     const size_t base = (size_t)blockIdx.x * SORT_CHUNK;
@@ -171,10 +165,7 @@ extern "C" __global__ __launch_bounds__(256) void rh_sort_hist(const uint32_t* k
 // digit inside LDS and then writes them out in that order: the pairs of one digit leave as one contiguous run instead
 // of 4-byte writes all over the output.
 extern "C" __global__ __launch_bounds__(256) void rh_sort_scatter(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
-                                                                 uint32_t n, uint32_t shift, const uint32_t* offsets, uint32_t n_blocks,
-                                                                 const unsigned long long* pair_total) {
-    if (pair_total) { if (*pair_total > n) return; n = (uint32_t)*pair_total; }
-    if ((size_t)blockIdx.x * SORT_CHUNK >= n) return;
+                                                                 uint32_t n, uint32_t shift, const uint32_t* offsets, uint32_t n_blocks) {
     __shared__ uint32_t cnt[4][256];            // per wave and digit: count, then the next free local slot
     __shared__ uint32_t digit_start[256];       // first local slot of each digit
     __shared__ uint32_t global_base[256];       // where this workgroup's run of each digit starts in the output
@@ -232,15 +223,196 @@ extern "C" __global__ __launch_bounds__(256) void rh_sort_scatter(const uint32_t
     }
 }
 
-// ---- tile ranges from the sorted key array --------------------------------------------------------------------------------
-extern "C" __global__ __launch_bounds__(256) void rh_tile_ranges(const uint32_t* keys, uint32_t n, uint32_t* tile_start, uint32_t* tile_end,
-                                                                const unsigned long long* pair_total) {
-    if (pair_total) { if (*pair_total > n) return; n = (uint32_t)*pair_total; }
-    const size_t i = (size_t)blockIdx.x * WG + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t k = keys[i];
-    if (i == 0 || keys[i - 1] != k) tile_start[k] = (uint32_t)i;
-    if (i == n - 1 || keys[i + 1] != k) tile_end[k] = (uint32_t)i + 1;
+// One sorting pass in one launch: the digit counts of the whole array are already known (rh_bin_pairs counted them), so
+// a workgroup only needs, per digit value, how many pairs with that value the workgroups before it hold -- a chained
+// look-back per digit value, thread d of every workgroup following digit value d (see rh_bin_state).  Workgroup `part`
+// (its ticket) sorts pairs [PASS_CHUNK * part, PASS_CHUNK * (part + 1)) the way rh_sort_scatter does: every wave walks
+// its 1024 consecutive pairs in order.
+// status: [parts + ceil(parts / PASS_GROUP)][256] words per pass (rhk::sort_status_words), cleared; counts must stay below 2^30.
+#ifndef RH_PASS_SORT_WAVES
+#define RH_PASS_SORT_WAVES 4
+#endif
+constexpr int PASS_SORT_WAVES = RH_PASS_SORT_WAVES;                      // waves that hold and sort the pairs, 1024 each
+constexpr int PASS_WG = PASS_SORT_WAVES * 64 + 256;                      // plus the four waves that follow the digit values
+constexpr int PASS_STEPS = 16, PASS_CHUNK = PASS_SORT_WAVES * 64 * PASS_STEPS;
+constexpr uint32_t PASS_GROUP = 32;                                      // parts per group of the two-level look-back
+
+// Exclusive scan of v[0..256) by one wave (four consecutive values per lane).
+__device__ __forceinline__ void wave_scan_256(const uint32_t* v, uint32_t* out, int lane) {
+    const uint32_t a = v[4 * lane], b = v[4 * lane + 1], c = v[4 * lane + 2], d = v[4 * lane + 3];
+    const uint32_t ex = wave_inclusive_scan(a + b + c + d, lane) - (a + b + c + d);
+    out[4 * lane] = ex; out[4 * lane + 1] = ex + a; out[4 * lane + 2] = ex + a + b; out[4 * lane + 3] = ex + a + b + c;
+}
+
+#ifdef RH_SORT_STAMPS      // diagnostic build (tools/probe_sort.hip): wall-clock stamps of the phases of the last pass, per part
+__device__ unsigned long long rh_sort_stamps[4096 * 8];
+#define RH_STAMP(k, who) do { if (threadIdx.x == (who) && part < 4096u) rh_sort_stamps[part * 8u + (k)] = wall_clock64(); } while (0)
+#else
+#define RH_STAMP(k, who) do {} while (0)
+#endif
+
+// `ticketed` = 0: the host knows that all the workgroups of the launch fit the device at once, and a workgroup takes its
+// index as its place in the chain (nobody can wait for a workgroup that never starts); otherwise places come from the
+// ticket counter.
+extern "C" __global__ __launch_bounds__(PASS_WG) void rh_sort_pass(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
+                                                                  uint32_t capacity, uint32_t shift, uint32_t pass, rh_bin_state* state, uint32_t* status,
+                                                                  unsigned long long* host_total, uint32_t ticketed) {
+    const unsigned long long total = state->total;
+    if (total > capacity) return;
+    const uint32_t n = (uint32_t)total;
+    __shared__ uint32_t s_part;
+    __shared__ uint32_t cnt[PASS_SORT_WAVES][256];   // per sorting wave and digit value: pairs
+    __shared__ uint32_t slot[PASS_SORT_WAVES][256];  // per sorting wave and digit value: the next free local slot
+    __shared__ uint32_t digit_start[256];            // first local slot of each digit value
+    __shared__ uint32_t all_count[256];              // the whole array's pairs per digit value
+    __shared__ uint32_t digit_base[256];             // their exclusive scan: pairs with a smaller digit value
+    __shared__ uint32_t before_mine[256];            // pairs with the same digit value in earlier parts
+    __shared__ uint32_t skey[PASS_CHUNK], sval[PASS_CHUNK];
+    if (ticketed && threadIdx.x == 0) s_part = atomicAdd(&state->ticket[1 + pass], 1u);
+    for (int i = threadIdx.x; i < PASS_SORT_WAVES * 256; i += PASS_WG) (&cnt[0][0])[i] = 0;
+    __syncthreads();
+    const uint32_t part = ticketed ? s_part : blockIdx.x, n_parts = gridDim.x;
+    if ((size_t)part * PASS_CHUNK >= n) return;
+    RH_STAMP(0, 0);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool sorts = wave < PASS_SORT_WAVES;       // else: thread d of the last four waves follows digit value d
+    const uint32_t d = (uint32_t)(threadIdx.x - PASS_SORT_WAVES * 64) & 255u;
+    const size_t block_base = (size_t)part * PASS_CHUNK;
+    const size_t wave_base = block_base + (size_t)wave * (PASS_STEPS * 64);
+    uint32_t key[PASS_STEPS], val[PASS_STEPS];
+    if (sorts) {
+        // (all the loads first, from addresses inside the array also for the lanes past its end: one round trip)
+#pragma unroll
+        for (int step = 0; step < PASS_STEPS; step++) {
+            const size_t idx = wave_base + (size_t)step * 64 + lane;
+            key[step] = keys_in[idx < n ? idx : 0];
+        }
+#pragma unroll
+        for (int step = 0; step < PASS_STEPS; step++)
+            if (wave_base + (size_t)step * 64 + lane < n) atomicAdd(&cnt[wave][(key[step] >> shift) & 0xffu], 1u);
+    } else {
+        uint32_t all = 0u;
+#pragma unroll
+        for (int k = 0; k < RH_DIGIT_COPIES; k++) all += state->digit_count[pass][k][d];
+        all_count[d] = all;
+    }
+    __syncthreads();
+    RH_STAMP(1, 0);
+    if (sorts) {
+        // The sorting waves order the part by digit value inside LDS (values ascending, inside a value the waves in order
+        // = input order) while the other waves find the part's place in the output.
+#pragma unroll
+        for (int step = 0; step < PASS_STEPS; step++) {
+            const size_t idx = wave_base + (size_t)step * 64 + lane;
+            val[step] = vals_in[idx < n ? idx : 0];
+        }
+        {   // this wave's first slot of every digit value (every wave works the layout out for itself: no barrier)
+            uint32_t tot[4], mine4[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                tot[i] = 0u; mine4[i] = 0u;
+#pragma unroll
+                for (int w = 0; w < PASS_SORT_WAVES; w++) { const uint32_t c = cnt[w][4 * lane + i]; tot[i] += c; if (w < wave) mine4[i] += c; }
+            }
+            const uint32_t sum = tot[0] + tot[1] + tot[2] + tot[3];
+            uint32_t at = wave_inclusive_scan(sum, lane) - sum;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                if (wave == 0) digit_start[4 * lane + i] = at;
+                slot[wave][4 * lane + i] = at + mine4[i];
+                at += tot[i];
+            }
+        }
+        const unsigned long long lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+        for (int step = 0; step < PASS_STEPS; step++) {
+            const size_t idx = wave_base + (size_t)step * 64 + lane;
+            const bool valid = idx < n;
+            const uint32_t dv = (key[step] >> shift) & 0xffu;
+            unsigned long long peers = __ballot(valid);
+#pragma unroll
+            for (int b = 0; b < 8; b++) {
+                unsigned long long bal = __ballot((dv >> b) & 1u);
+                peers &= ((dv >> b) & 1u) ? bal : ~bal;
+            }
+            if (valid) {
+                const uint32_t at = slot[wave][dv] + (uint32_t)__popcll(peers & lt_mask);
+                skey[at] = key[step]; sval[at] = val[step];
+            }
+            // the highest lane of every group advances the slot (the reads above finish first: same wave, program order)
+            if (valid && (peers >> lane) == 1ull) slot[wave][dv] += (uint32_t)__popcll(peers);
+        }
+        RH_STAMP(2, 0);
+    } else {
+        uint32_t c = 0u;
+#pragma unroll
+        for (int w = 0; w < PASS_SORT_WAVES; w++) c += cnt[w][d];
+        uint32_t* const mine = status + (size_t)part * 256u + d;
+        __hip_atomic_store(mine, (RH_STATUS_PARTIAL << 30) | c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (wave == PASS_SORT_WAVES) wave_scan_256(all_count, digit_base, lane);
+        // The look-back, in two levels: the parts before this one in its group of PASS_GROUP (all polled at once: counts
+        // only), and the groups before that, whose last parts keep a chain of their own (group count, then group prefix).
+        const uint32_t group = part / PASS_GROUP, member = part % PASS_GROUP;
+        uint32_t* const group_status = status + (size_t)n_parts * 256u;
+        bool gave_up = false;
+        auto poll = [&](const uint32_t* word, uint32_t need_prefix) -> uint32_t {
+            uint32_t st = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), spins = 0;
+            while ((st >> 30) == 0u || (need_prefix && (st >> 30) != RH_STATUS_PREFIX)) {
+                if (++spins > RH_LOOKBACK_SPINS) { gave_up = true; return RH_STATUS_PREFIX << 30; }
+                __builtin_amdgcn_s_sleep(1);
+                st = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return st;
+        };
+        uint32_t before = 0u;                                // pairs with this digit value in earlier parts
+        for (uint32_t j0 = 0; j0 < member; j0 += 8u) {
+            uint32_t st[8];
+#pragma unroll
+            for (uint32_t j = 0; j < 8u; j++)
+                st[j] = j0 + j < member ? __hip_atomic_load(status + (size_t)(part - member + j0 + j) * 256u + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (RH_STATUS_PARTIAL << 30);
+#pragma unroll
+            for (uint32_t j = 0; j < 8u; j++) {
+                if ((st[j] >> 30) == 0u) st[j] = poll(status + (size_t)(part - member + j0 + j) * 256u + d, 0u);
+                before += st[j] & 0x3fffffffu;
+            }
+        }
+        if (member == PASS_GROUP - 1u) {
+            // last part of a group: publishes the group's count, finds the prefix of the groups before, publishes the group's prefix
+            uint32_t* const ours = group_status + (size_t)group * 256u + d;
+            const uint32_t group_count = before + c;
+            __hip_atomic_store(ours, ((group == 0u ? RH_STATUS_PREFIX : RH_STATUS_PARTIAL) << 30) | group_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            uint32_t groups_before = 0u;
+            bool done = group == 0u;
+            for (int64_t b = (int64_t)group - 1; !done && b >= 0; b -= 4) {
+                uint32_t st[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) st[j] = b - j >= 0 ? __hip_atomic_load(group_status + (size_t)(b - j) * 256u + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (RH_STATUS_PREFIX << 30);
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (done) break;
+                    if ((st[j] >> 30) == 0u) st[j] = poll(group_status + (size_t)(b - j) * 256u + d, 0u);
+                    groups_before += st[j] & 0x3fffffffu;
+                    done = (st[j] >> 30) == RH_STATUS_PREFIX;
+                }
+            }
+            if (group != 0u) __hip_atomic_store(ours, (RH_STATUS_PREFIX << 30) | (groups_before + group_count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            before += groups_before;
+        } else if (group != 0u) {
+            before += poll(group_status + (size_t)(group - 1u) * 256u + d, 1u) & 0x3fffffffu;
+        }
+        if (gave_up) { state->fault = 1u; host_total[1] = 1ull; }
+        before_mine[d] = before;
+        RH_STAMP(3, PASS_SORT_WAVES * 64);
+    }
+    __syncthreads();
+    RH_STAMP(4, 0);
+    const uint32_t chunk_n = (uint32_t)(n - block_base < (size_t)PASS_CHUNK ? n - block_base : (size_t)PASS_CHUNK);
+    for (uint32_t i = threadIdx.x; i < chunk_n; i += PASS_WG) {
+        const uint32_t k = skey[i], dv = (k >> shift) & 0xffu;
+        const uint32_t dst = digit_base[dv] + before_mine[dv] + (i - digit_start[dv]);
+        keys_out[dst] = k; vals_out[dst] = sval[i];
+    }
+    RH_STAMP(5, 0);
 }
 
 // ---- capture: texture region -> buffer with a 256-byte-aligned row pitch --------------------------------------------------
@@ -297,6 +469,8 @@ hipError_t static_scratch(void** ptr, size_t* bytes) {
 
 uint32_t scan_chunks_for(uint32_t n) { return div_up(n, SCAN_CHUNK); }
 uint32_t sort_blocks_for(uint32_t n) { return div_up(n, SORT_CHUNK); }
+uint32_t sort_parts_for(uint32_t n) { return div_up(n, PASS_CHUNK); }
+size_t sort_status_words(uint32_t capacity) { const uint32_t parts = sort_parts_for(capacity); return (size_t)(parts + div_up(parts, PASS_GROUP)) * 256u; }
 
 // In-place exclusive scan of data[0..n); chunk_tmp needs scan_chunks_for(n) words.
 void exclusive_scan(uint32_t* data, uint32_t n, uint32_t* chunk_tmp, unsigned long long* total_out, hipStream_t s, bool general) {
@@ -313,36 +487,52 @@ void exclusive_scan(uint32_t* data, uint32_t n, uint32_t* chunk_tmp, unsigned lo
 }
 
 void bin_emit(const rh_tile_range* ranges, uint32_t n_clusters, uint32_t tiles_x, const uint32_t* block_bases,
-              uint32_t* keys, uint32_t* vals, hipStream_t s, const unsigned long long* pair_total, uint32_t capacity) {
+              uint32_t* keys, uint32_t* vals, hipStream_t s) {
     if (n_clusters == 0) return;
-    hipLaunchKernelGGL(rh_bin_emit, dim3(div_up(n_clusters, WG)), dim3(WG), 0, s, ranges, n_clusters, tiles_x, block_bases, keys, vals, pair_total, capacity);
+    hipLaunchKernelGGL(rh_bin_emit, dim3(div_up(n_clusters, WG)), dim3(WG), 0, s, ranges, n_clusters, tiles_x, block_bases, keys, vals);
 }
 
 // Sorts n pairs by the low `key_bits` bits of the key.  Buffers ping-pong; returns 0 when the result is in
 // (keys_a, vals_a) and 1 when it is in (keys_b, vals_b).  hist needs 256 * sort_blocks_for(n) words, chunk_tmp
 // scan_chunks_for(256 * sort_blocks_for(n)) words.
 int radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, uint32_t n, uint32_t key_bits,
-                     uint32_t* hist, uint32_t* chunk_tmp, hipStream_t s, bool general, const unsigned long long* pair_total) {
+                     uint32_t* hist, uint32_t* chunk_tmp, hipStream_t s, bool general) {
     if (n == 0) return 0;
     const uint32_t blocks = sort_blocks_for(n);
     int cur = 0;
     for (uint32_t shift = 0; shift < key_bits; shift += 8) {
         uint32_t* ki = cur ? keys_b : keys_a; uint32_t* vi = cur ? vals_b : vals_a;
         uint32_t* ko = cur ? keys_a : keys_b; uint32_t* vo = cur ? vals_a : vals_b;
-        hipLaunchKernelGGL(rh_sort_hist, dim3(blocks), dim3(WG), 0, s, ki, n, shift, hist, blocks, pair_total);
+        hipLaunchKernelGGL(rh_sort_hist, dim3(blocks), dim3(WG), 0, s, ki, n, shift, hist, blocks);
         exclusive_scan(hist, 256u * blocks, chunk_tmp, nullptr, s, general);
-        hipLaunchKernelGGL(rh_sort_scatter, dim3(blocks), dim3(WG), 0, s, ki, vi, ko, vo, n, shift, hist, blocks, pair_total);
+        hipLaunchKernelGGL(rh_sort_scatter, dim3(blocks), dim3(WG), 0, s, ki, vi, ko, vo, n, shift, hist, blocks);
         cur ^= 1;
     }
     return cur;
 }
 
-// tile_end must be tile_start + n_tiles (one allocation, cleared by one fill).
-void tile_ranges(const uint32_t* keys, uint32_t n, uint32_t* tile_start, uint32_t* tile_end, uint32_t n_tiles, hipStream_t s,
-                 const unsigned long long* pair_total) {
-    (void)hipMemsetAsync(tile_start, 0, (size_t)n_tiles * 8, s);
-    if (n == 0) return;
-    hipLaunchKernelGGL(rh_tile_ranges, dim3(div_up(n, WG)), dim3(WG), 0, s, keys, n, tile_start, tile_end, pair_total);
+// The sorting passes of the chain that is queued without scans (see rh_bin_state); same result and return value as
+// radix_sort_pairs.  status: RH sort passes x sort_blocks_for(capacity) x 256 words, cleared.
+uint32_t sort_pass_resident_parts(uint32_t compute_units) {
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rh_sort_pass, PASS_WG, 0) != hipSuccess || per_cu < 1) return 0;
+    return (uint32_t)per_cu * compute_units;
+}
+
+int sort_passes_chained(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, uint32_t capacity, uint32_t key_bits,
+                        rh_bin_state* state, uint32_t* status, unsigned long long* host_total, uint32_t resident_parts, hipStream_t s) {
+    const uint32_t blocks = sort_parts_for(capacity);
+    const uint32_t ticketed = blocks > resident_parts ? 1u : 0u;
+    int cur = 0;
+    uint32_t pass = 0;
+    for (uint32_t shift = 0; shift < key_bits; shift += 8, pass++) {
+        uint32_t* ki = cur ? keys_b : keys_a; uint32_t* vi = cur ? vals_b : vals_a;
+        uint32_t* ko = cur ? keys_a : keys_b; uint32_t* vo = cur ? vals_a : vals_b;
+        hipLaunchKernelGGL(rh_sort_pass, dim3(blocks), dim3(PASS_WG), 0, s, ki, vi, ko, vo, capacity, shift, pass, state,
+                           status + (size_t)pass * sort_status_words(capacity), host_total, ticketed);
+        cur ^= 1;
+    }
+    return cur;
 }
 
 void polyphase_build(const void* src, void* dst, uint32_t width, uint32_t height, uint32_t layers, hipStream_t s) {

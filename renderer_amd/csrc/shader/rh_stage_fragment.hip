@@ -330,6 +330,9 @@ RH_DEVICE void setup_kernel(const rh_setup_args& a) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     const uint32_t tile = a.tiles[i];
+    // the ends of a tile's run of pairs
+    if (i == 0u || a.tiles[i - 1u] != tile) a.tile_start[tile] = i;
+    if (i == n - 1u || a.tiles[i + 1u] != tile) a.tile_end[tile] = i + 1u;
     const int ox = (int)(tile % a.p.tiles_x) * TILE, oy = (int)(tile / a.p.tiles_x) * TILE;
     setup_pair<S>(a.p, a.clusters[i], ox, oy, reinterpret_cast<uint32_t*>(a.rec + (size_t)i * (REC_WORDS * 4)),
                   reinterpret_cast<uint32_t*>(a.ext + (size_t)i * a.ext_bytes));

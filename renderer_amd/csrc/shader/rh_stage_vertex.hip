@@ -1,7 +1,8 @@
 // Vertex-stage code object: compiled once per vertex source with
 //     hipcc --genco --offload-arch=gfx950 -ffp-contract=off -DRH_VERTEX_SOURCE='"<file>.vert.hip"' rh_stage_vertex.hip
-// Exports rh_bin_count: runs the vertex function for every cluster (pair of consecutive triangles of one
-// instance), and records which screen tiles the cluster's bounding box touches.
+// Exports rh_bin_count and rh_bin_pairs: both run the vertex function for every cluster (pair of consecutive triangles
+// of one instance) and find the screen tiles the cluster's bounding box touches; the first only records and counts them
+// (the form that waits for the count), the second writes the (tile, cluster) pair array in the same launch.
 #include "rh_shader.h"
 #include RH_VERTEX_SOURCE
 #include "rh_geometry.h"
@@ -11,6 +12,50 @@ extern "C" __device__ const rh_module_info_t rh_module_info = {
     rh::fnv1a(RH_VERTEX_TAG), 0u, 0u
 };
 
+namespace {
+
+// The inclusive rectangle of tiles the bounding box of `cluster` touches; returns the number of tiles (0: none).
+__device__ __forceinline__ uint32_t cluster_tiles(const rh_draw_params& p, uint32_t cluster, uint32_t& tx0, uint32_t& ty0, uint32_t& tx1, uint32_t& ty1) {
+    const uint32_t instance = cluster / p.cpi, local = cluster - instance * p.cpi;
+    int bx0 = 0x7fffffff, by0 = 0x7fffffff, bx1 = -1, by1 = -1;
+    int x0, y0, x1, y1;
+    const uint32_t tri0 = local * 2u;
+    const bool second = tri0 + 1u < p.tpi;
+    if (p.topology == 1u) {
+        // strip: the two triangles share two of their four vertices (the order of a triangle's vertices does not matter here)
+        const rh::SnappedVertex v0 = rh::run_vertex(p, tri0, instance), v1 = rh::run_vertex(p, tri0 + 1u, instance), v2 = rh::run_vertex(p, tri0 + 2u, instance);
+        if (rh::tri_pixel_bbox(p, v0, v1, v2, x0, y0, x1, y1)) { bx0 = x0; by0 = y0; bx1 = x1; by1 = y1; }
+        if (second) {
+            const rh::SnappedVertex v3 = rh::run_vertex(p, tri0 + 3u, instance);
+            if (rh::tri_pixel_bbox(p, v1, v2, v3, x0, y0, x1, y1)) { bx0 = min(bx0, x0); by0 = min(by0, y0); bx1 = max(bx1, x1); by1 = max(by1, y1); }
+        }
+    } else {
+        for (uint32_t k = 0; k < (second ? 2u : 1u); k++) {
+            const uint32_t first = 3u * (tri0 + k);
+            const rh::SnappedVertex v0 = rh::run_vertex(p, first, instance), v1 = rh::run_vertex(p, first + 1u, instance), v2 = rh::run_vertex(p, first + 2u, instance);
+            if (rh::tri_pixel_bbox(p, v0, v1, v2, x0, y0, x1, y1)) { bx0 = min(bx0, x0); by0 = min(by0, y0); bx1 = max(bx1, x1); by1 = max(by1, y1); }
+        }
+    }
+    tx0 = 1u; ty0 = 0u; tx1 = 0u; ty1 = 0u;             // x0 = 1 > x1 = 0: empty
+    if (bx1 < bx0 || by1 < by0) return 0u;
+    tx0 = (uint32_t)bx0 / RH_TILE_W; ty0 = (uint32_t)by0 / RH_TILE_H;
+    tx1 = (uint32_t)bx1 / RH_TILE_W; ty1 = (uint32_t)by1 / RH_TILE_H;
+    return (tx1 - tx0 + 1) * (ty1 - ty0 + 1);
+}
+
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t n = __shfl_up(v, off);
+        if (lane >= off) v += n;
+    }
+    return v;
+}
+
+constexpr unsigned long long STATUS_VALUE = (1ull << 62) - 1ull;
+
+} // namespace
+
 // One thread per cluster.  Writes the cluster's inclusive tile rectangle and the per-workgroup sum of tile counts
 // (the scan of those sums gives every workgroup its base offset in the (tile, cluster) pair array).
 extern "C" __global__ __launch_bounds__(256) void rh_bin_count(rh_bin_count_args a) {
@@ -18,27 +63,9 @@ extern "C" __global__ __launch_bounds__(256) void rh_bin_count(rh_bin_count_args
     const uint32_t cluster = blockIdx.x * 256u + threadIdx.x;
     uint32_t count = 0;
     if (cluster < p.n_clusters) {
-        const uint32_t instance = cluster / p.cpi, local = cluster - instance * p.cpi;
-        int bx0 = 0x7fffffff, by0 = 0x7fffffff, bx1 = -1, by1 = -1;
-        for (uint32_t k = 0; k < 2; k++) {
-            const uint32_t tri = local * 2 + k;
-            if (tri >= p.tpi) break;
-            uint32_t idx[3]; rh::tri_vertices(p.topology, tri, idx);
-            rh::SnappedVertex v0 = rh::run_vertex(p, idx[0], instance);
-            rh::SnappedVertex v1 = rh::run_vertex(p, idx[1], instance);
-            rh::SnappedVertex v2 = rh::run_vertex(p, idx[2], instance);
-            int x0, y0, x1, y1;
-            if (rh::tri_pixel_bbox(p, v0, v1, v2, x0, y0, x1, y1)) {
-                bx0 = min(bx0, x0); by0 = min(by0, y0); bx1 = max(bx1, x1); by1 = max(by1, y1);
-            }
-        }
-        rh_tile_range r; r.lo = 1u; r.hi = 0u;          // x0 = 1 > x1 = 0: empty
-        if (bx1 >= bx0 && by1 >= by0) {
-            uint32_t tx0 = (uint32_t)bx0 / RH_TILE_W, ty0 = (uint32_t)by0 / RH_TILE_H;
-            uint32_t tx1 = (uint32_t)bx1 / RH_TILE_W, ty1 = (uint32_t)by1 / RH_TILE_H;
-            r.lo = tx0 | (ty0 << 16); r.hi = tx1 | (ty1 << 16);
-            count = (tx1 - tx0 + 1) * (ty1 - ty0 + 1);
-        }
+        rh_tile_range r; uint32_t tx0, ty0, tx1, ty1;
+        count = cluster_tiles(p, cluster, tx0, ty0, tx1, ty1);
+        r.lo = tx0 | (ty0 << 16); r.hi = tx1 | (ty1 << 16);
         a.ranges[cluster] = r;
     }
     // workgroup sum: wave reduce, then 4 partials through LDS
@@ -48,4 +75,111 @@ extern "C" __global__ __launch_bounds__(256) void rh_bin_count(rh_bin_count_args
     if ((threadIdx.x & 63u) == 0) partial[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) a.block_sums[blockIdx.x] = partial[0] + partial[1] + partial[2] + partial[3];
+}
+
+// The pair array in one launch (see rh_bin_pairs_args).  Workgroup `part` (its ticket) owns clusters
+// [RH_PAIR_PART * part, RH_PAIR_PART * (part + 1)), every thread RH_PAIR_PER_THREAD consecutive ones; the pairs of a
+// cluster are its tiles in row-major order, clusters in order.  (Large parts: every workgroup costs a ticket, a slot in
+// the look-back chain and an add per digit value, and adds to one word go one at a time.)
+extern "C" __global__ __launch_bounds__(RH_PAIR_THREADS) void rh_bin_pairs(rh_bin_pairs_args a) {
+    const rh_draw_params& p = a.p;
+    constexpr uint32_t PART = RH_PAIR_PART, THREADS = RH_PAIR_THREADS, PER = RH_PAIR_PER_THREAD, WAVES = THREADS / 64u;
+    static_assert(PART == THREADS * PER, "part size");
+    __shared__ uint32_t s_part;
+    __shared__ uint32_t wave_sum[WAVES];
+    __shared__ unsigned long long s_base;
+    __shared__ uint32_t digits[RH_SORT_MAX_PASSES][256];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (a.ticketed && threadIdx.x == 0) s_part = atomicAdd(&a.state->ticket[0], 1u);
+    if (threadIdx.x < 256u) for (uint32_t k = 0; k < a.sort_passes; k++) digits[k][threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t part = a.ticketed ? s_part : blockIdx.x, n_parts = (p.n_clusters + PART - 1u) / PART;
+    if (part >= n_parts) return;
+    const uint32_t cluster0 = part * PART + threadIdx.x * PER;
+    uint32_t tx0[PER], ty0[PER], tx1[PER], ty1[PER], cnt[PER], count = 0u;
+#pragma unroll
+    for (uint32_t j = 0; j < PER; j++) {
+        tx0[j] = 1u; ty0[j] = 0u; tx1[j] = 0u; ty1[j] = 0u; cnt[j] = 0u;
+        if (cluster0 + j < p.n_clusters) cnt[j] = cluster_tiles(p, cluster0 + j, tx0[j], ty0[j], tx1[j], ty1[j]);
+        count += cnt[j];
+    }
+    const uint32_t inc = wave_inclusive_scan(count, (int)lane);
+    if (lane == 63u) wave_sum[wave] = inc;
+    __syncthreads();
+    uint32_t before = inc - count;
+    unsigned long long part_total = 0ull;
+#pragma unroll
+    for (uint32_t w = 0; w < WAVES; w++) { const uint32_t ws = wave_sum[w]; part_total += ws; if (w < wave) before += ws; }
+    if (wave == 0u) {
+        // the look-back: lane i polls the i-th predecessor of the current window of 64
+        unsigned long long* const status = a.cluster_status;
+        if (lane == 0u) __hip_atomic_store(&status[part], ((unsigned long long)(part == 0u ? RH_STATUS_PREFIX : RH_STATUS_PARTIAL) << 62) | part_total,
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long base = 0ull;
+        bool gave_up = false;
+        for (int64_t window = (int64_t)part - 1; window >= 0; window -= 64) {
+            const int64_t idx = window - (int64_t)lane;
+            unsigned long long st = (unsigned long long)RH_STATUS_PREFIX << 62;             // before the first workgroup: nothing
+            if (idx >= 0) {
+                uint32_t spins = 0;
+                while (true) {
+                    st = __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((st >> 62) != 0ull) break;
+                    if (++spins > RH_LOOKBACK_SPINS) { gave_up = true; st = (unsigned long long)RH_STATUS_PREFIX << 62; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            const unsigned long long known = __ballot((st >> 62) == (unsigned long long)RH_STATUS_PREFIX);
+            // add up the lanes up to and including the first that knows its prefix
+            const uint32_t last = known ? (uint32_t)__builtin_ctzll(known) : 63u;
+            unsigned long long v = lane <= last ? (st & STATUS_VALUE) : 0ull;
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+            base += __shfl(v, 0);
+            if (known) break;
+        }
+        if (__ballot(gave_up) && lane == 0u) { a.state->fault = 1u; a.host_total[1] = 1ull; }
+        if (lane == 0u) {
+            s_base = base;
+            if (part != 0u) __hip_atomic_store(&status[part], ((unsigned long long)RH_STATUS_PREFIX << 62) | (base + part_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (part == n_parts - 1u) { a.state->total = base + part_total; a.host_total[0] = base + part_total; }
+        }
+    }
+    __syncthreads();
+    unsigned long long off = s_base + before;
+    const uint32_t passes = a.sort_passes;
+#pragma unroll
+    for (uint32_t j = 0; j < PER; j++) {
+        const bool big = cnt[j] > 32u;
+        const unsigned long long first = off;
+        if (!big)
+            for (uint32_t ty = ty0[j]; ty <= ty1[j]; ty++)
+                for (uint32_t tx = tx0[j]; tx <= tx1[j]; tx++, off++) {
+                    if (off >= a.capacity) continue;
+                    const uint32_t tile = ty * p.tiles_x + tx;
+                    a.keys[off] = tile; a.vals[off] = cluster0 + j;
+                    for (uint32_t k = 0; k < passes; k++) atomicAdd(&digits[k][(tile >> (8u * k)) & 0xffu], 1u);
+                }
+        else off += cnt[j];
+        // clusters that touch more than 32 tiles are written by the whole wave, one after the other
+        for (unsigned long long todo = __ballot(big); todo; todo &= todo - 1ull) {
+            const int src = __builtin_ctzll(todo);
+            const uint32_t lo = __shfl(tx0[j] | (ty0[j] << 16), src), hi = __shfl(tx1[j] | (ty1[j] << 16), src), cc = __shfl(cluster0 + j, src);
+            const unsigned long long o = __shfl(first, src);
+            const uint32_t x0 = lo & 0xffffu, y0 = lo >> 16, x1 = hi & 0xffffu, y1 = hi >> 16;
+            const uint32_t w = x1 - x0 + 1u, n = w * (y1 - y0 + 1u);
+            for (uint32_t i = lane; i < n; i += 64u) {
+                if (o + i >= a.capacity) break;
+                const uint32_t tile = (y0 + i / w) * p.tiles_x + (x0 + i % w);
+                a.keys[o + i] = tile; a.vals[o + i] = cc;
+                for (uint32_t k = 0; k < passes; k++) atomicAdd(&digits[k][(tile >> (8u * k)) & 0xffu], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    // the workgroups spread their adds over RH_DIGIT_COPIES copies of the counts
+    if (threadIdx.x < 256u)
+        for (uint32_t k = 0; k < passes; k++) {
+            const uint32_t c = digits[k][threadIdx.x];
+            if (c) atomicAdd(&a.state->digit_count[k][part % RH_DIGIT_COPIES][threadIdx.x], c);
+        }
 }

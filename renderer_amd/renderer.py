@@ -178,13 +178,17 @@ class Renderer:
         """Forces the kernel body that reads all pipeline state at run time (identical results; for testing)."""
         _ffi.check(_ffi.lib().rh_device_set_option(self.device, _ffi.OPTION_GENERAL_KERNELS, 1 if enabled else 0))
 
+    def set_binning_tickets(self, enabled):
+        """Forces the form of the binning chain that launches too large for the device use (identical results; for testing)."""
+        _ffi.check(_ffi.lib().rh_device_set_option(self.device, _ffi.OPTION_BINNING_TICKETS, 1 if enabled else 0))
+
     def set_timing(self, enabled):
         _ffi.check(_ffi.lib().rh_device_set_option(self.device, _ffi.OPTION_TIMING, 1 if enabled else 0))
 
     def drain_timings(self):
         t = _ffi.Timings()
         _ffi.check(_ffi.lib().rh_device_drain_timings(self.device, C.byref(t)))
-        return {"passes": t.passes, "bin_ms": t.bin_ms, "tile_ms": t.tile_ms}
+        return {"passes": t.passes, "bin_ms": t.bin_ms, "setup_ms": t.setup_ms, "tile_ms": t.tile_ms}
 
     def stream(self):
         return _ffi.lib().rh_device_stream(self.device)

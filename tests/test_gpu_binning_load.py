@@ -13,10 +13,11 @@ from test_gpu_parity import assert_same
 pytestmark = pytest.mark.gpu
 
 
-def draw_both_forms(scene, what):
+def draw_both_forms(scene, what, tickets=False):
     want = scenes.draw_oracle(scene)["color"]
     hs = scenes.HipScene(scene)
     try:
+        hs.renderer.set_binning_tickets(tickets)
         hs.draw()                                   # first pass of the device: waits for its pair count
         assert_same(hs.read_color(), want, what + " (waiting form)")
         hs.draw()                                   # queued whole before the count is known
@@ -62,6 +63,27 @@ def test_more_than_65536_tiles(oracle):
     stack[:, 0] = (rng.integers(0, 4, 1500) * 0.5 - 0.75 + rng.uniform(-0.004, 0.004, 1500)).astype(np.float32)
     stats = draw_both_forms(scene, "65792 tiles")
     assert stats["tiles_x"] * stats["tiles_y"] > 65536
+
+
+def test_quads_over_many_tiles_in_the_queued_form(oracle):
+    """Quads of 300 px touch about a hundred tiles each: their pairs are written by a whole wave, not by the thread that
+    owns the quad; small quads in between keep the two ways of writing side by side."""
+    scene = scenes.random_quads_scene(1500, 300, 2048, 1024, seed=105)
+    small = scenes.random_quads_scene(1500, 10, 2048, 1024, seed=106)
+    scene["instances"][::2] = small["instances"][::2]
+    stats = draw_both_forms(scene, "quads over ~100 tiles")
+    assert stats["bin_entries"] > 50_000
+
+
+@pytest.mark.parametrize("shape", ["1024 tiles", "65792 tiles"])
+def test_chain_places_from_tickets(oracle, shape):
+    """The queued form with places in the look-back chains taken from ticket counters (what launches too large to fit the
+    device at once do), at two and three sorting passes."""
+    if shape == "1024 tiles":
+        scene = scenes.random_quads_scene(100_000, 16, 2048, 1024, seed=107)
+    else:
+        scene = scenes.random_quads_scene(20_000, 48, 8192, 8224, seed=108)
+    draw_both_forms(scene, "tickets / " + shape, tickets=True)
 
 
 def tiny_then(r, W, H):

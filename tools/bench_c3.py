@@ -63,7 +63,7 @@ def main():
     t = r.drain_timings()
     n_frag1 = args.quads * args.side * args.side
     out = {"workload": f"two-pass {S}x{S}: {args.quads} quads {args.side}x{args.side} px into A, then one quad sampling A into B",
-           "ms_per_frame": wall * 1e3, "tile_ms_both_passes": t["tile_ms"] / args.steps, "binning_ms_both_passes": t["bin_ms"] / args.steps,
+           "ms_per_frame": wall * 1e3, "tile_ms_both_passes": t["tile_ms"] / args.steps, "binning_ms_both_passes": t["bin_ms"] / args.steps, "setup_ms_both_passes": t["setup_ms"] / args.steps,
            "fragments": n_frag1 + S * S, "fragments_per_s": (n_frag1 + S * S) / wall}
     print(json.dumps(out), flush=True)
     h1.close(); r.close()

@@ -87,7 +87,8 @@ struct rh_device {
     uint32_t compute_units = 0, resident_sort_parts = 0;   // (workgroups of a chained sorting pass the device holds at once)
     uint64_t pair_guess = 0;                    // room given to the pair arrays of a queued pass; 0: no pass seen yet
     hipEvent_t counted = nullptr;               // recorded once the count is in h_total and the pairs are sorted
-    const void* pending_pass = nullptr;         // (a PassCmd of the command buffer being submitted)
+    const void* pending_pass = nullptr;         // (a PassCmd of the command buffer being submitted, or of `pending_cb`)
+    rh_cmdbuf* pending_cb = nullptr;            // the last command buffer of a submit, kept while its last pass awaits its count
     uint32_t pending_capacity = 0;
     // allocation caches (exact-size reuse; capture buffers come and go every frame)
     std::multimap<size_t, void*> free_device, free_pinned;
@@ -214,6 +215,9 @@ void pinned_free(rh_device* dev, size_t size, void* p) {
 }
 
 int set_device(rh_device* dev) { RH_HIP(hipSetDevice(dev->ordinal)); return 0; }
+int resolve_pending(rh_device* dev, bool blocking = true);
+// What every entry point that queues work on the device's stream, reads results or hands out device memory starts with.
+int enter(rh_device* dev) { return set_device(dev) || resolve_pending(dev); }
 
 uint32_t unorm8(double c) {
     float o = (float)c;
@@ -281,6 +285,8 @@ void rh_device_destroy(rh_device* dev) {
     if (!dev) return;
     (void)hipSetDevice(dev->ordinal);
     (void)hipStreamSynchronize(dev->stream);
+    dev->pending_pass = nullptr;                // (nobody will look at the results of a pass still awaiting its count)
+    if (dev->pending_cb) { rh_cmdbuf* cb = dev->pending_cb; dev->pending_cb = nullptr; rh_cmdbuf_release(cb); }
     std::vector<rh_buffer*> pending; pending.swap(dev->pending_maps);
     for (rh_buffer* b : pending) rh_buffer_release(b);
     rh_texture* screen = dev->screen; dev->screen = nullptr;
@@ -322,6 +328,7 @@ int rh_device_info(rh_device* dev, char* name, size_t cap) {
 
 int rh_device_set_option(rh_device* dev, int option, int value) {
     if (!dev) return fail("rh_device_set_option: null device");
+    if (enter(dev)) return 1;                   // (a pass that has to run again runs under the options it was submitted under)
     if (option == RH_OPTION_CLIP_TO_VIEWPORT) { dev->clip_to_viewport = value ? 1 : 0; return 0; }
     if (option == RH_OPTION_GENERAL_KERNELS) { dev->general_kernels = value ? 1 : 0; return 0; }
     if (option == RH_OPTION_BINNING_TICKETS) { dev->binning_tickets = value ? 1 : 0; return 0; }
@@ -336,12 +343,12 @@ int rh_device_set_option(rh_device* dev, int option, int value) {
 
 int rh_device_synchronize(rh_device* dev) {
     if (!dev) return fail("rh_device_synchronize: null device");
-    if (set_device(dev)) return 1;
+    if (enter(dev)) return 1;
     RH_HIP(hipStreamSynchronize(dev->stream));
     return 0;
 }
 
-void* rh_device_stream(rh_device* dev) { return dev ? (void*)dev->stream : nullptr; }
+void* rh_device_stream(rh_device* dev) { return dev && !enter(dev) ? (void*)dev->stream : nullptr; }
 
 int rh_screen_texture(rh_device* dev, rh_texture** out) {
     if (!dev || !out) return fail("rh_screen_texture: bad argument");
@@ -353,6 +360,7 @@ int rh_screen_resize(rh_device* dev, uint32_t width, uint32_t height) {
     if (!dev) return fail("rh_screen_resize: null device");
     if (width == 0 || height == 0) return 0;           // reference src/renderer.rs:57 ignores zero sizes
     if (width == dev->width && height == dev->height) return 0;
+    if (enter(dev)) return 1;
     rh_texture* t = nullptr;
     if (rh_texture_create(dev, width, height, 1, RH_FORMAT_BGRA_U8, 1,
                           RH_TEXTURE_RENDER_ATTACHMENT | RH_TEXTURE_COPY_SRC | RH_TEXTURE_BINDING, &t)) return 1;
@@ -385,13 +393,13 @@ int rh_buffer_write(rh_buffer* buf, size_t offset, const void* data, size_t len)
     if (!buf || (!data && len)) return fail("rh_buffer_write: bad argument");
     if (offset > buf->size || len > buf->size - offset) return fail("rh_buffer_write: range %zu+%zu exceeds buffer size %zu", offset, len, buf->size);
     if (len == 0) return 0;
-    if (set_device(buf->dev)) return 1;
+    if (enter(buf->dev)) return 1;
     RH_HIP(hipMemcpyAsync((uint8_t*)buf->dptr + offset, data, len, hipMemcpyHostToDevice, buf->dev->stream));
     return 0;
 }
 
 size_t rh_buffer_size(rh_buffer* buf) { return buf ? buf->size : 0; }
-void* rh_buffer_device_ptr(rh_buffer* buf) { return buf ? buf->dptr : nullptr; }
+void* rh_buffer_device_ptr(rh_buffer* buf) { return buf && !enter(buf->dev) ? buf->dptr : nullptr; }
 void rh_buffer_retain(rh_buffer* buf) { if (buf) buf->refs.fetch_add(1); }
 
 void rh_buffer_release(rh_buffer* buf) {
@@ -412,7 +420,7 @@ int rh_buffer_map_async(rh_buffer* buf, rh_map_callback cb, void* user) {
     if (!(buf->usage & RH_BUFFER_MAP_READ)) return fail("rh_buffer_map_async: buffer was not created with MAP_READ");
     if (buf->map_state != 0) return fail("rh_buffer_map_async: buffer is already mapped or mapping");
     rh_device* dev = buf->dev;
-    if (set_device(dev)) return 1;
+    if (enter(dev)) return 1;
     if (!buf->hptr && pinned_alloc(dev, buf->size, &buf->hptr)) return 1;
     if (!buf->map_event) RH_HIP(hipEventCreateWithFlags(&buf->map_event, hipEventDisableTiming));
     RH_HIP(hipMemcpyAsync(buf->hptr, buf->dptr, buf->size, hipMemcpyDeviceToHost, dev->stream));
@@ -439,7 +447,7 @@ int rh_buffer_unmap(rh_buffer* buf) {
 
 int rh_poll(rh_device* dev, int wait) {
     if (!dev) return fail("rh_poll: null device");
-    if (set_device(dev)) return 1;
+    if (set_device(dev) || resolve_pending(dev, wait != 0)) return 1;
     size_t done = 0;
     for (; done < dev->pending_maps.size(); done++) {
         rh_buffer* b = dev->pending_maps[done];
@@ -490,7 +498,7 @@ int rh_texture_write(rh_texture* tex, uint32_t x, uint32_t y, uint32_t layer, ui
     const size_t row_bytes = (size_t)width * tex->bpt;
     if (bytes_per_row < row_bytes) return fail("rh_texture_write: bytes_per_row %u smaller than a row (%zu bytes)", bytes_per_row, row_bytes);
     if (data_len < (size_t)bytes_per_row * (height - 1) + row_bytes) return fail("rh_texture_write: %zu bytes of data are too few for %u rows", data_len, height);
-    if (set_device(tex->dev)) return 1;
+    if (enter(tex->dev)) return 1;
     uint8_t* dst = (uint8_t*)tex->dptr + (((size_t)layer * tex->height + y) * tex->width + x) * tex->bpt;
     tex->poly_valid = false;
     RH_HIP(hipMemcpy2DAsync(dst, (size_t)tex->width * tex->bpt, data, bytes_per_row, row_bytes, height, hipMemcpyHostToDevice, tex->dev->stream));
@@ -503,7 +511,7 @@ int rh_texture_read(rh_texture* tex, uint32_t layer, void* out, size_t out_len) 
     // a multisampled texture reads back as width*height*samples texels, the samples of a pixel adjacent (for tests)
     const size_t layer_bytes = (size_t)tex->width * tex->height * tex->bpt * tex->samples;
     if (out_len < layer_bytes) return fail("rh_texture_read: output too small (%zu < %zu)", out_len, layer_bytes);
-    if (set_device(tex->dev)) return 1;
+    if (enter(tex->dev)) return 1;
     RH_HIP(hipMemcpyAsync(out, (uint8_t*)tex->dptr + layer * layer_bytes, layer_bytes, hipMemcpyDeviceToHost, tex->dev->stream));
     RH_HIP(hipStreamSynchronize(tex->dev->stream));
     return 0;
@@ -518,7 +526,7 @@ int rh_texture_size(rh_texture* tex, uint32_t* width, uint32_t* height, uint32_t
     return 0;
 }
 
-void* rh_texture_device_ptr(rh_texture* tex) { if (tex) tex->poly_always = true; return tex ? tex->dptr : nullptr; }
+void* rh_texture_device_ptr(rh_texture* tex) { if (tex) tex->poly_always = true; return tex && !enter(tex->dev) ? tex->dptr : nullptr; }
 void rh_texture_retain(rh_texture* tex) { if (tex) tex->refs.fetch_add(1); }
 void rh_texture_release(rh_texture* tex) {
     if (!tex) return;
@@ -982,24 +990,31 @@ int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer, rh_device::Pa
 // Looks at the pair count of the pass that was queued without waiting for it (before anything else is queued behind
 // it): normally it fitted and there is nothing to do; otherwise its kernels have written nothing, and the pass runs
 // again in the waiting form.
-int resolve_pending(rh_device* dev) {
+int resolve_pending(rh_device* dev, bool blocking) {
     if (!dev->pending_pass) return 0;
+    if (!blocking && hipEventQuery(dev->counted) == hipErrorNotReady) return 0;
     const PassCmd& c = *static_cast<const PassCmd*>(dev->pending_pass);
     const uint64_t capacity = dev->pending_capacity;
-    dev->pending_pass = nullptr;
-    RH_HIP(hipEventSynchronize(dev->counted));
+    rh_cmdbuf* const kept = dev->pending_cb;
+    dev->pending_pass = nullptr; dev->pending_cb = nullptr;
+    int rc = 0;
+    hipError_t e = hipEventSynchronize(dev->counted);
     const uint64_t total = dev->h_total[0];
-    if (dev->h_total[1]) { dev->h_total[1] = 0; return fail("render pass: a binning workgroup gave up waiting for its predecessors; the results of the pass are undefined"); }
-    if (total >= 0x7fffffffull) return fail("render pass: %llu (tile, cluster) pairs exceed the 31-bit pair index", (unsigned long long)total);
-    dev->stats.bin_entries = total;
-    if (total <= capacity) {
-        dev->pair_guess = std::max<uint64_t>(dev->pair_guess, std::min<uint64_t>(total + total / 4 + 4096, 0x7ffffffeull));
-        return 0;
+    if (e != hipSuccess) rc = fail("render pass: waiting for the pair count failed: %s", hipGetErrorString(e));
+    else if (dev->h_total[1]) { dev->h_total[1] = 0; rc = fail("render pass: a binning workgroup gave up waiting for its predecessors; the results of the pass are undefined"); }
+    else if (total >= 0x7fffffffull) rc = fail("render pass: %llu (tile, cluster) pairs exceed the 31-bit pair index", (unsigned long long)total);
+    else {
+        dev->stats.bin_entries = total;
+        if (total <= capacity) dev->pair_guess = std::max<uint64_t>(dev->pair_guess, std::min<uint64_t>(total + total / 4 + 4096, 0x7ffffffeull));
+        else {
+            // the attempt that wrote nothing is not a pass of its own: its timing marks go back to the pool
+            for (int k = 0; k < 4 && dev->timing && !dev->timing_events.empty(); k++) { dev->event_pool.push_back(dev->timing_events.back()); dev->timing_events.pop_back(); }
+            dev->stats.reruns++;
+            rc = execute_pass(dev, c, false, dev->grown, false);
+        }
     }
-    // the attempt that wrote nothing is not a pass of its own: its timing marks go back to the pool
-    for (int k = 0; k < 4 && dev->timing && !dev->timing_events.empty(); k++) { dev->event_pool.push_back(dev->timing_events.back()); dev->timing_events.pop_back(); }
-    dev->stats.reruns++;
-    return execute_pass(dev, c, false, dev->grown, false);
+    if (kept) rh_cmdbuf_release(kept);
+    return rc;
 }
 
 int execute_copy(rh_device* dev, const CopyCmd& c) {
@@ -1015,8 +1030,9 @@ extern "C" {
 
 int rh_submit(rh_device* dev, rh_cmdbuf* const* list, size_t n) {
     if (!dev || (!list && n)) return fail("rh_submit: bad argument");
-    if (set_device(dev)) return 1;
-    int rc = 0;
+    int rc = enter(dev);
+    size_t last = n;                            // the last command buffer of the list
+    for (size_t i = 0; i < n; i++) if (list[i]) last = i;
     for (size_t i = 0; i < n; i++) {
         rh_cmdbuf* cb = list[i];
         if (!cb) continue;
@@ -1026,7 +1042,10 @@ int rh_submit(rh_device* dev, rh_cmdbuf* const* list, size_t n) {
                 if (!rc) rc = c.kind == 0 ? execute_pass(dev, c.pass, true, dev->grown, false) : execute_copy(dev, c.copy);
                 if (rc) break;
             }
-            if (!rc) rc = resolve_pending(dev);       // (the commands go away with the buffer)
+            // A pass still awaiting its count at the end of the submit stays that way: the host does not wait here.  Its
+            // command buffer is kept until the count has been looked at, by the next call that queues work or reads results.
+            if (!rc && dev->pending_pass && i == last) { dev->pending_cb = cb; continue; }
+            if (!rc) rc = resolve_pending(dev);
             dev->pending_pass = nullptr;
         }
         rh_cmdbuf_release(cb);
@@ -1038,7 +1057,7 @@ int rh_submit(rh_device* dev, rh_cmdbuf* const* list, size_t n) {
 int rh_submit_static(rh_device* dev, rh_cmdbuf* const* list, size_t n) {
     if (!dev || (!list && n)) return fail("rh_submit_static: bad argument");
     if (!dev->held.rec.ptr) return fail("rh_submit_static: the static scratch array of this device is not available");
-    if (set_device(dev)) return 1;
+    if (enter(dev)) return 1;
     for (size_t i = 0; i < n; i++) {
         const rh_cmdbuf* cb = list[i];
         if (!cb) continue;
@@ -1052,7 +1071,7 @@ int rh_submit_static(rh_device* dev, rh_cmdbuf* const* list, size_t n) {
 
 int rh_device_drain_timings(rh_device* dev, rh_timings* out) {
     if (!dev || !out) return fail("rh_device_drain_timings: bad argument");
-    if (set_device(dev)) return 1;
+    if (enter(dev)) return 1;
     out->passes = 0; out->bin_ms = 0.0; out->setup_ms = 0.0; out->tile_ms = 0.0;
     const size_t n = dev->timing_events.size() / 4;
     for (size_t i = 0; i < n; i++) {
@@ -1071,6 +1090,7 @@ int rh_device_drain_timings(rh_device* dev, rh_timings* out) {
 
 int rh_device_last_pass_stats(rh_device* dev, rh_pass_stats* out) {
     if (!dev || !out) return fail("rh_device_last_pass_stats: bad argument");
+    if (enter(dev)) return 1;                   // (the pair count of a pass still awaiting it)
     *out = dev->stats;
     return 0;
 }
@@ -1334,7 +1354,7 @@ int rh_compressor_write_packet(rh_compressor* c, uint32_t stream, const void* me
 
 int rh_compressor_submit(rh_compressor* c) {
     if (!c) return fail("rh_compressor_submit: null compressor");
-    if (set_device(c->dev)) return 1;
+    if (enter(c->dev)) return 1;
     for (;;) {
         if (compressor_wait_round(c)) return 1;
         if (compressor_queue_empty(c)) return compressor_collect_round(c, c->round);
@@ -1431,7 +1451,7 @@ int rh_png_encode(rh_device* dev, rh_buffer* image, uint32_t width, uint32_t hei
     if ((uint64_t)width * 4u > padded_bytes_per_row || (padded_bytes_per_row & 3u)) return fail("rh_png_encode: row pitch %u does not hold %u RGBA8 pixels", padded_bytes_per_row, width);
     if ((uint64_t)padded_bytes_per_row * height > image->size) return fail("rh_png_encode: the buffer holds %zu bytes, %u rows of %u are needed", image->size, height, padded_bytes_per_row);
     if (width > (1u << 24)) return fail("rh_png_encode: image too wide");
-    if (set_device(dev)) return 1;
+    if (enter(dev)) return 1;
     const uint32_t slot = png_slot_dwords(width);
     const size_t out_dev = (size_t)height * (12u + (size_t)slot * 4u) + 16u;
     const size_t rows_bytes = (size_t)height * (3 * 4 + 8) + 8;

@@ -196,7 +196,7 @@ def main():
         import bench_capture
         cap_s, cap_info, cap_error = float("inf"), None, None
         try:
-            cap_s, cap_info, _ = bench_capture.run_capture(
+            cap_s, cap_info, cap_last = bench_capture.run_capture(
                 frames=args.capture_frames, streams=args.capture_streams, out=f"/tmp/rh_bench_capture_{os.getpid()}_{rank}",
                 hip_ordinal=local_rank, seed=4 + rank,
                 # untimed rounds first: the compressor pins its host buffers in them
@@ -215,7 +215,21 @@ def main():
             capture = {"metric": "recorded frames/s", "value": args.capture_frames * n_gpus / cap_s, "unit": "frames/s",
                        "frames_per_gpu": args.capture_frames, "streams_per_gpu": args.capture_streams,
                        "ms_per_frame_per_gpu": cap_s / args.capture_frames * 1e3, "workload": cap_info["workload"],
-                       "raw_MB_per_frame": cap_info["raw_MB_per_frame"], "compressed_MB_per_frame": cap_info["compressed_MB_per_frame"]}
+                       "raw_MB_per_frame": cap_info["raw_MB_per_frame"], "compressed_MB_per_frame": cap_info["compressed_MB_per_frame"],
+                       "frames_dropped": cap_info["frames_dropped"], "budget_MB": cap_info["budget_MB"]}
+            # rh_lz4f_compress against the HBM roofline: the bytes it must read and write (raw frames in, LZ4F streams
+            # out) over the HIP-event time of its launches (this rank's)
+            k = cap_info["kernel"]
+            if k["kernel_ms"] > 0:
+                achieved = (k["bytes_in"] + k["bytes_out"]) / (k["kernel_ms"] * 1e-3) / 1e9
+                capture["roofline"] = {"bound": "hbm", "kernel": "rh_lz4f_compress", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": achieved / HBM_PEAK_GBS, "traffic": None, "launches": k["rounds"],
+                                       "algorithmic_bytes_per_launch": (k["bytes_in"] + k["bytes_out"]) / max(1, k["rounds"]),
+                                       "kernel_ms_per_launch": k["kernel_ms"] / max(1, k["rounds"]),
+                                       "note": "latency-bound: one wavefront per stream walks LZ4's sequential match search"}
+            if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
+                _, multi = bench_capture.liblz4_baseline(np.ascontiguousarray(cap_last).tobytes(), cpu_frames=4)
+                capture["cpu_baseline"] = multi
 
     parity_failed = False
     if rank == 0:

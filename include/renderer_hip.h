@@ -280,6 +280,16 @@ int rh_compressor_peek(rh_compressor* c, uint32_t stream, const uint8_t** ptr, s
 int rh_compressor_consume(rh_compressor* c, uint32_t stream, size_t n);
 /* Flushes and appends the LZ4F end mark to `stream` (LZ4F_compressEnd, when the reference drops the writer). */
 int rh_compressor_finish_stream(rh_compressor* c, uint32_t stream);
+/* What the compression kernel did since the previous call (the counters start again): for benchmarks; the reference
+ * prints comparable figures in its statistics display (src/compressor.rs:150-229). */
+typedef struct rh_compressor_stats {
+    uint64_t rounds;          /* kernel launches that have finished */
+    uint64_t jobs;            /* packets compressed (one per stream and launch) */
+    uint64_t bytes_in;        /* uncompressed bytes read */
+    uint64_t bytes_out;       /* LZ4F bytes written */
+    double kernel_ms;         /* HIP-event time of those launches on the compression stream */
+} rh_compressor_stats;
+int rh_compressor_drain_stats(rh_compressor* c, rh_compressor_stats* out);
 /* PngEncoder::encode_to_bytes (src/png_encoder.rs:6-38) on the device: encodes the captured frame held in `image`
  * (RGBA8 rows `padded_bytes_per_row` apart, `width` x `height`, as src/video_recorder.rs:66-128 lays it out) as an 8-bit
  * RGBA PNG and writes the complete file to `out` (host memory, `cap` bytes; *len = file size).  Only the finished PNG

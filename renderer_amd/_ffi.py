@@ -71,6 +71,11 @@ class Timings(C.Structure):
     _fields_ = [("passes", C.c_uint32), ("bin_ms", C.c_double), ("tile_ms", C.c_double), ("setup_ms", C.c_double)]
 
 
+class CompressorStats(C.Structure):
+    _fields_ = [("rounds", C.c_uint64), ("jobs", C.c_uint64), ("bytes_in", C.c_uint64), ("bytes_out", C.c_uint64),
+                ("kernel_ms", C.c_double)]
+
+
 MAP_CALLBACK = C.CFUNCTYPE(None, C.c_void_p, C.c_int)
 
 # name -> (restype, argtypes); every symbol declared in include/renderer_hip.h
@@ -131,6 +136,7 @@ SIGNATURES = {
     "rh_compressor_pending": (C.c_size_t, [_P, C.c_uint32]),
     "rh_compressor_read": (C.c_int, [_P, C.c_uint32, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "rh_compressor_finish_stream": (C.c_int, [_P, C.c_uint32]),
+    "rh_compressor_drain_stats": (C.c_int, [_P, _P]),
     "rh_png_bound": (C.c_size_t, [C.c_uint32, C.c_uint32]),
     "rh_png_encode": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "rh_lz4f_decompress": (C.c_int, [_P, C.c_size_t, _P, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),

@@ -23,7 +23,7 @@ def generate_timestamp(now=None):
 
 class Compressor:
     def __init__(self, renderer, directory, max_frames_queued=None, lz4_compression_level=0, print_stats=False,
-                 n_streams=64, timestamp=None):
+                 n_streams=64, timestamp=None, max_buffer_size_in_megabytes=None):
         if lz4_compression_level > CLEVEL_MAX:
             raise AssertionError(f"Please choose a compression level in the range 0..={CLEVEL_MAX}")
         os.makedirs(directory, exist_ok=True)
@@ -32,12 +32,20 @@ class Compressor:
         self.n_streams = n_streams
         # packets are compressed when every stream has one queued, or when this many frames wait
         self.max_frames_queued = max_frames_queued if max_frames_queued else n_streams
+        # The capture budget the recorder was started with (Renderer.start_recording), when the caller passes it on: a
+        # frame's bytes go back to the budget once its round has been compressed, so a round plus the frames captured
+        # while it is being compressed must fit; rounds are cut short accordingly (see compress_to_disk).
+        self.max_buffer_size_in_bytes = None
+        if max_buffer_size_in_megabytes is not None:
+            import numpy as np
+            self.max_buffer_size_in_bytes = int(np.float32(max_buffer_size_in_megabytes) * np.float32(1024.0) * np.float32(1024.0))
         self.print_stats = print_stats
         out = C.c_void_p()
         _ffi.check(_ffi.lib().rh_compressor_create(renderer.device, n_streams, lz4_compression_level, C.byref(out)))
         self.handle = out
         self.files = [open(os.path.join(directory, f"{self.timestamp}--{i}.sz"), "wb", buffering=0) for i in range(n_streams)]
-        self.queued = []            # frames whose packets are queued on the device (kept alive until compressed)
+        self.queued = []            # frames whose packets are queued on the device
+        self.in_flight = []         # frames of the round being compressed: they hold their share of the budget until it is done
         self.frames_captured = 0
         self.frames_dropped = 0
         self.raw_video_size = 0
@@ -58,21 +66,31 @@ class Compressor:
         else:
             self.frames_dropped += 1
         self.queued.append(video_frame)
-        if len(self.queued) >= min(self.n_streams, self.max_frames_queued):
+        if len(self.queued) >= self._round_size(video_frame):
             self.submit()
 
-    def _release_queued(self):
-        for frame in self.queued:
+    def _round_size(self, video_frame):
+        """Frames per round: one per stream, unless the capture budget holds fewer.  The recorder accepts a frame while
+        the bytes in flight do not exceed the budget (reference src/video_recorder.rs:80-82), i.e. budget // frame + 1
+        frames; half of them may wait in a round while the other half is captured."""
+        n = min(self.n_streams, self.max_frames_queued)
+        if self.max_buffer_size_in_bytes is not None and video_frame.frame_size_in_bytes > 0:
+            frames_in_budget = self.max_buffer_size_in_bytes // video_frame.frame_size_in_bytes + 1
+            n = min(n, max(1, frames_in_budget // 2))
+        return n
+
+    def _release(self, frames):
+        for frame in frames:
             frame.drop()                # returns the frame's bytes to the capture budget (reference src/video_frame.rs:70-77)
-        self.queued = []
 
     def submit(self):
         """Hands the queued packets to the GPU (streams run concurrently there) and, while they are being compressed,
         appends the bytes of the previous hand-off to the files -- the reference's worker threads do both beside the
         render thread (src/compressor.rs:100-131)."""
         self._join_drain()
-        _ffi.check(_ffi.lib().rh_compressor_submit(self.handle))
-        self._release_queued()          # the library keeps the capture buffers alive until they are compressed
+        _ffi.check(_ffi.lib().rh_compressor_submit(self.handle))    # waits for the round in flight, then starts the queued one
+        self._release(self.in_flight)   # compressed: the reference's worker drops a frame once it has written it
+        self.in_flight, self.queued = self.queued, []
         # The file writes go to a background thread: until the next hand-off this thread only queues packets
         # (rh_compressor_write_packet), which touches none of the state that peek/consume use.
         if self._background is None:
@@ -84,7 +102,8 @@ class Compressor:
         """Compresses all queued packets, waits for them and appends the bytes to the files."""
         self._join_drain()
         _ffi.check(_ffi.lib().rh_compressor_flush(self.handle))
-        self._release_queued()
+        self._release(self.in_flight + self.queued)
+        self.in_flight, self.queued = [], []
         self._drain()
 
     def _join_drain(self):
@@ -132,6 +151,12 @@ class Compressor:
             from concurrent.futures import ThreadPoolExecutor
             self._pool = ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1))
         return self._pool
+
+    def drain_kernel_stats(self):
+        """What the compression kernel did since the previous call: launches, packets, bytes in and out, kernel time."""
+        st = _ffi.CompressorStats()
+        _ffi.check(_ffi.lib().rh_compressor_drain_stats(self.handle, C.byref(st)))
+        return {"rounds": st.rounds, "jobs": st.jobs, "bytes_in": st.bytes_in, "bytes_out": st.bytes_out, "kernel_ms": st.kernel_ms}
 
     def finish(self):
         """Waits for everything queued, writes the end marks and closes the files (reference src/compressor.rs:46-62)."""

@@ -1131,6 +1131,9 @@ struct rh_compressor {
     Scratch d_jobs, d_stage, d_out[2], d_lens;       // two output areas: round k+1 is compressed while round k's bytes are copied out
     int out_sel = 0;
     unsigned long long* h_lens = nullptr; size_t h_lens_cap = 0;
+    hipEvent_t k0 = nullptr, k1 = nullptr;           // around the kernel of the round in flight
+    rh_compressor_stats stats{};                     // since the last rh_compressor_drain_stats
+    uint64_t round_bytes_in = 0;
 };
 
 namespace {
@@ -1206,8 +1209,12 @@ int compressor_submit_round(rh_compressor* c) {
     RH_HIP(hipMemcpyAsync(c->d_stage.ptr, stage.data(), stage.size(), hipMemcpyHostToDevice, c->stream));
     RH_HIP(hipMemcpyAsync(c->d_jobs.ptr, jobs.data(), n * sizeof(rh_lz4_job), hipMemcpyHostToDevice, c->stream));
     RH_HIP(hipStreamSynchronize(c->stream));        // the pageable staging vectors go out of scope below
+    c->round_bytes_in = 0;
+    for (const rh_lz4_job& jb : jobs) for (uint32_t w = 0; w < jb.n_writes; w++) c->round_bytes_in += jb.write_len[w];
+    RH_HIP(hipEventRecord(c->k0, c->stream));
     int rc = rhk::lz4f_compress_launch(c->d_jobs.as<rh_lz4_job>(), n, c->d_states, c->stream);
     if (rc) return fail("rh_compressor: kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+    RH_HIP(hipEventRecord(c->k1, c->stream));
     RH_HIP(hipMemcpyAsync(c->h_lens, c->d_lens.ptr, n * 8, hipMemcpyDeviceToHost, c->stream));
     R.active = true; R.waited = false;
     return 0;
@@ -1221,6 +1228,11 @@ int compressor_wait_round(rh_compressor* c) {
     RH_HIP(hipStreamSynchronize(c->stream));
     R.waited = true;
     R.lens.assign(c->h_lens, c->h_lens + n);
+    {   float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, c->k0, c->k1) == hipSuccess) c->stats.kernel_ms += ms;
+        c->stats.rounds++; c->stats.jobs += n; c->stats.bytes_in += c->round_bytes_in;
+        for (uint32_t j = 0; j < n; j++) c->stats.bytes_out += R.lens[j];
+    }
     for (uint32_t j = 0; j < n; j++) {
         if (R.images[j]) rh_buffer_release(R.images[j]);
         if (R.lens[j] > R.out_cap[j]) return fail("rh_compressor: stream %u overflowed its output area", R.job_stream[j]);
@@ -1302,7 +1314,11 @@ int rh_compressor_create(rh_device* dev, uint32_t n_streams, int level, rh_compr
         if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->copy_stream, hipStreamNonBlocking, greatest);
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->frames_ready, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreate(&c->k0);
+    if (e == hipSuccess) e = hipEventCreate(&c->k1);
     if (e != hipSuccess) {
+        if (c->k0) (void)hipEventDestroy(c->k0);
+        if (c->k1) (void)hipEventDestroy(c->k1);
         if (c->frames_ready) (void)hipEventDestroy(c->frames_ready);
         if (c->stream) (void)hipStreamDestroy(c->stream);
         if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
@@ -1334,6 +1350,7 @@ void rh_compressor_destroy(rh_compressor* c) {
     if (c->h_lens) (void)hipHostFree(c->h_lens);
     if (c->d_states) (void)hipFree(c->d_states);
     (void)hipEventDestroy(c->frames_ready);
+    (void)hipEventDestroy(c->k0); (void)hipEventDestroy(c->k1);
     (void)hipStreamDestroy(c->stream);
     (void)hipStreamDestroy(c->copy_stream);
     delete c;
@@ -1416,6 +1433,13 @@ int rh_compressor_read(rh_compressor* c, uint32_t stream, void* dst, size_t cap,
         if (rh_compressor_consume(c, stream, k)) return 1;
     }
     *len = done;
+    return 0;
+}
+
+int rh_compressor_drain_stats(rh_compressor* c, rh_compressor_stats* out) {
+    if (!c || !out) return fail("rh_compressor_drain_stats: bad argument");
+    *out = c->stats;
+    c->stats = rh_compressor_stats{};
     return 0;
 }
 

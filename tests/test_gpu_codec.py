@@ -180,6 +180,43 @@ def test_record_compress_decompress_roundtrip(oracle, tmp_path):
     hs.close(); r.close()
 
 
+def test_4k_recording_under_the_500_mb_budget_drops_nothing(oracle, tmp_path):
+    """The budget of the reference's example (500 MB, examples/quads_main_thread.rs:95) holds 16 frames of 4K; a frame's
+    bytes stay in the budget until its round has been compressed (reference src/video_frame.rs:70-77), so the compressor
+    cuts its rounds to what the budget holds instead of waiting for one frame per stream: nothing is dropped, and the
+    bytes in flight never pass what the recorder admits."""
+    from renderer_amd import Compressor, Renderer
+    W, H = 3840, 2160
+    scene = scenes.random_quads_scene(200, 40, W, H, seed=21, target="screen")
+    r = Renderer(W, H)
+    hs = scenes.HipScene(scene, renderer=r)
+    comp = Compressor(r, str(tmp_path), n_streams=64, max_buffer_size_in_megabytes=500.)
+    frame_bytes = W * H * 4
+    peak = [0]
+    statuses = []
+
+    def sink(frame):
+        peak[0] = max(peak[0], frame.buffer_size_in_bytes.load())
+        statuses.append(frame.status.name)
+        comp.compress_to_disk(frame)
+
+    r.start_recording([hs.pipeline], Renderer.clear_color(0., 0., 0., 1.), 500., sink, keep_on_device=True)
+    r.flush()
+    n_frames = 40
+    for _ in range(n_frames):
+        r.render(hs.pipeline, hs.clear, hs.viewport, hs.count)
+        r.finish_frame()
+    budget = r.recorder.buffer_size_in_bytes
+    r.stop_recording([hs.pipeline])
+    comp.finish()
+    assert statuses == ["Captured"] * n_frames and comp.frames_dropped == 0 and comp.frames_captured == n_frames
+    assert comp._round_size(type("F", (), {"frame_size_in_bytes": frame_bytes})) == 8
+    assert peak[0] <= 500 * 1024 * 1024 + frame_bytes
+    assert budget.load() == 0                   # every frame gave its bytes back
+    assert sum(os.path.getsize(os.path.join(tmp_path, f)) for f in os.listdir(tmp_path)) > 0
+    hs.close(); r.close()
+
+
 def png_idat_stream(png):
     """Concatenated IDAT payloads, checking every chunk's CRC on the way."""
     import struct

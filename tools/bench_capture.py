@@ -19,7 +19,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def run_capture(frames=128, streams=64, quads=100_000, side=32, width=3840, height=2160, out="/tmp/rh_cap", hip_ordinal=0,
-                seed=4, before_timing=None, after_timing=None, warmup=None):
+                seed=4, before_timing=None, after_timing=None, warmup=None, budget_mb=None):
     """Renders and records `frames` frames; returns (elapsed seconds, info dict, last recorded image).  `before_timing`
     and `after_timing` are called around the timed loop (multi-process runs put their barriers there).  `warmup` untimed
     frames come first, by default two rounds of the streams: the compressor pins one host buffer per round in flight
@@ -37,7 +37,10 @@ def run_capture(frames=128, streams=64, quads=100_000, side=32, width=3840, heig
     shutil.rmtree(out, ignore_errors=True)
     r = Renderer(W, H, hip_ordinal=hip_ordinal)
     hs = scenes.HipScene(scene, renderer=r)
-    comp = Compressor(r, out, n_streams=streams)
+    # budget: two rounds of the streams' frames may be held on the device at once (33 MB each at 4K): one being
+    # compressed, one being captured
+    budget_mb = (2 * streams + 2) * W * H * 4 / (1024.0 * 1024.0) if budget_mb is None else budget_mb
+    comp = Compressor(r, out, n_streams=streams, max_buffer_size_in_megabytes=budget_mb)
     t_compress = [0.0]
 
     def sink(frame):
@@ -45,9 +48,7 @@ def run_capture(frames=128, streams=64, quads=100_000, side=32, width=3840, heig
         comp.compress_to_disk(frame)
         t_compress[0] += time.perf_counter() - t
 
-    # budget: all streams' frames may be queued on the device at once (33 MB each at 4K)
-    r.start_recording([hs.pipeline], Renderer.clear_color(0., 0., 0., 1.), float((streams + 2) * W * H * 4), sink,
-                      keep_on_device=True)
+    r.start_recording([hs.pipeline], Renderer.clear_color(0., 0., 0., 1.), budget_mb, sink, keep_on_device=True)
     r.flush()
 
     def step():
@@ -68,6 +69,7 @@ def run_capture(frames=128, streams=64, quads=100_000, side=32, width=3840, heig
         f.seek(0)
     t_compress[0] = 0.0
     raw0, packed0 = comp.raw_video_size, comp.compressed_size
+    comp.drain_kernel_stats()
 
     if before_timing:
         before_timing()
@@ -79,6 +81,7 @@ def run_capture(frames=128, streams=64, quads=100_000, side=32, width=3840, heig
     if after_timing:
         after_timing()
     elapsed = time.perf_counter() - t0
+    kernel = comp.drain_kernel_stats()
     raw = comp.raw_video_size - raw0
     packed = comp.compressed_size - packed0
     last = hs.read_recording()
@@ -87,12 +90,75 @@ def run_capture(frames=128, streams=64, quads=100_000, side=32, width=3840, heig
     hs.close()
     r.close()
     shutil.rmtree(out, ignore_errors=True)
-    info = {"frames": frames, "streams": streams,
+    info = {"frames": frames, "streams": streams, "frames_dropped": comp.frames_dropped, "budget_MB": budget_mb,
             "workload": f"{quads} animated quads {side}x{side} px, {W}x{H}, recording attachment, GPU LZ4F level 0 into "
                         f"{streams} stream files per GPU",
-            "compress_ms_per_frame": t_compress[0] / frames * 1e3,
+            "compress_ms_per_frame": t_compress[0] / frames * 1e3, "kernel": kernel,
             "raw_MB_per_frame": raw / frames / 1e6, "compressed_MB_per_frame": packed / frames / 1e6}
     return elapsed, info, last
+
+
+def liblz4_baseline(img, cpu_frames=4, all_cores=True):
+    """The system's liblz4 (what the reference links through lzzzz) with the reference's preferences (level 0,
+    auto-flush; reference src/compressor.rs:138-144) on the image bytes `img`, repeated: one stream on one core, and one
+    stream per core on the box's CPU share as the reference runs them (src/compressor.rs:24-26).  Returns the
+    `cpu_baseline` objects (one core, all cores)."""
+    import ctypes as C
+
+    class Prefs(C.Structure):              # LZ4F_preferences_t of lz4frame.h 1.9.x
+        _fields_ = [("blockSizeID", C.c_uint32), ("blockMode", C.c_uint32), ("contentChecksumFlag", C.c_uint32),
+                    ("frameType", C.c_uint32), ("contentSize", C.c_uint64), ("dictID", C.c_uint32),
+                    ("blockChecksumFlag", C.c_uint32), ("compressionLevel", C.c_int32), ("autoFlush", C.c_uint32),
+                    ("favorDecSpeed", C.c_uint32), ("reserved", C.c_uint32 * 3)]
+
+    L = C.CDLL("liblz4.so.1")
+    L.LZ4F_createCompressionContext.argtypes = [C.POINTER(C.c_void_p), C.c_uint]; L.LZ4F_createCompressionContext.restype = C.c_size_t
+    L.LZ4F_compressBegin.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]; L.LZ4F_compressBegin.restype = C.c_size_t
+    L.LZ4F_compressBound.argtypes = [C.c_size_t, C.c_void_p]; L.LZ4F_compressBound.restype = C.c_size_t
+    L.LZ4F_compressUpdate.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.LZ4F_compressUpdate.restype = C.c_size_t
+    L.LZ4F_isError.argtypes = [C.c_size_t]; L.LZ4F_isError.restype = C.c_uint
+
+    def compress_on_one_core(n_frames, result, slot):
+        """One LZ4F stream, the way one worker thread of the reference holds one (src/compressor.rs:64-69); only the
+        library call on the image is timed.  ctypes releases the GIL during the call, so threads run in parallel."""
+        ctx, prefs = C.c_void_p(), Prefs()
+        prefs.autoFlush = 1
+        assert not L.LZ4F_isError(L.LZ4F_createCompressionContext(C.byref(ctx), 100))
+        head = (C.c_uint8 * 32)()
+        assert not L.LZ4F_isError(L.LZ4F_compressBegin(ctx, head, 32, C.byref(prefs)))
+        src = (C.c_uint8 * len(img)).from_buffer_copy(img)
+        cap = L.LZ4F_compressBound(len(img), C.byref(prefs))
+        dst = (C.c_uint8 * cap)()
+        busy = 0.0
+        for _ in range(n_frames):
+            t1 = time.perf_counter()
+            n = L.LZ4F_compressUpdate(ctx, dst, cap, src, len(img), None)
+            busy += time.perf_counter() - t1
+            assert not L.LZ4F_isError(n)
+        result[slot] = busy
+
+    one = [0.0]
+    compress_on_one_core(cpu_frames, one, 0)
+    single = {"value": cpu_frames / one[0], "unit": "frames/s", "cores": 1, "kind": "reference",
+              "sample": f"system liblz4 1.9.3 (the library the reference links), level 0, {cpu_frames} frames of {len(img)} B on one core "
+                        f"(compress only, no rendering), {one[0]:.2f} s"}
+    if not all_cores:
+        return single, None
+    import threading
+    cores = min(16, os.cpu_count() or 1)
+    busy = [0.0] * cores
+    threads = [threading.Thread(target=compress_on_one_core, args=(cpu_frames, busy, i)) for i in range(cores)]
+    t1 = time.perf_counter()
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    wall = time.perf_counter() - t1
+    multi = {"value": cores * cpu_frames / wall, "unit": "frames/s", "cores": cores, "kind": "reference",
+             "sample": f"system liblz4 1.9.3 (the library the reference links), level 0, {cores} threads with one LZ4F stream each, "
+                       f"{cpu_frames} frames of {len(img)} B per thread (compress only, no rendering), {wall:.2f} s wall including context set-up"}
+    return single, multi
 
 
 def main():
@@ -117,64 +183,10 @@ def main():
            "raw_MB_per_frame": info["raw_MB_per_frame"], "compressed_MB_per_frame": info["compressed_MB_per_frame"],
            "raw_GBps": info["raw_MB_per_frame"] * args.frames / elapsed / 1e3}
 
-    # CPU baseline: the system's liblz4 (what the reference links through lzzzz) with the reference's preferences
-    # (level 0, auto-flush; reference src/compressor.rs:138-144), one stream on one core, the last recorded frame repeated
-    import ctypes as C
-
-    class Prefs(C.Structure):              # LZ4F_preferences_t of lz4frame.h 1.9.x
-        _fields_ = [("blockSizeID", C.c_uint32), ("blockMode", C.c_uint32), ("contentChecksumFlag", C.c_uint32),
-                    ("frameType", C.c_uint32), ("contentSize", C.c_uint64), ("dictID", C.c_uint32),
-                    ("blockChecksumFlag", C.c_uint32), ("compressionLevel", C.c_int32), ("autoFlush", C.c_uint32),
-                    ("favorDecSpeed", C.c_uint32), ("reserved", C.c_uint32 * 3)]
-
-    L = C.CDLL("liblz4.so.1")
-    L.LZ4F_createCompressionContext.argtypes = [C.POINTER(C.c_void_p), C.c_uint]; L.LZ4F_createCompressionContext.restype = C.c_size_t
-    L.LZ4F_compressBegin.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]; L.LZ4F_compressBegin.restype = C.c_size_t
-    L.LZ4F_compressBound.argtypes = [C.c_size_t, C.c_void_p]; L.LZ4F_compressBound.restype = C.c_size_t
-    L.LZ4F_compressUpdate.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
-    L.LZ4F_compressUpdate.restype = C.c_size_t
-    L.LZ4F_isError.argtypes = [C.c_size_t]; L.LZ4F_isError.restype = C.c_uint
-    img = np.ascontiguousarray(last).tobytes()
-
-    def compress_on_one_core(n_frames, result, slot):
-        """One LZ4F stream, the way one worker thread of the reference holds one (src/compressor.rs:64-69); only the
-        library call on the image is timed.  ctypes releases the GIL during the call, so threads run in parallel."""
-        ctx, prefs = C.c_void_p(), Prefs()
-        prefs.autoFlush = 1
-        assert not L.LZ4F_isError(L.LZ4F_createCompressionContext(C.byref(ctx), 100))
-        head = (C.c_uint8 * 32)()
-        assert not L.LZ4F_isError(L.LZ4F_compressBegin(ctx, head, 32, C.byref(prefs)))
-        src = (C.c_uint8 * len(img)).from_buffer_copy(img)
-        cap = L.LZ4F_compressBound(len(img), C.byref(prefs))
-        dst = (C.c_uint8 * cap)()
-        busy = 0.0
-        for _ in range(n_frames):
-            t1 = time.perf_counter()
-            n = L.LZ4F_compressUpdate(ctx, dst, cap, src, len(img), None)
-            busy += time.perf_counter() - t1
-            assert not L.LZ4F_isError(n)
-        result[slot] = busy
-
     if args.cpu_frames > 0:
-        one = [0.0]
-        compress_on_one_core(args.cpu_frames, one, 0)
-        out["cpu_baseline"] = {"value": args.cpu_frames / one[0], "unit": "frames/s", "cores": 1, "kind": "reference-library",
-                               "sample": f"liblz4 1.9.3 level 0, {args.cpu_frames} frames of {len(img)} B on one core "
-                                         f"(compress only, no rendering), {one[0]:.2f} s"}
-        # the reference runs one stream per core (src/compressor.rs:24-26): the same on this box's CPU share
-        import threading
-        cores = min(16, os.cpu_count() or 1)
-        busy = [0.0] * cores
-        threads = [threading.Thread(target=compress_on_one_core, args=(args.cpu_frames, busy, i)) for i in range(cores)]
-        t1 = time.perf_counter()
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
-        wall = time.perf_counter() - t1
-        out["cpu_baseline_all_cores"] = {"value": cores * args.cpu_frames / wall, "unit": "frames/s", "cores": cores, "kind": "reference-library",
-                                         "sample": f"{cores} threads, one LZ4F stream each, {args.cpu_frames} frames per thread, {wall:.2f} s wall "
-                                                   "(includes context set-up)"}
+        single, multi = liblz4_baseline(np.ascontiguousarray(last).tobytes(), args.cpu_frames)
+        out["cpu_baseline"] = single
+        out["cpu_baseline_all_cores"] = multi
     print(json.dumps(out), flush=True)
 
 

@@ -4,7 +4,7 @@
 #pragma once
 #include <stdint.h>
 
-#define RH_DEVICE_ABI_VERSION 11u
+#define RH_DEVICE_ABI_VERSION 12u
 #define RH_MODULE_MAGIC 0x52484d4fu   // "RHMO"
 
 #define RH_DEV_MAX_ATTRIBUTES 8
@@ -152,6 +152,13 @@ struct rh_attach_dev {
     uint8_t* resolve_ptr;
     uint32_t resolve_pitch_px;
     uint32_t resolve_format;
+    // Capture (4-byte UNORM attachments of single-sampled passes): null, or a buffer that receives the texels of the
+    // region [cap_x0, cap_x0 + cap_w) x [cap_y0, cap_y0 + cap_h) as the tile goes back to memory, rows `cap_pitch` bytes
+    // apart, the bytes behind a row's texels zeroed -- what a texture-to-buffer copy behind the pass would write.  Every
+    // tile then writes its part of the region, also the tiles of a Load attachment that no primitive touches.
+    uint8_t* cap_ptr;
+    uint32_t cap_pitch;
+    uint32_t cap_x0, cap_y0, cap_w, cap_h;
 };
 
 struct rh_tile_args {

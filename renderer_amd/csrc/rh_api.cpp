@@ -88,6 +88,7 @@ struct rh_device {
     uint64_t pair_guess = 0;                    // room given to the pair arrays of a queued pass; 0: no pass seen yet
     hipEvent_t counted = nullptr;               // recorded once the count is in h_total and the pairs are sorted
     const void* pending_pass = nullptr;         // (a PassCmd of the command buffer being submitted, or of `pending_cb`)
+    const void* pending_fused = nullptr;        // (the CopyCmd performed by that pass, or null)
     rh_cmdbuf* pending_cb = nullptr;            // the last command buffer of a submit, kept while its last pass awaits its count
     uint32_t pending_capacity = 0;
     // allocation caches (exact-size reuse; capture buffers come and go every frame)
@@ -773,9 +774,26 @@ int launch_module_kernel(hipFunction_t fn, uint32_t grid, uint32_t block, void* 
     return 0;
 }
 
+// The copy of a colour attachment into a buffer right behind the pass that wrote it (the capture of a recorded frame,
+// reference src/video_recorder.rs:107-128) needs no launch and no second trip of the texels through memory when the
+// tile kernel can write the buffer as it writes the tiles back: single-sampled pass over the whole target, 4-byte
+// UNORM attachments only.
+bool fusable_copy(const rh_device* dev, const PassCmd& c, const CopyCmd& cp) {
+    if (dev->strip_row1 != 0 || c.pipeline->samples != 1 || cp.width == 0 || cp.height == 0) return false;
+    bool found = false;
+    for (const rh_attachment_desc& a : c.attachments) {
+        const uint32_t f = a.texture->format;
+        if (f == RH_FORMAT_RGBA_F16 || f == RH_FORMAT_RGBA_F32) return false;
+        if (a.texture == cp.tex) found = a.texture->bpt == 4;
+    }
+    return found;
+}
+
 // `ss`: the scratch areas the pass works in; `no_alloc`: called from rh_submit_static, which must not allocate -- timing
 // marks (they create events) and footprint copies that do not exist yet are left out.
-int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer, rh_device::PassScratch& ss, bool no_alloc) {
+// `fused`: a texture-to-buffer copy that follows the pass in its command buffer and that the tile kernel performs as it
+// writes its tiles back (see fusable_copy), or null.
+int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer, rh_device::PassScratch& ss, bool no_alloc, const CopyCmd* fused) {
     rh_pipeline* pl = c.pipeline;
     const rh_texture* t0 = c.attachments[0].texture;
     const uint32_t W = t0->width, H = t0->height;
@@ -923,7 +941,7 @@ int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer, rh_device::Pa
     ta.tile_start = tile_start; ta.tile_end = tile_end;
     ta.pair_total = pair_total; ta.pair_capacity = (uint32_t)total;
     ta.n_att = (uint32_t)c.attachments.size();
-    bool any_clear = false;
+    bool any_clear = false, capturing = false;
     for (size_t i = 0; i < c.attachments.size(); i++) {
         const rh_attachment_desc& a = c.attachments[i];
         rh_attach_dev& d = ta.att[i];
@@ -931,6 +949,11 @@ int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer, rh_device::Pa
         d.clear_rgba8 = unorm8(a.clear[0]) | (unorm8(a.clear[1]) << 8) | (unorm8(a.clear[2]) << 16) | (unorm8(a.clear[3]) << 24);
         for (int k = 0; k < 4; k++) d.clear_f[k] = (float)a.clear[k];
         if (a.resolve_target) { d.resolve_ptr = (uint8_t*)a.resolve_target->dptr; d.resolve_pitch_px = a.resolve_target->width; d.resolve_format = a.resolve_target->format; }
+        if (fused && a.texture == fused->tex && !capturing) {
+            capturing = true;
+            d.cap_ptr = (uint8_t*)fused->buf->dptr; d.cap_pitch = fused->bytes_per_row;
+            d.cap_x0 = fused->ox; d.cap_y0 = fused->oy; d.cap_w = fused->width; d.cap_h = fused->height;
+        }
         any_clear = any_clear || a.load_op == RH_LOAD_OP_CLEAR;
     }
     ta.src_factor = pl->targets[0].src_factor; ta.dst_factor = pl->targets[0].dst_factor;
@@ -973,7 +996,7 @@ int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer, rh_device::Pa
         // every tile runs: the resolve rewrites the whole target from the multisampled texture (Load included)
         hipFunction_t fn = pl->fs->tile_ms[ms_index - 1];
         if (n_launch_tiles > 0 && launch_module_kernel(fn, n_launch_tiles, RH_TILE_THREADS, &ta, sizeof ta, s)) return 1;
-    } else if ((total > 0 || any_clear) && n_launch_tiles > 0) {
+    } else if ((total > 0 || any_clear || fused) && n_launch_tiles > 0) {
         bool any_float = false;
         for (const rh_attachment_desc& a : c.attachments) any_float = any_float || a.texture->format == RH_FORMAT_RGBA_F16 || a.texture->format == RH_FORMAT_RGBA_F32;
         hipFunction_t fn = any_float ? pl->fs->tile_wide[c.attachments.size() - 1] : pl->fs->tile[c.attachments.size() - 1];
@@ -981,7 +1004,7 @@ int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer, rh_device::Pa
     }
     if (!no_alloc && timing_mark(dev)) return 1;
 
-    if (deferred) { dev->pending_pass = &c; dev->pending_capacity = (uint32_t)total; }
+    if (deferred) { dev->pending_pass = &c; dev->pending_capacity = (uint32_t)total; dev->pending_fused = fused; }
     dev->stats.clusters = n_clusters; dev->stats.bin_entries = deferred ? 0 : total;
     dev->stats.tiles_x = p.tiles_x; dev->stats.tiles_y = p.tiles_y; dev->stats.tile_w = RH_TILE_W; dev->stats.tile_h = RH_TILE_H;
     return 0;
@@ -994,6 +1017,7 @@ int resolve_pending(rh_device* dev, bool blocking) {
     if (!dev->pending_pass) return 0;
     if (!blocking && hipEventQuery(dev->counted) == hipErrorNotReady) return 0;
     const PassCmd& c = *static_cast<const PassCmd*>(dev->pending_pass);
+    const CopyCmd* const fused = static_cast<const CopyCmd*>(dev->pending_fused);
     const uint64_t capacity = dev->pending_capacity;
     rh_cmdbuf* const kept = dev->pending_cb;
     dev->pending_pass = nullptr; dev->pending_cb = nullptr;
@@ -1010,7 +1034,7 @@ int resolve_pending(rh_device* dev, bool blocking) {
             // the attempt that wrote nothing is not a pass of its own: its timing marks go back to the pool
             for (int k = 0; k < 4 && dev->timing && !dev->timing_events.empty(); k++) { dev->event_pool.push_back(dev->timing_events.back()); dev->timing_events.pop_back(); }
             dev->stats.reruns++;
-            rc = execute_pass(dev, c, false, dev->grown, false);
+            rc = execute_pass(dev, c, false, dev->grown, false, fused);
         }
     }
     if (kept) rh_cmdbuf_release(kept);
@@ -1037,10 +1061,14 @@ int rh_submit(rh_device* dev, rh_cmdbuf* const* list, size_t n) {
         rh_cmdbuf* cb = list[i];
         if (!cb) continue;
         if (!rc) {
-            for (const Cmd& c : cb->cmds) {
+            for (size_t k = 0; k < cb->cmds.size() && !rc; k++) {
+                const Cmd& c = cb->cmds[k];
                 rc = resolve_pending(dev);
-                if (!rc) rc = c.kind == 0 ? execute_pass(dev, c.pass, true, dev->grown, false) : execute_copy(dev, c.copy);
                 if (rc) break;
+                if (c.kind != 0) { rc = execute_copy(dev, c.copy); continue; }
+                const CopyCmd* fused = (k + 1 < cb->cmds.size() && cb->cmds[k + 1].kind == 1 && fusable_copy(dev, c.pass, cb->cmds[k + 1].copy)) ? &cb->cmds[k + 1].copy : nullptr;
+                rc = execute_pass(dev, c.pass, true, dev->grown, false, fused);
+                if (fused) k++;
             }
             // A pass still awaiting its count at the end of the submit stays that way: the host does not wait here.  Its
             // command buffer is kept until the count has been looked at, by the next call that queues work or reads results.
@@ -1061,9 +1089,13 @@ int rh_submit_static(rh_device* dev, rh_cmdbuf* const* list, size_t n) {
     for (size_t i = 0; i < n; i++) {
         const rh_cmdbuf* cb = list[i];
         if (!cb) continue;
-        for (const Cmd& c : cb->cmds) {
+        for (size_t k = 0; k < cb->cmds.size(); k++) {
+            const Cmd& c = cb->cmds[k];
             // every pass waits for its pair count (that is a synchronisation, not an allocation) and works in the held areas
-            if (c.kind == 0 ? execute_pass(dev, c.pass, false, dev->held, true) : execute_copy(dev, c.copy)) return 1;
+            if (c.kind != 0) { if (execute_copy(dev, c.copy)) return 1; continue; }
+            const CopyCmd* fused = (k + 1 < cb->cmds.size() && cb->cmds[k + 1].kind == 1 && fusable_copy(dev, c.pass, cb->cmds[k + 1].copy)) ? &cb->cmds[k + 1].copy : nullptr;
+            if (execute_pass(dev, c.pass, false, dev->held, true, fused)) return 1;
+            if (fused) k++;
         }
     }
     return 0;

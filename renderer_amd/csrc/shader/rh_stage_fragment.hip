@@ -422,6 +422,26 @@ RH_DEVICE void blend_pixel(uint4* px, const rh_attach_dev& at, float4 s, uint32_
     *px = make_uint4(__float_as_uint(o0), __float_as_uint(o1), __float_as_uint(o2), __float_as_uint(o3));
 }
 
+// The tile's part of a captured region (rh_attach_dev::cap_ptr): the texels as the attachment's memory holds them, and,
+// from the tile that holds the region's last column, the zeroed bytes behind each row.
+RH_DEVICE void capture_tile(const rh_attach_dev& at, const uint32_t* px, int ox, int oy, int lane) {
+    for (int i = lane; i < TILE_PX; i += 64) {
+        const uint32_t cx = (uint32_t)(ox + (i & (TILE - 1))) - at.cap_x0, cy = (uint32_t)(oy + i / TILE) - at.cap_y0;
+        if (cx < at.cap_w && cy < at.cap_h) {
+            const uint32_t v = px[i];
+            *reinterpret_cast<uint32_t*>(at.cap_ptr + (size_t)cy * at.cap_pitch + (size_t)cx * 4u) = at.format == FORMAT_BGRA_U8 ? swap_rb(v) : v;
+        }
+    }
+    const uint32_t last = at.cap_x0 + at.cap_w - 1u, pad = (at.cap_pitch - at.cap_w * 4u) / 4u;
+    if (last - (uint32_t)ox < (uint32_t)TILE && pad != 0u)
+        for (int r = 0; r < TILE; r++) {
+            const uint32_t cy = (uint32_t)(oy + r) - at.cap_y0;
+            if (cy < at.cap_h)
+                for (uint32_t k = (uint32_t)lane; k < pad; k += 64u) *reinterpret_cast<uint32_t*>(at.cap_ptr + (size_t)cy * at.cap_pitch + (size_t)(at.cap_w + k) * 4u) = 0u;
+        }
+}
+RH_DEVICE void capture_tile(const rh_attach_dev&, const uint4*, int, int, int) {}        // (wide kernels: never asked to)
+
 // The LDS of a tile wave.
 template <int NA, bool WIDE = false>
 struct TileLds {
@@ -453,7 +473,7 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
 #pragma unroll
     for (int t = 0; t < NA; t++) {
         const rh_attach_dev& at = a.att[t];
-        if (at.load_op == 0u && start == end) continue;          // untouched tile of a Load attachment
+        if (at.load_op == 0u && start == end && !at.cap_ptr) continue;          // untouched tile of a Load attachment
         for (int i = lane; i < TILE_PX; i += 64) {
             const uint32_t gx = (uint32_t)(ox + (i & (TILE - 1))), gy = (uint32_t)(oy + i / TILE);
             PxT v{};
@@ -676,11 +696,14 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
 #pragma unroll
     for (int t = 0; t < NA; t++) {
         const rh_attach_dev& at = a.att[t];
-        if (at.load_op == 0u && start == end) continue;
-        for (int i = lane; i < TILE_PX; i += 64) {
-            const uint32_t gx = (uint32_t)(ox + (i & (TILE - 1))), gy = (uint32_t)(oy + i / TILE);
-            if (gx < p.width && gy < p.height) store_pixel(at, (size_t)gy * at.pitch_px + gx, lds.px[t][i]);
-        }
+        const bool untouched = at.load_op == 0u && start == end;
+        if (untouched && !at.cap_ptr) continue;
+        if (!untouched)
+            for (int i = lane; i < TILE_PX; i += 64) {
+                const uint32_t gx = (uint32_t)(ox + (i & (TILE - 1))), gy = (uint32_t)(oy + i / TILE);
+                if (gx < p.width && gy < p.height) store_pixel(at, (size_t)gy * at.pitch_px + gx, lds.px[t][i]);
+            }
+        if (!WIDE && at.cap_ptr) capture_tile(at, &lds.px[t][0], ox, oy, lane);
     }
     RH_PHASE_MARK(3)
     RH_PHASE_END

@@ -518,3 +518,40 @@ def test_two_recorded_pipelines_share_the_recording_texture(oracle):
         assert_same(got[0][:, :W * 4].reshape(H, W, 4), o2["recording"], "captured frame")
     finally:
         r.close()
+
+
+def test_captured_frame_of_a_loaded_sparse_pass_with_margins(oracle):
+    """The capture copy behind the Last recorded pipeline (reference src/video_recorder.rs:107-128) is performed by the
+    tile kernel as it writes its tiles back.  A pass that loads the recording texture and touches few tiles still has
+    to deliver every texel of the viewport's region, rows padded to 256 bytes with zeros, in the form that waits for the
+    pair count and in the queued one."""
+    from renderer_amd import Renderer, _ffi
+    W, H = 333, 217
+    scene = scenes.random_quads_scene(12, 20, W, H, seed=31, target="screen")
+    scene.update(record=True, record_clear=None, viewport=(1.6, 1.0))
+    before = np.random.default_rng(32).integers(0, 255, (H, W, 4), dtype=np.uint8)
+    r = Renderer(W, H)
+    try:
+        hs = scenes.HipScene(scene, renderer=r)
+        tex = r.recorder.recording_texture
+        _ffi.check(_ffi.lib().rh_texture_write(tex.handle, 0, 0, 0, W, H, before.ctypes.data, before.nbytes, W * 4))
+        recording = before
+        for k in range(3):
+            want = scenes.draw_oracle(scene, initial_recording=recording)
+            recording = want["recording"]
+            hs.draw()
+            r.synchronize()
+            r.recorder.process_mapped_buffers()
+            frame = hs.frames[k]
+            got = []
+            frame.image_data.bytes_fn(lambda b: got.append(np.array(b).reshape(frame.height, frame.padded_bytes_per_row)))
+            x0, y0 = int(np.ceil(hs.viewport.margin_x)), int(np.ceil(hs.viewport.margin_y))
+            assert (x0 > 0 or y0 > 0) and frame.padded_bytes_per_row > frame.width * 4
+            # the copied extent is the texture minus the rounded-up margins on both sides (src/video_recorder.rs:124-125),
+            # which can be a row or column short of the frame's size; what is not copied stays zero
+            ew, eh = W - 2 * x0, H - 2 * y0
+            assert_same(got[0][:eh, :ew * 4].reshape(eh, ew, 4), recording[y0:y0 + eh, x0:x0 + ew], f"captured frame {k + 1}")
+            assert not got[0][:, ew * 4:].any() and not got[0][eh:].any(), "row padding and rows not copied"
+            assert_same(tex.read(), recording, f"recording texture after frame {k + 1}")
+    finally:
+        r.close()

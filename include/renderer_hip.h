@@ -302,6 +302,25 @@ int rh_png_encode(rh_device* dev, rh_buffer* image, uint32_t width, uint32_t hei
  * decoding stops after the last complete block; *complete is 1 when the end mark was reached. */
 int rh_lz4f_decompress(const void* src, size_t src_len, void* dst, size_t dst_cap, size_t* produced, size_t* consumed, int* complete);
 
+/* lz4f::BufReadDecompressor over many stream files at once (src/decompressor.rs:186-249: one reader per `.sz` file, read
+ * incrementally).  The caller feeds each stream the bytes of its file in pieces of any size; rh_decoder_run decodes the
+ * complete LZ4F blocks fed so far, every stream in the same kernel launch (one wavefront per stream; at most
+ * RH_DECODER_MAX_BLOCKS_PER_RUN blocks per stream and call), and the decoded bytes are handed out in order through
+ * peek / consume (pinned host memory owned by the decoder).  A stream whose file ends in the middle of a block simply
+ * stops at its last complete block (src/decompressor.rs:216-235 stops at an unclean end); a malformed block ends its
+ * stream the same way.  dev = NULL: the same object decoding on the host (no GPU needed). */
+typedef struct rh_decoder rh_decoder;
+#define RH_DECODER_MAX_BLOCKS_PER_RUN 32
+enum { RH_STREAM_RUNNING = 0, RH_STREAM_ENDED = 1 /* end mark reached */, RH_STREAM_FAILED = 2 /* not an LZ4 frame, or a malformed block */ };
+int rh_decoder_create(rh_device* dev, uint32_t n_streams, rh_decoder** out);
+void rh_decoder_destroy(rh_decoder* d);
+int rh_decoder_feed(rh_decoder* d, uint32_t stream, const void* src, size_t len);
+int rh_decoder_run(rh_decoder* d);
+int rh_decoder_peek(rh_decoder* d, uint32_t stream, const uint8_t** ptr, size_t* len);
+int rh_decoder_consume(rh_decoder* d, uint32_t stream, size_t n);
+/* state: RH_STREAM_*; buffered: fed bytes not decoded yet; ready: decoded bytes not consumed yet (any pointer may be NULL) */
+int rh_decoder_stream_info(rh_decoder* d, uint32_t stream, int* state, size_t* buffered, size_t* ready);
+
 #ifdef __cplusplus
 }
 #endif

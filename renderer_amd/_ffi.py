@@ -140,6 +140,13 @@ SIGNATURES = {
     "rh_png_bound": (C.c_size_t, [C.c_uint32, C.c_uint32]),
     "rh_png_encode": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.c_uint32, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "rh_lz4f_decompress": (C.c_int, [_P, C.c_size_t, _P, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
+    "rh_decoder_create": (C.c_int, [_P, C.c_uint32, _PP]),
+    "rh_decoder_destroy": (None, [_P]),
+    "rh_decoder_feed": (C.c_int, [_P, C.c_uint32, _P, C.c_size_t]),
+    "rh_decoder_run": (C.c_int, [_P]),
+    "rh_decoder_peek": (C.c_int, [_P, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "rh_decoder_consume": (C.c_int, [_P, C.c_uint32, C.c_size_t]),
+    "rh_decoder_stream_info": (C.c_int, [_P, C.c_uint32, C.POINTER(C.c_int), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
 }
 
 _lib = None

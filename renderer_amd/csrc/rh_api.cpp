@@ -1621,3 +1621,281 @@ int rh_lz4f_decompress(const void* src_, size_t n, void* dst_, size_t cap, size_
 }
 
 } // extern "C"
+
+// ---- stream decoder ------------------------------------------------------------------------------------------------------------
+struct rh_decoder {
+    rh_device* dev = nullptr;                        // null: host decoding
+    uint32_t n_streams = 0;
+    struct Segment { const uint8_t* ptr = nullptr; size_t len = 0; int buf = -1; };
+    struct Stream {
+        std::vector<uint8_t> pending;                // fed bytes not decoded yet, from `at`
+        size_t at = 0;
+        bool header_done = false;
+        uint32_t trailer = 0;                        // 4 with block checksums
+        bool content_checksum = false;
+        uint32_t max_block = 0;                      // decoded bytes of a block at most (BD byte)
+        int state = RH_STREAM_RUNNING;
+        uint64_t decoded = 0;
+        std::deque<Segment> ready;
+        std::vector<uint8_t> window;                 // host decoding: the last 64 KiB decoded
+    };
+    std::vector<Stream> st;
+    struct OutBuf { void* h = nullptr; size_t cap = 0; size_t live = 0; };
+    std::vector<OutBuf> bufs;                        // decoded bytes wait here (pinned with a device, plain memory without)
+    rh_lz4_decode_state* d_states = nullptr;
+    Scratch d_jobs, d_src, d_out;
+    void* h_src = nullptr; size_t h_src_cap = 0;     // pinned staging of the compressed bytes of a run
+    rh_lz4_decode_job* h_jobs = nullptr; size_t h_jobs_cap = 0;
+};
+
+namespace {
+
+// One block's sequences on the host (`hist` = the decoded bytes so far, ending at out + pos).
+bool host_decode_block(const uint8_t* b, const uint8_t* bend, std::vector<uint8_t>& out, size_t block_start, size_t max_block, uint64_t before) {
+    while (b < bend) {
+        const unsigned token = *b++;
+        size_t lit = token >> 4;
+        if (lit == 15) { unsigned x; do { if (b >= bend) return false; x = *b++; lit += x; } while (x == 255); }
+        if ((size_t)(bend - b) < lit || out.size() - block_start + lit > max_block) return false;
+        out.insert(out.end(), b, b + lit); b += lit;
+        if (b >= bend) break;
+        if (bend - b < 2) return false;
+        const size_t off = (size_t)b[0] | ((size_t)b[1] << 8); b += 2;
+        size_t ml = token & 15;
+        if (ml == 15) { unsigned x; do { if (b >= bend) return false; x = *b++; ml += x; } while (x == 255); }
+        ml += 4;
+        if (off == 0 || off > before + out.size() || out.size() - block_start + ml > max_block) return false;
+        if (off > out.size()) return false;          // (the caller keeps 64 KiB of history in front of the data)
+        const size_t from = out.size() - off;
+        for (size_t i = 0; i < ml; i++) out.push_back(out[from + i]);
+    }
+    return b == bend;
+}
+
+int decoder_out_buffer(rh_decoder* d, size_t total) {
+    int bi = -1;
+    for (size_t i = 0; i < d->bufs.size(); i++) if (d->bufs[i].live == 0 && d->bufs[i].cap >= total) { bi = (int)i; break; }
+    if (bi >= 0) return bi;
+    for (size_t i = 0; i < d->bufs.size(); i++) if (d->bufs[i].live == 0) { bi = (int)i; break; }
+    if (bi < 0) { d->bufs.emplace_back(); bi = (int)d->bufs.size() - 1; }
+    rh_decoder::OutBuf& b = d->bufs[bi];
+    if (b.h) { if (d->dev) (void)hipHostFree(b.h); else free(b.h); }
+    b.h = nullptr; b.cap = 0;
+    const size_t want = total + total / 4 + 4096;
+    if (d->dev) { if (hipHostMalloc(&b.h, want, hipHostMallocDefault) != hipSuccess) { fail("rh_decoder: pinned allocation of %zu bytes failed", want); return -1; } }
+    else { b.h = malloc(want); if (!b.h) { fail("rh_decoder: out of memory"); return -1; } }
+    b.cap = want;
+    return bi;
+}
+
+} // namespace
+
+extern "C" {
+
+int rh_decoder_create(rh_device* dev, uint32_t n_streams, rh_decoder** out) {
+    if (!out || n_streams == 0) return fail("rh_decoder_create: bad argument");
+    rh_decoder* d = new rh_decoder();
+    d->dev = dev; d->n_streams = n_streams; d->st.resize(n_streams);
+    if (dev) {
+        if (enter(dev)) { delete d; return 1; }
+        if (hipMalloc((void**)&d->d_states, (size_t)n_streams * sizeof(rh_lz4_decode_state)) != hipSuccess) { delete d; return fail("rh_decoder_create: device allocation failed"); }
+        device_retain(dev);
+    }
+    *out = d;
+    return 0;
+}
+
+void rh_decoder_destroy(rh_decoder* d) {
+    if (!d) return;
+    rh_device* dev = d->dev;
+    if (dev) {
+        (void)hipSetDevice(dev->ordinal);
+        (void)hipStreamSynchronize(dev->stream);
+        Scratch* all[] = { &d->d_jobs, &d->d_src, &d->d_out };
+        for (Scratch* s : all) s->release();
+        if (d->d_states) (void)hipFree(d->d_states);
+        if (d->h_src) (void)hipHostFree(d->h_src);
+        if (d->h_jobs) (void)hipHostFree(d->h_jobs);
+    }
+    for (auto& b : d->bufs) if (b.h) { if (dev) (void)hipHostFree(b.h); else free(b.h); }
+    delete d;
+    if (dev) device_release(dev);
+}
+
+int rh_decoder_feed(rh_decoder* d, uint32_t stream, const void* src, size_t len) {
+    if (!d || (!src && len)) return fail("rh_decoder_feed: bad argument");
+    if (stream >= d->n_streams) return fail("rh_decoder_feed: stream %u out of range (%u streams)", stream, d->n_streams);
+    rh_decoder::Stream& S = d->st[stream];
+    if (S.state != RH_STREAM_RUNNING) return 0;      // bytes behind the end mark, or behind the failure: ignored
+    if (S.at > 0 && S.at * 2 > S.pending.size()) { S.pending.erase(S.pending.begin(), S.pending.begin() + (ptrdiff_t)S.at); S.at = 0; }
+    S.pending.insert(S.pending.end(), (const uint8_t*)src, (const uint8_t*)src + len);
+    return 0;
+}
+
+int rh_decoder_run(rh_decoder* d) {
+    if (!d) return fail("rh_decoder_run: null decoder");
+    if (d->dev && enter(d->dev)) return 1;
+    struct Plan { uint32_t stream, n_blocks; size_t src_at, src_len, stage_off; uint64_t out_cap, out_off; bool ends; size_t end_skip; };
+    std::vector<Plan> plans;
+    size_t stage_total = 0, out_total = 0;
+    for (uint32_t si = 0; si < d->n_streams; si++) {
+        rh_decoder::Stream& S = d->st[si];
+        if (S.state != RH_STREAM_RUNNING) continue;
+        const uint8_t* p = S.pending.data(); const size_t n = S.pending.size();
+        auto le32 = [&](size_t at) { return (uint32_t)p[at] | ((uint32_t)p[at + 1] << 8) | ((uint32_t)p[at + 2] << 16) | ((uint32_t)p[at + 3] << 24); };
+        if (!S.header_done) {
+            if (n - S.at < 7) continue;
+            if (le32(S.at) != 0x184D2204u || (p[S.at + 4] >> 6) != 1) { S.state = RH_STREAM_FAILED; continue; }
+            const uint8_t flg = p[S.at + 4], bd = p[S.at + 5];
+            const size_t header = 6 + ((flg >> 3) & 1 ? 8 : 0) + (flg & 1 ? 4 : 0) + 1;
+            if (n - S.at < header) continue;
+            const uint32_t id = (bd >> 4) & 7u;
+            if (id < 4) { S.state = RH_STREAM_FAILED; continue; }
+            S.max_block = 1u << (8 + 2 * id);                             // 4: 64 KiB ... 7: 4 MiB
+            if (d->dev && S.max_block > 65536u) return fail("rh_decoder: stream %u uses %u-byte blocks; the device decoder takes 64 KiB blocks (the reference's setting)", si, S.max_block);
+            S.trailer = (flg >> 4) & 1 ? 4 : 0; S.content_checksum = (flg >> 2) & 1;
+            S.at += header; S.header_done = true;
+        }
+        Plan pl{}; pl.stream = si; pl.src_at = S.at;
+        size_t pos = S.at;
+        while (pl.n_blocks < RH_DECODER_MAX_BLOCKS_PER_RUN) {
+            if (n - pos < 4) break;
+            const uint32_t bh = le32(pos);
+            if (bh == 0) { pl.ends = true; pl.end_skip = 4; break; }
+            const size_t bsz = bh & 0x7fffffffu;
+            if (bsz > (size_t)S.max_block + 65536) { if (pl.n_blocks == 0) S.state = RH_STREAM_FAILED; break; }      // (decoded after the blocks before it)
+            if (n - pos - 4 < bsz + S.trailer) break;                     // incomplete: wait for more bytes
+            pos += 4 + bsz + S.trailer; pl.n_blocks++;
+        }
+        pl.src_len = pos - S.at;
+        if (pl.n_blocks == 0) { if (pl.ends) { S.at += pl.end_skip; S.state = RH_STREAM_ENDED; } continue; }
+        pl.out_cap = (uint64_t)pl.n_blocks * S.max_block;
+        pl.stage_off = stage_total; stage_total += ((pl.src_len + 64 + 4095) & ~(size_t)4095) + 4096;
+        pl.out_off = out_total; out_total += pl.out_cap + 32;
+        plans.push_back(pl);
+    }
+    if (plans.empty()) return 0;
+    const int bi = decoder_out_buffer(d, out_total);
+    if (bi < 0) return 1;
+    uint8_t* const host_out = (uint8_t*)d->bufs[bi].h;
+    std::vector<uint64_t> produced(plans.size(), 0);
+    std::vector<uint32_t> blocks_done(plans.size(), 0), status(plans.size(), 0);
+    if (d->dev) {
+        rh_device* dev = d->dev;
+        if (stage_total > d->h_src_cap) {
+            if (d->h_src) (void)hipHostFree(d->h_src);
+            d->h_src = nullptr; d->h_src_cap = 0;
+            RH_HIP(hipHostMalloc(&d->h_src, stage_total + stage_total / 4, hipHostMallocDefault));
+            d->h_src_cap = stage_total + stage_total / 4;
+        }
+        if (plans.size() > d->h_jobs_cap) {
+            if (d->h_jobs) (void)hipHostFree(d->h_jobs);
+            d->h_jobs = nullptr; d->h_jobs_cap = 0;
+            RH_HIP(hipHostMalloc((void**)&d->h_jobs, plans.size() * 2 * sizeof(rh_lz4_decode_job), hipHostMallocDefault));
+            d->h_jobs_cap = plans.size() * 2;
+        }
+        if (d->d_src.ensure(stage_total) || d->d_out.ensure(out_total) || d->d_jobs.ensure(plans.size() * sizeof(rh_lz4_decode_job))) return 1;
+        for (size_t j = 0; j < plans.size(); j++) {
+            const Plan& pl = plans[j];
+            rh_decoder::Stream& S = d->st[pl.stream];
+            memcpy((uint8_t*)d->h_src + pl.stage_off, S.pending.data() + pl.src_at, pl.src_len);
+            rh_lz4_decode_job& jb = d->h_jobs[j];
+            memset(&jb, 0, sizeof jb);
+            jb.stream = pl.stream; jb.n_blocks = pl.n_blocks;
+            jb.src = d->d_src.as<uint8_t>() + pl.stage_off; jb.src_len = (uint32_t)pl.src_len; jb.block_trailer = S.trailer;
+            // (out_off is a multiple of 16 plus what makes the address congruent to the stream position)
+            jb.out = d->d_out.as<uint8_t>() + ((pl.out_off + 15) & ~(size_t)15) + (S.decoded & 15u);
+            jb.out_cap = pl.out_cap; jb.decoded_before = S.decoded;
+        }
+        hipStream_t s = dev->stream;
+        RH_HIP(hipMemcpyAsync(d->d_src.ptr, d->h_src, stage_total, hipMemcpyHostToDevice, s));
+        RH_HIP(hipMemcpyAsync(d->d_jobs.ptr, d->h_jobs, plans.size() * sizeof(rh_lz4_decode_job), hipMemcpyHostToDevice, s));
+        const int rc = rhk::lz4f_decode_launch(d->d_jobs.as<rh_lz4_decode_job>(), (uint32_t)plans.size(), d->d_states, s);
+        if (rc) return fail("rh_decoder: kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+        RH_HIP(hipMemcpyAsync(d->h_jobs, d->d_jobs.ptr, plans.size() * sizeof(rh_lz4_decode_job), hipMemcpyDeviceToHost, s));
+        RH_HIP(hipStreamSynchronize(s));
+        size_t off = 0;
+        for (size_t j = 0; j < plans.size(); j++) {
+            produced[j] = d->h_jobs[j].out_len; blocks_done[j] = d->h_jobs[j].blocks_done; status[j] = d->h_jobs[j].status;
+            if (produced[j] > plans[j].out_cap) return fail("rh_decoder: stream %u overflowed its output area", plans[j].stream);
+            if (produced[j]) RH_HIP(hipMemcpyAsync(host_out + off, d->h_jobs[j].out, produced[j], hipMemcpyDeviceToHost, s));
+            off += produced[j];
+        }
+        RH_HIP(hipStreamSynchronize(s));
+    } else {
+        size_t off = 0;
+        for (size_t j = 0; j < plans.size(); j++) {
+            const Plan& pl = plans[j];
+            rh_decoder::Stream& S = d->st[pl.stream];
+            // decoded bytes are appended behind the stream's window, so that matches find their history in front
+            std::vector<uint8_t> work = S.window;
+            const size_t hist = work.size();
+            const uint8_t* p = S.pending.data() + pl.src_at;
+            size_t pos = 0; uint64_t good = 0;
+            for (uint32_t b = 0; b < pl.n_blocks; b++) {
+                const uint32_t bh = (uint32_t)p[pos] | ((uint32_t)p[pos + 1] << 8) | ((uint32_t)p[pos + 2] << 16) | ((uint32_t)p[pos + 3] << 24);
+                const size_t bsz = bh & 0x7fffffffu, block_start = work.size();
+                bool ok = true;
+                if (bh & 0x80000000u) { ok = bsz <= S.max_block; if (ok) work.insert(work.end(), p + pos + 4, p + pos + 4 + bsz); }
+                else ok = host_decode_block(p + pos + 4, p + pos + 4 + bsz, work, block_start, S.max_block, S.decoded - hist);
+                if (!ok) { status[j] = RH_LZ4_DECODE_MALFORMED; work.resize(block_start); break; }
+                pos += 4 + bsz + S.trailer; blocks_done[j]++; good = work.size() - hist;
+            }
+            produced[j] = good;
+            memcpy(host_out + off, work.data() + hist, good);
+            off += good;
+            const size_t keep = std::min<size_t>(work.size(), 65536);
+            S.window.assign(work.end() - (ptrdiff_t)keep, work.end());
+        }
+    }
+    size_t off = 0;
+    for (size_t j = 0; j < plans.size(); j++) {
+        const Plan& pl = plans[j];
+        rh_decoder::Stream& S = d->st[pl.stream];
+        if (produced[j]) {
+            rh_decoder::Segment sg; sg.ptr = host_out + off; sg.len = produced[j]; sg.buf = bi;
+            S.ready.push_back(sg); d->bufs[bi].live++;
+        }
+        off += produced[j];
+        S.decoded += produced[j];
+        if (status[j] != RH_LZ4_DECODE_OK) { S.state = RH_STREAM_FAILED; continue; }
+        S.at = pl.src_at + pl.src_len;
+        if (pl.ends) { S.at += pl.end_skip; S.state = RH_STREAM_ENDED; }
+    }
+    return 0;
+}
+
+int rh_decoder_peek(rh_decoder* d, uint32_t stream, const uint8_t** ptr, size_t* len) {
+    if (!d || !ptr || !len) return fail("rh_decoder_peek: bad argument");
+    if (stream >= d->n_streams) return fail("rh_decoder_peek: stream %u out of range", stream);
+    rh_decoder::Stream& S = d->st[stream];
+    if (S.ready.empty()) { *ptr = nullptr; *len = 0; return 0; }
+    *ptr = S.ready.front().ptr; *len = S.ready.front().len;
+    return 0;
+}
+
+int rh_decoder_consume(rh_decoder* d, uint32_t stream, size_t n) {
+    if (!d) return fail("rh_decoder_consume: null decoder");
+    if (stream >= d->n_streams) return fail("rh_decoder_consume: stream %u out of range", stream);
+    rh_decoder::Stream& S = d->st[stream];
+    while (n) {
+        if (S.ready.empty()) return fail("rh_decoder_consume: more bytes than are ready");
+        rh_decoder::Segment& sg = S.ready.front();
+        const size_t k = std::min(n, sg.len);
+        sg.ptr += k; sg.len -= k; n -= k;
+        if (sg.len == 0) { d->bufs[sg.buf].live--; S.ready.pop_front(); }
+    }
+    return 0;
+}
+
+int rh_decoder_stream_info(rh_decoder* d, uint32_t stream, int* state, size_t* buffered, size_t* ready) {
+    if (!d) return fail("rh_decoder_stream_info: null decoder");
+    if (stream >= d->n_streams) return fail("rh_decoder_stream_info: stream %u out of range", stream);
+    const rh_decoder::Stream& S = d->st[stream];
+    if (state) *state = S.state;
+    if (buffered) *buffered = S.pending.size() - S.at;
+    if (ready) { size_t r = 0; for (const auto& sg : S.ready) r += sg.len; *ready = r; }
+    return 0;
+}
+
+} // extern "C"

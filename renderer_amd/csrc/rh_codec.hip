@@ -477,7 +477,223 @@ extern "C" __global__ __launch_bounds__(64) void rh_lz4f_compress(const rh_lz4_j
     if (lane == 0) { S.current_offset = st.current_offset; S.dict_size = st.dict_size; *job.out_len = op; }
 }
 
+// ---- LZ4F block decoding (the inverse; reference src/decompressor.rs:186-249 reads its stream files through
+// lz4f::BufReadDecompressor) ----------------------------------------------------------------------------------------------
+// One wavefront per stream walks the sequences of its blocks in order; what is parallel is inside a sequence: the
+// look-ahead (the next 64 compressed bytes arrive with one LDS read: token, length bytes, short literal runs and the
+// offset are picked out of the lanes), the literal copy and the match copy (an overlapping match repeats with the period
+// of its offset, so every byte's source lies before the match).  Decoded bytes go to a 64 KiB ring in LDS, which is
+// also where matches read from, and leave for memory one block at a time in 16-byte pieces.
+namespace {
+
+constexpr uint32_t IN_WINDOW = 8192u, IN_HALF = IN_WINDOW / 2u;
+
+struct DecodeLds {
+    uint8_t ring[KB64];                 // byte at stream position p at index p mod 64 KiB
+    uint8_t in[IN_WINDOW];              // compressed byte at source position q at index q mod 8 KiB
+};
+
+} // namespace
+
+extern "C" __global__ __launch_bounds__(64) void rh_lz4f_decode(rh_lz4_decode_job* jobs, rh_lz4_decode_state* states) {
+    extern __shared__ uint8_t lds_raw[];
+    DecodeLds& L = *reinterpret_cast<DecodeLds*>(lds_raw);
+    const uint32_t lane = threadIdx.x;
+    rh_lz4_decode_job& job = jobs[blockIdx.x];
+    rh_lz4_decode_state& S = states[job.stream];
+    g_cu8* const src = (g_cu8*)job.src;
+    g_u8* const out = (g_u8*)job.out;
+    const uint32_t src_len = __builtin_amdgcn_readfirstlane(job.src_len), n_blocks = __builtin_amdgcn_readfirstlane(job.n_blocks);
+    const uint32_t trailer = __builtin_amdgcn_readfirstlane(job.block_trailer);
+    const uint64_t out_cap = job.out_cap, before = job.decoded_before;
+    const uint32_t ring0 = (uint32_t)before & (KB64 - 1u);                // ring index of out[0]
+
+    // the stream's window so far
+    if (before != 0)
+        for (uint32_t i = lane * 16u; i < KB64; i += 64u * 16u) *reinterpret_cast<uint4*>(L.ring + i) = *reinterpret_cast<const uint4*>(S.window + i);
+    // compressed bytes arrive in halves of the input window: [loaded - 8 KiB, loaded) is held
+    uint32_t loaded = 0;
+    auto refill = [&](uint32_t cursor) {
+        while (loaded < src_len + 64u && cursor + IN_HALF > loaded) {             // (the source is readable up to a multiple of 4096)
+#pragma unroll
+            for (uint32_t k = 0; k < IN_HALF / (64u * 16u); k++) {
+                const uint32_t q = loaded + (k * 64u + lane) * 16u;
+                *reinterpret_cast<u32x4*>(L.in + (q & (IN_WINDOW - 1u))) = *(g_cu32x4*)(src + q);
+            }
+            loaded += IN_HALF;
+        }
+    };
+    auto in_byte = [&](uint32_t q) -> uint32_t { return L.in[q & (IN_WINDOW - 1u)]; };
+
+    uint32_t cursor = 0;                // source position
+    uint64_t op = 0;                    // bytes decoded by this job
+    uint64_t good = 0;                  // ... up to the end of the last block decoded completely
+    uint32_t status = RH_LZ4_DECODE_OK, blocks_done = 0;
+    refill(0);
+    __syncthreads();
+    for (uint32_t blk = 0; blk < n_blocks && status == RH_LZ4_DECODE_OK; blk++) {
+        refill(cursor);
+        const uint32_t header = __builtin_amdgcn_readfirstlane(in_byte(cursor) | (in_byte(cursor + 1u) << 8) | (in_byte(cursor + 2u) << 16) | (in_byte(cursor + 3u) << 24));
+        const uint32_t bsize = header & 0x7fffffffu;
+        cursor += 4u;
+        const uint32_t bend = cursor + bsize;
+        const uint64_t block_start = op;
+        if (bsize == 0u || bsize > src_len || bend > src_len) { status = RH_LZ4_DECODE_MALFORMED; break; }
+        if (header & BLOCK_UNCOMPRESSED_FLAG) {
+            if (bsize > KB64) { status = RH_LZ4_DECODE_MALFORMED; break; }
+            if (op + bsize > out_cap) { status = RH_LZ4_DECODE_NO_ROOM; break; }
+            for (uint32_t done = 0; done < bsize; ) {
+                refill(cursor);
+                const uint32_t piece = min(bsize - done, loaded - cursor);
+                for (uint32_t i = lane; i < piece; i += 64u) L.ring[(ring0 + (uint32_t)op + i) & (KB64 - 1u)] = (uint8_t)in_byte(cursor + i);
+                cursor += piece; done += piece; op += piece;
+            }
+        } else {
+            while (cursor < bend) {
+                refill(cursor);
+                // look-ahead: lane i holds the compressed byte at cursor + i
+                const uint32_t la = in_byte(cursor + lane);
+                const uint32_t token = (uint32_t)__builtin_amdgcn_readfirstlane((int)la);
+                uint32_t at = 1u;                                               // look-ahead lane of the next unread byte
+                uint32_t lit = token >> 4;
+                bool inside = true;                                             // everything read so far came from the look-ahead
+                if (lit == 15u) {
+                    // length bytes: 255s, then one byte below 255
+                    const unsigned long long ends = __ballot(lane >= at && la != 255u);
+                    if (ends) {
+                        const uint32_t e = (uint32_t)__builtin_ctzll(ends);
+                        lit = 15u + 255u * (e - at) + (uint32_t)__builtin_amdgcn_readlane((int)la, (int)e);
+                        at = e + 1u;
+                    } else {
+                        // longer than the look-ahead: byte by byte
+                        inside = false;
+                        uint32_t q = cursor + 1u, x;
+                        do {
+                            if (q >= bend) { status = RH_LZ4_DECODE_MALFORMED; break; }
+                            if (q + 64u > loaded) refill(q);
+                            x = (uint32_t)__builtin_amdgcn_readfirstlane((int)in_byte(q)); q++; lit += x;
+                        } while (x == 255u);
+                        if (status != RH_LZ4_DECODE_OK) break;
+                        cursor = q; at = 0u;
+                    }
+                }
+                if (inside) { if (cursor + at > bend) { status = RH_LZ4_DECODE_MALFORMED; break; } }
+                const uint32_t lit_pos = inside ? cursor + at : cursor;          // source position of the first literal
+                if (lit > bend - lit_pos) { status = RH_LZ4_DECODE_MALFORMED; break; }
+                if (op - block_start + lit > KB64) { status = RH_LZ4_DECODE_MALFORMED; break; }
+                if (op + lit > out_cap) { status = RH_LZ4_DECODE_NO_ROOM; break; }
+                const uint32_t rop = ring0 + (uint32_t)op;
+                if (inside && at + lit + 2u <= 64u) {
+                    // the literals and the offset are in the look-ahead
+                    if (lane >= at && lane < at + lit) L.ring[(rop + lane - at) & (KB64 - 1u)] = (uint8_t)la;
+                    at += lit;
+                    cursor += at; at = 0u;
+                    op += lit;
+                    if (cursor >= bend) break;                                   // last sequence of the block: literals only
+                    // (the offset bytes are the two look-ahead lanes behind the literals)
+                } else {
+                    uint32_t q = lit_pos;
+                    for (uint32_t done = 0; done < lit; ) {
+                        refill(q);
+                        const uint32_t piece = min(lit - done, loaded - q);
+                        for (uint32_t i = lane; i < piece; i += 64u) L.ring[(rop + done + i) & (KB64 - 1u)] = (uint8_t)in_byte(q + i);
+                        q += piece; done += piece;
+                    }
+                    cursor = q; op += lit;
+                    if (cursor >= bend) break;
+                    refill(cursor);
+                }
+                // offset and match length: a fresh look-ahead unless the old one still covers them
+                if (bend - cursor < 2u) { status = RH_LZ4_DECODE_MALFORMED; break; }
+                const uint32_t lb = in_byte(cursor + lane);
+                const uint32_t offset = (uint32_t)__builtin_amdgcn_readfirstlane((int)lb) | ((uint32_t)__builtin_amdgcn_readlane((int)lb, 1) << 8);
+                uint32_t ml = token & 15u, used = 2u;
+                if (ml == 15u) {
+                    const unsigned long long ends = __ballot(lane >= 2u && lb != 255u);
+                    if (ends) {
+                        const uint32_t e = (uint32_t)__builtin_ctzll(ends);
+                        ml = 15u + 255u * (e - 2u) + (uint32_t)__builtin_amdgcn_readlane((int)lb, (int)e);
+                        used = e + 1u;
+                    } else {
+                        uint32_t q = cursor + 2u, x;
+                        do {
+                            if (q >= bend) { status = RH_LZ4_DECODE_MALFORMED; break; }
+                            if (q + 64u > loaded) refill(q);
+                            x = (uint32_t)__builtin_amdgcn_readfirstlane((int)in_byte(q)); q++; ml += x;
+                        } while (x == 255u);
+                        if (status != RH_LZ4_DECODE_OK) break;
+                        used = q - cursor;
+                    }
+                }
+                ml += 4u;
+                cursor += used;
+                if (cursor > bend) { status = RH_LZ4_DECODE_MALFORMED; break; }
+                if (offset == 0u || (uint64_t)offset > before + op) { status = RH_LZ4_DECODE_BAD_OFFSET; break; }
+                if (op - block_start + ml > KB64) { status = RH_LZ4_DECODE_MALFORMED; break; }
+                if (op + ml > out_cap) { status = RH_LZ4_DECODE_NO_ROOM; break; }
+                // match copy
+                const uint32_t dst = ring0 + (uint32_t)op, from = dst - offset;
+                if (offset >= 64u) {
+                    // 64 bytes per step: their sources were written by earlier steps (LDS operations of a wave finish in order)
+                    for (uint32_t i = lane; i < ml; i += 64u) L.ring[(dst + i) & (KB64 - 1u)] = L.ring[(from + i) & (KB64 - 1u)];
+                } else {
+                    // whole periods per step: lane % offset with a multiplication (exact for lanes and offsets below 64)
+                    const uint32_t recip = (65536u + offset - 1u) / offset;
+                    const uint32_t phase = lane - ((lane * recip) >> 16) * offset;
+                    const uint32_t per_step = (64u / offset) * offset;
+                    const uint32_t v = L.ring[(from + phase) & (KB64 - 1u)];       // the period itself never changes
+                    for (uint32_t base = 0; base < ml; base += per_step)
+                        if (lane < per_step && base + lane < ml) L.ring[(dst + base + lane) & (KB64 - 1u)] = (uint8_t)v;
+                }
+                op += ml;
+            }
+            if (status != RH_LZ4_DECODE_OK) break;
+            if (cursor != bend) { status = RH_LZ4_DECODE_MALFORMED; break; }
+        }
+        cursor = bend + trailer;
+        // the block leaves for memory
+        __syncthreads();
+        {
+            const uint32_t n = (uint32_t)(op - block_start);
+            const uint32_t r = ring0 + (uint32_t)block_start;
+            g_u8* const o = out + block_start;
+            uint32_t head = (uint32_t)((16u - ((uintptr_t)o & 15u)) & 15u); if (head > n) head = n;
+            if (lane < head) o[lane] = L.ring[(r + lane) & (KB64 - 1u)];
+            const uint32_t pieces = (n - head) >> 4;
+            for (uint32_t i = lane; i < pieces; i += 64u) {
+                const uint32_t at = r + head + i * 16u;
+                u32x4 v;
+                if ((at & 15u) == 0u && ((at & (KB64 - 1u)) + 16u <= KB64)) v = *reinterpret_cast<const u32x4*>(L.ring + (at & (KB64 - 1u)));
+                else {
+                    uint32_t w[4];
+                    for (int k = 0; k < 4; k++) {
+                        const uint32_t a = at + 4u * (uint32_t)k;
+                        w[k] = (uint32_t)L.ring[a & (KB64 - 1u)] | ((uint32_t)L.ring[(a + 1u) & (KB64 - 1u)] << 8) | ((uint32_t)L.ring[(a + 2u) & (KB64 - 1u)] << 16) | ((uint32_t)L.ring[(a + 3u) & (KB64 - 1u)] << 24);
+                    }
+                    v = u32x4{w[0], w[1], w[2], w[3]};
+                }
+                *(__attribute__((address_space(1))) u32x4*)(o + head + i * 16u) = v;
+            }
+            const uint32_t done = head + pieces * 16u;
+            if (done + lane < n) o[done + lane] = L.ring[(r + done + lane) & (KB64 - 1u)];
+        }
+        blocks_done++; good = op;
+    }
+    __syncthreads();
+    // persist the window
+    for (uint32_t i = lane * 16u; i < KB64; i += 64u * 16u) *reinterpret_cast<uint4*>(S.window + i) = *reinterpret_cast<const uint4*>(L.ring + i);
+    if (lane == 0) { job.out_len = good; job.status = status; job.blocks_done = blocks_done; }
+}
+
 namespace rhk {
+
+int lz4f_decode_launch(rh_lz4_decode_job* d_jobs, uint32_t n_jobs, rh_lz4_decode_state* d_states, hipStream_t s) {
+    if (n_jobs == 0) return 0;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rh_lz4f_decode), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(DecodeLds));
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(rh_lz4f_decode, dim3(n_jobs), dim3(64), sizeof(DecodeLds), s, d_jobs, d_states);
+    return (int)hipGetLastError();
+}
 
 size_t lz4_lds_bytes() { return sizeof(Lds); }
 

@@ -46,7 +46,7 @@ def scan_directory_for_timestamps(directory):
 
 
 def lz4f_decompress(data):
-    """Decodes one LZ4 frame with the library's host decoder; a truncated tail is tolerated."""
+    """Decodes one LZ4 frame held in memory with the library's host decoder; a truncated tail is tolerated."""
     data = bytes(data)
     cap = max(1 << 16, len(data) * 4)
     L = _ffi.lib()
@@ -63,36 +63,139 @@ def lz4f_decompress(data):
         cap *= 4
 
 
-def read_packets(raw):
-    """Yields VideoFrames from a decompressed stream; stops at an unclean end (reference src/decompressor.rs:214-243)."""
-    pos = 0
+class StreamReaders:
+    """The readers of one group of stream files (reference src/decompressor.rs:197-198: a BufReadDecompressor over a
+    BufReader per file), decoded together: the files are read a piece at a time, and the complete LZ4F blocks of all of
+    them go through one decoder run (rh_decoder_*: one wavefront per stream on the device; on the host when no device
+    is given).  What a reader hands out is bounded: a stream with `high_water` decoded bytes waiting is not fed."""
+
+    FILE_PIECE = 1 << 20
+    LARGEST_BLOCK = (4 << 20) + 8       # an LZ4F block with its header and checksum at the largest block size
+
+    def __init__(self, paths, device=None, high_water=64 << 20):
+        self.files = [open(p, "rb") for p in paths]
+        self.eof = [False] * len(paths)
+        self.bytes = [bytearray() for _ in paths]       # decoded, not yet read
+        self.high_water = high_water
+        out = C.c_void_p()
+        _ffi.check(_ffi.lib().rh_decoder_create(device, len(paths), C.byref(out)))
+        self.handle = out
+
+    def close(self):
+        if self.handle is not None:
+            _ffi.lib().rh_decoder_destroy(self.handle)
+            self.handle = None
+        for f in self.files:
+            f.close()
+
+    def _info(self, i):
+        state, buffered, ready = C.c_int(), C.c_size_t(), C.c_size_t()
+        _ffi.check(_ffi.lib().rh_decoder_stream_info(self.handle, i, C.byref(state), C.byref(buffered), C.byref(ready)))
+        return state.value, buffered.value, ready.value
+
+    def _pump(self, wanted):
+        """One decoder run over every stream that can use one; returns False when stream `wanted` cannot get any further."""
+        L = _ffi.lib()
+        fed = False
+        for i, f in enumerate(self.files):
+            state, buffered, _ = self._info(i)
+            if state != 0 or self.eof[i] or buffered >= max(2 * self.FILE_PIECE, self.LARGEST_BLOCK):
+                continue              # (enough fed for the next run: at least one whole block, whatever the piece size)
+            if i != wanted and len(self.bytes[i]) >= self.high_water:
+                continue
+            piece = f.read(self.FILE_PIECE)
+            if not piece:
+                self.eof[i] = True
+                continue
+            _ffi.check(L.rh_decoder_feed(self.handle, i, piece, len(piece)))
+            fed = fed or i == wanted
+        before = self._info(wanted)[1]
+        _ffi.check(L.rh_decoder_run(self.handle))
+        progressed = False
+        for i in range(len(self.files)):
+            if i != wanted and len(self.bytes[i]) >= self.high_water:
+                continue                                    # (its decoded bytes stay with the decoder for now)
+            while True:
+                ptr, n = C.c_void_p(), C.c_size_t()
+                _ffi.check(L.rh_decoder_peek(self.handle, i, C.byref(ptr), C.byref(n)))
+                if not n.value:
+                    break
+                self.bytes[i] += C.string_at(ptr.value, n.value)
+                _ffi.check(L.rh_decoder_consume(self.handle, i, n.value))
+                if i == wanted:
+                    progressed = True
+        if progressed:
+            return True
+        state, after, _ = self._info(wanted)
+        # without new decoded bytes the stream can still get further if it runs and new bytes arrived or the run took some in
+        return state == 0 and (fed or after != before)
+
+    def read_exact(self, i, n):
+        """n decoded bytes of stream i, or None when the stream ends before (Read::read_exact failing)."""
+        buf = self.bytes[i]
+        while len(buf) < n:
+            if not self._pump(i):
+                if len(buf) >= n:
+                    break
+                return None
+        out = bytes(buf[:n])
+        del buf[:n]
+        return out
+
+
+def read_packets(read_exact):
+    """Yields VideoFrames from a decoded stream, `read_exact(n)` returning n bytes or None at the end; stops at an
+    unclean end (reference src/decompressor.rs:214-243)."""
     while True:
-        if len(raw) - pos < U64_LEN:
+        head = read_exact(U64_LEN)
+        if head is None:
             return
-        packet_len = int.from_bytes(raw[pos:pos + 8], "big"); pos += 8
-        if len(raw) - pos < U64_LEN:
+        packet_len = int.from_bytes(head, "big")
+        head = read_exact(U64_LEN)
+        if head is None:
             return
-        video_frame_len = int.from_bytes(raw[pos:pos + 8], "big"); pos += 8
-        if len(raw) - pos < video_frame_len:
+        video_frame_len = int.from_bytes(head, "big")
+        if video_frame_len > (1 << 20):                     # (a bincode VideoFrame takes tens of bytes)
+            return
+        meta = read_exact(video_frame_len)
+        if meta is None:
             return
         try:
-            video_frame, _ = VideoFrame.decode(raw[pos:pos + video_frame_len])
+            video_frame, _ = VideoFrame.decode(meta)
         except (ValueError, IndexError):
             return
-        pos += video_frame_len
         if video_frame.image_data is not None:
             remainder_len = packet_len - U64_LEN - U64_LEN - video_frame_len
-            if len(raw) - pos < remainder_len:
+            if remainder_len < 0:
                 return
-            video_frame.image_data = ImageData.Bytes(raw[pos:pos + remainder_len])
-            pos += remainder_len
+            image = read_exact(remainder_len)
+            if image is None:
+                return
+            video_frame.image_data = ImageData.Bytes(image)
         yield video_frame
 
 
+def packets_of_bytes(raw):
+    """read_packets over bytes held in memory."""
+    pos = [0]
+
+    def read_exact(n):
+        if len(raw) - pos[0] < n:
+            return None
+        out = raw[pos[0]:pos[0] + n]
+        pos[0] += n
+        return out
+
+    return read_packets(read_exact)
+
+
 class Decompressor:
-    def __init__(self, directory, remove_files_after_decompression):
+    def __init__(self, directory, remove_files_after_decompression, renderer=None):
+        """renderer: the Renderer whose device decodes the LZ4F blocks of all the files together; None: the library's host
+        decoder does (the reference decodes on one CPU thread per file)."""
         self.directory = directory
         self.remove_files_after_decompression = remove_files_after_decompression
+        self.device = renderer.device if renderer is not None else None
 
     @staticmethod
     def can_run(directory):
@@ -104,8 +207,12 @@ class Decompressor:
         ordered = scan_directory_for_timestamps(self.directory)
         for timestamp, filenames in ordered.items():
             filenames.sort()
-            workers = [self._worker(f, per_thread_function, timestamp) for f in filenames]
-            order_frames_from_workers(workers, in_order_function, timestamp)
+            readers = StreamReaders([os.path.join(self.directory, f) for f in filenames], self.device)
+            try:
+                workers = [self._worker(readers, i, per_thread_function, timestamp) for i in range(len(filenames))]
+                order_frames_from_workers(workers, in_order_function, timestamp)
+            finally:
+                readers.close()
         # files are removed only after everything succeeded (reference src/decompressor.rs:43-50)
         if self.remove_files_after_decompression:
             for filenames in ordered.values():
@@ -115,11 +222,8 @@ class Decompressor:
                     except OSError:
                         pass
 
-    def _worker(self, filename, per_thread_function, timestamp):
-        with open(os.path.join(self.directory, filename), "rb") as f:
-            data = f.read()
-        raw, _complete = lz4f_decompress(data)
-        for video_frame in read_packets(raw):
+    def _worker(self, readers, i, per_thread_function, timestamp):
+        for video_frame in read_packets(lambda n: readers.read_exact(i, n)):
             yield video_frame, per_thread_function(video_frame, timestamp)
 
 

@@ -55,7 +55,7 @@ def test_filename_grammar():
 
 
 def test_host_decoder_and_packet_reader(oracle, tmp_path):
-    from renderer_amd.decompressor import lz4f_decompress, read_packets
+    from renderer_amd.decompressor import lz4f_decompress, packets_of_bytes as read_packets
     frames = [make_frame(1), make_frame(2, dropped=True), make_frame(3, w=100, h=3)]
     path = tmp_path / "s.sz"
     write_sz(path, frames, oracle)
@@ -122,3 +122,86 @@ def test_ffmpeg_pipe_command_line_and_duplication(tmp_path, monkeypatch, capfd):
                     "-c:v", "libx264", "-r", "60", str(tmp_path / "recorded.mp4")]
     assert open(tmp_path / "out.stdin", "rb").read() == b"PNG1PNG1PNG3"
     assert "Duplicating previous frame" in capfd.readouterr().err
+
+
+def noisy_frame(number, w, h, seed):
+    """A frame whose image compresses into many kinds of sequences: flat runs, a repeating row, noise."""
+    f = make_frame(number, w=w, h=h)
+    rng = np.random.default_rng(seed)
+    rows = np.frombuffer(f.image_data.bytes(), dtype=np.uint8).reshape(h, f.padded_bytes_per_row).copy()
+    rows[h // 4: h // 2] = rng.integers(0, 255, rows[h // 4: h // 2].shape, dtype=np.uint8)       # incompressible: stored blocks
+    rows[h // 2:] = rows[h // 2]                                                                # far matches, one row apart
+    rows[: h // 4, ::3] = 7                                                                     # short overlapping matches
+    from renderer_amd import ImageData
+    f.image_data = ImageData.Bytes(rows.tobytes())
+    return f
+
+
+def decode_with(device, path_frames, tmp_path, oracle, cut=None, piece=None):
+    """Writes stream files with liblz4, reads them back through StreamReaders; returns the frames per stream."""
+    from renderer_amd.decompressor import StreamReaders, read_packets
+    paths = []
+    for i, frames in enumerate(path_frames):
+        path = tmp_path / f"s{i}.sz"
+        write_sz(path, frames, oracle)
+        if cut is not None and i == 0:
+            data = open(path, "rb").read()
+            open(path, "wb").write(data[:-cut])
+        paths.append(str(path))
+    readers = StreamReaders(paths, device)
+    if piece:
+        readers.FILE_PIECE = piece
+    try:
+        # interleaved, one frame at a time, the way the re-ordering loop pulls
+        workers = [read_packets(lambda n, i=i: readers.read_exact(i, n)) for i in range(len(paths))]
+        got = [[] for _ in paths]
+        live = list(range(len(paths)))
+        while live:
+            for i in list(live):
+                f = next(workers[i], None)
+                if f is None:
+                    live.remove(i)
+                else:
+                    got[i].append(f)
+        return got
+    finally:
+        readers.close()
+
+
+def check_streams(got, want):
+    for g, w in zip(got, want):
+        assert [f.frame_number for f in g] == [f.frame_number for f in w]
+        for a, b in zip(g, w):
+            assert (a.image_data is None) == (b.image_data is None)
+            if b.image_data is not None:
+                assert a.image_data.bytes() == b.image_data.bytes(), f"frame {b.frame_number}"
+
+
+def test_stream_readers_on_the_host(oracle, tmp_path):
+    """Several stream files decoded together, a piece of each file at a time: frames of many blocks (history across
+    blocks and across decoder runs), stored blocks, dropped frames, tiny pieces."""
+    streams = [[noisy_frame(1, 500, 300, 1), make_frame(4, dropped=True), noisy_frame(7, 640, 700, 2)],
+               [noisy_frame(2, 64, 64, 3), noisy_frame(5, 1000, 900, 4)],
+               [make_frame(3), make_frame(6, w=100, h=3)]]
+    check_streams(decode_with(None, streams, tmp_path, oracle), streams)
+    check_streams(decode_with(None, streams, tmp_path, oracle, piece=777), streams)
+
+
+def test_stream_readers_stop_at_a_truncated_tail(oracle, tmp_path):
+    """A file cut in the middle of a block gives the packets that are complete in the blocks before the cut (reference
+    src/decompressor.rs:216-235: read_exact fails, the worker ends); the other files are not affected."""
+    streams = [[noisy_frame(1, 300, 200, 5), noisy_frame(3, 300, 200, 6)], [noisy_frame(2, 300, 200, 7)]]
+    got = decode_with(None, streams, tmp_path, oracle, cut=5000)
+    assert [f.frame_number for f in got[0]] == [1]
+    check_streams([got[0], got[1]], [streams[0][:1], streams[1]])
+
+
+def test_stream_readers_reject_garbage(tmp_path):
+    from renderer_amd.decompressor import StreamReaders
+    path = tmp_path / "g.sz"
+    open(path, "wb").write(b"not an lz4 frame at all, just bytes" * 10)
+    readers = StreamReaders([str(path)])
+    try:
+        assert readers.read_exact(0, 8) is None
+    finally:
+        readers.close()

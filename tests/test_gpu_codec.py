@@ -161,7 +161,7 @@ def test_record_compress_decompress_roundtrip(oracle, tmp_path):
     def in_order(video_frame, result, timestamp):
         seen.append((video_frame, result))
 
-    Decompressor(str(tmp_path), True).decompress_from_disk(lambda f, ts: PngEncoder.encode_to_bytes(f), in_order)
+    Decompressor(str(tmp_path), True, renderer=r).decompress_from_disk(lambda f, ts: PngEncoder.encode_to_bytes(f), in_order)
     assert [f.frame_number for f, _ in seen] == list(range(1, n_frames + 1))
     vw = hs.viewport
     x0, y0 = int(np.ceil(vw.margin_x)), int(np.ceil(vw.margin_y))
@@ -215,6 +215,58 @@ def test_4k_recording_under_the_500_mb_budget_drops_nothing(oracle, tmp_path):
     assert budget.load() == 0                   # every frame gave its bytes back
     assert sum(os.path.getsize(os.path.join(tmp_path, f)) for f in os.listdir(tmp_path)) > 0
     hs.close(); r.close()
+
+
+def test_device_decoder_against_liblz4_streams(oracle, tmp_path):
+    """Stream files written by liblz4 (the library the reference links), decoded on the device, all streams in the same
+    launches: frames of many blocks (history across blocks and across launches), stored blocks, short overlapping
+    matches, dropped frames; the same bytes as the host decoder gives.  Then with file pieces of 777 bytes."""
+    import test_capture_cpu as cc
+    from renderer_amd import Renderer
+    r = Renderer(64, 64)
+    try:
+        streams = [[cc.noisy_frame(1, 500, 300, 1), cc.make_frame(4, dropped=True), cc.noisy_frame(7, 1920, 1080, 2)],
+                   [cc.noisy_frame(2, 64, 64, 3), cc.noisy_frame(5, 1000, 900, 4)],
+                   [cc.make_frame(3), cc.make_frame(6, w=100, h=3)],
+                   [cc.noisy_frame(8 + k, 320, 200, 10 + k) for k in range(5)]]
+        cc.check_streams(cc.decode_with(r.device, streams, tmp_path, oracle), streams)
+        cc.check_streams(cc.decode_with(r.device, streams[:3], tmp_path, oracle, piece=777), streams[:3])
+    finally:
+        r.close()
+
+
+def test_device_decoder_stops_at_a_truncated_tail_and_at_malformed_blocks(oracle, tmp_path):
+    """A file cut inside a block ends at its last complete block (reference src/decompressor.rs:216-235); a block whose
+    bytes are damaged ends its stream without touching the others, whatever the damage claims (lengths and offsets are
+    checked against the block and the decoded data before anything is copied)."""
+    import test_capture_cpu as cc
+    from renderer_amd import Renderer
+    from renderer_amd.decompressor import StreamReaders, read_packets
+    r = Renderer(64, 64)
+    try:
+        streams = [[cc.noisy_frame(1, 300, 200, 5), cc.noisy_frame(3, 300, 200, 6)], [cc.noisy_frame(2, 300, 200, 7)]]
+        got = cc.decode_with(r.device, streams, tmp_path, oracle, cut=5000)
+        assert [f.frame_number for f in got[0]] == [1]
+        cc.check_streams(got, [streams[0][:1], streams[1]])
+        # damage: every position of a small stream in turn overwritten with 0xff (long lengths, far offsets, bad headers)
+        good = tmp_path / "good.sz"
+        cc.write_sz(good, [cc.noisy_frame(9, 40, 30, 8)], oracle)
+        data = bytearray(open(good, "rb").read())
+        rng = np.random.default_rng(9)
+        for at in sorted(set(rng.integers(7, len(data) - 4, 60).tolist())):
+            bad = bytearray(data)
+            bad[at] = 0xff
+            p = tmp_path / "bad.sz"
+            open(p, "wb").write(bad)
+            readers = StreamReaders([str(p), str(good)], r.device)
+            try:
+                damaged = list(read_packets(lambda n: readers.read_exact(0, n)))
+                intact = list(read_packets(lambda n: readers.read_exact(1, n)))
+            finally:
+                readers.close()
+            assert len(damaged) <= 1 and [f.frame_number for f in intact] == [9]
+    finally:
+        r.close()
 
 
 def png_idat_stream(png):

@@ -76,21 +76,42 @@ def gather_bytes(payload, dst=0, device="cpu", group=None):
     return out
 
 
-def all_gather_strips(strip, height, device="cpu", group=None):
-    """All-gathers the row strips of a target (uint8 tensor [rows, width, 4] per rank, rows = strip_for_rank) into the
-    full image on every rank, for a later pass that samples the whole target."""
-    import torch
+def all_gather_strips_in_place(image, group=None, collective=None):
+    """Every rank holds its own strip (strip_for_rank) of `image`, a contiguous uint8 tensor [height, width, 4]; on return
+    every rank holds the whole image.  Row strips of a contiguous image are contiguous in memory, so the collective works
+    on the image itself and nothing is staged: strips of equal size are one all_gather_into_tensor whose input is the
+    rank's slice of the output; otherwise every rank posts one send of its slice and one receive into each peer's slice
+    (a grouped point-to-point exchange; RCCL runs the group as one launch).  `collective`: None picks the all-gather for
+    equal strips unless the backend is gloo, whose all-gather stages a copy of the whole image inside the library while
+    its sends and receives work on the caller's memory; True / False force one form (equal strips only for True)."""
     import torch.distributed as dist
-    world = dist.get_world_size(group)
-    width = strip.shape[1]
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if world == 1:
+        return
+    if not image.is_contiguous():
+        raise ValueError("all_gather_strips_in_place: the image must be contiguous")
+    height = image.shape[0]
     rows = [strip_for_rank(height, r, world) for r in range(world)]
-    max_rows = max(r1 - r0 for r0, r1 in rows)
-    via = comm_device(device, group)
-    padded = torch.zeros((max_rows, width, 4), dtype=torch.uint8, device=via)
-    padded[:strip.shape[0]] = strip.to(via)
-    parts = [torch.empty_like(padded) for _ in range(world)]
-    dist.all_gather(parts, padded, group=group)
-    return torch.cat([parts[r][:rows[r][1] - rows[r][0]] for r in range(world)], dim=0).to(device)
+    r0, r1 = rows[rank]
+    equal = all(b - a == r1 - r0 for a, b in rows)
+    if collective is None:
+        collective = equal and dist.get_backend(group) != "gloo"
+    if collective:
+        if not equal:
+            raise ValueError("all_gather_strips_in_place: the all-gather form needs strips of equal size")
+        dist.all_gather_into_tensor(image.view(-1), image[r0:r1].view(-1), group=group)
+        return
+    ops = []
+    for peer in range(world):
+        if peer == rank:
+            continue
+        p0, p1 = rows[peer]
+        if r1 > r0:
+            ops.append(dist.P2POp(dist.isend, image[r0:r1], peer, group))
+        if p1 > p0:
+            ops.append(dist.P2POp(dist.irecv, image[p0:p1], peer, group))
+    for work in dist.batch_isend_irecv(ops) if ops else []:
+        work.wait()
 
 
 class _DeviceArray:
@@ -112,17 +133,20 @@ def texture_as_tensor(texture, device):
 
 def exchange_strips(renderer, texture, rank, world, device, group=None):
     """After every rank has rendered its strip of `texture` (Renderer.set_strip(*strip_for_rank(...))), makes the whole
-    image present on every rank: the strips are all-gathered (RCCL over xGMI between GPUs) straight out of and into the
-    texture's device memory, so that a following pass can sample the complete target."""
-    import torch.distributed as dist
+    image present on every rank, so that a following pass can sample the complete target: the strips are all-gathered in
+    place, out of and into the texture's device memory (RCCL over xGMI between GPUs).  With gloo, which takes no device
+    tensors (rehearsals of the multi-process path on one GPU), the image goes through host memory."""
+    import torch
     renderer.synchronize()                       # the strip is rendered on the renderer's own HIP stream
     if world == 1:
         return
     image = texture_as_tensor(texture, device)
-    height = image.shape[0]
-    r0, r1 = strip_for_rank(height, rank, world)
-    full = all_gather_strips(image[r0:r1], height, device=device, group=group)
-    image.copy_(full)
-    import torch
+    if comm_device(device, group) == "cpu":
+        r0, r1 = strip_for_rank(image.shape[0], rank, world)
+        host = torch.empty(image.shape, dtype=torch.uint8)
+        host[r0:r1] = image[r0:r1].cpu()
+        all_gather_strips_in_place(host, group=group)
+        image.copy_(host)
+    else:
+        all_gather_strips_in_place(image, group=group)
     torch.cuda.synchronize()
-    del dist

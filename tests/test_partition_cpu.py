@@ -63,11 +63,35 @@ def _worker(rank, world, port, out_dir):
             assert sorted(frames) == list(range(1, n_frames + 1))
             assert all(frames[f] == bytes([f]) * (f * 3) for f in frames)
         # sort-first strips: the all-gathered image equals the reference image on every rank
-        H, W = 100, 5
-        full = (np.arange(H * W * 4) % 251).astype(np.uint8).reshape(H, W, 4)
-        r0, r1 = partition.strip_for_rank(H, rank, world)
-        image = partition.all_gather_strips(torch.from_numpy(full[r0:r1].copy()), H)
-        assert np.array_equal(image.numpy(), full)
+        # (100 rows: strips of 64 and 36 rows, the point-to-point form; 128 rows: equal strips, one all-gather)
+        for H, W in ((100, 5), (128, 7)):
+            full = (np.arange(H * W * 4) % 251).astype(np.uint8).reshape(H, W, 4)
+            r0, r1 = partition.strip_for_rank(H, rank, world)
+            image = torch.zeros((H, W, 4), dtype=torch.uint8)
+            image[r0:r1] = torch.from_numpy(full[r0:r1].copy())
+            partition.all_gather_strips_in_place(image)
+            assert np.array_equal(image.numpy(), full)
+            if H == 128:                                # the form RCCL takes for equal strips, on gloo
+                image[:r0] = 0; image[r1:] = 0
+                partition.all_gather_strips_in_place(image, collective=True)
+                assert np.array_equal(image.numpy(), full)
+        # in place: at the size of a 16384^2 target's strips the exchange needs no second copy of a strip
+        import resource
+        for H in (4096, 4096 + 32):                     # equal strips; unequal strips
+            W = 8192                                    # 128 MiB image, 64 MiB strips
+            image = torch.zeros((H, W, 4), dtype=torch.uint8)
+            r0, r1 = partition.strip_for_rank(H, rank, world)
+            image[r0:r1] = rank + 1
+            image[:] += 0                               # every page touched before the measurement
+            dist.barrier()
+            before = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+            partition.all_gather_strips_in_place(image)
+            grown = (resource.getrusage(resource.RUSAGE_SELF).ru_maxrss - before) * 1024
+            strip_bytes = min(b - a for a, b in (partition.strip_for_rank(H, r, world) for r in range(world))) * W * 4
+            o0, o1 = partition.strip_for_rank(H, 1 - rank, world)
+            assert int(image[o0:o1].min()) == int(image[o0:o1].max()) == 2 - rank
+            assert grown < strip_bytes, f"the exchange grew the process by {grown} bytes; a strip has {strip_bytes}"
+            del image
         open(os.path.join(out_dir, f"ok{rank}"), "w").close()
     finally:
         dist.destroy_process_group()

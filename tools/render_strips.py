@@ -55,15 +55,8 @@ def render_two_pass(size, quads, side, rank=0, world=1, local_rank=0, device="cp
     r.render(p2, clear, None, (1, 4))                         # pass 2, this rank's strip of B
     r.finish_frame()
     r.synchronize()
-    image = None
-    if world == 1:
-        image = b_tex.read()
-    else:
-        import torch
-        b_all = partition.all_gather_strips(partition.texture_as_tensor(b_tex, device)[row0:row1], S, device=device)
-        torch.cuda.synchronize()
-        if rank == 0:
-            image = b_all.cpu().numpy()
+    partition.exchange_strips(r, b_tex, rank, world, device)  # the strips of B meet in place as well
+    image = b_tex.read() if rank == 0 else None
     seconds = time.perf_counter() - t0
     r.set_strip(0, 0)
     h1.close(); r.close()
@@ -97,7 +90,7 @@ def main():
         device = f"cuda:{local_rank}"
     image, seconds = render_two_pass(args.size, args.quads, args.side, rank, world, local_rank, device)
     if rank == 0:
-        print(f"two-pass {args.size}x{args.size} on {world} GPU(s): {seconds * 1e3:.1f} ms (strips, all-gather of A, gather of B included)")
+        print(f"two-pass {args.size}x{args.size} on {world} GPU(s): {seconds * 1e3:.1f} ms (strips and the all-gathers of A and B included)")
         if args.out:
             from PIL import Image
             Image.fromarray(image, "RGBA").save(args.out)

@@ -50,6 +50,7 @@ struct Texture2D {
     // Footprint copies regrouped by phase (rh_slot_dev::poly), when the kernel body was built for them: the copy picked for
     // the primitive being shaded (PolyCopy, prepared once per primitive by the tile kernel), else null.
     const uint8_t* poly_base; float poly_S, poly_invS, poly_WS;
+    uint32_t static_poly;       // 1: the kernel body was built for textures that all have footprint copies: poly_base is set
 
     // Texel (x, y) of `layer` (generic path, any supported format): 8-bit channels on the 0..255 scale, float channels
     // as they are (a half converts to float exactly).
@@ -97,7 +98,7 @@ struct Texture2D {
         if (static_rgba8 || ((format == FORMAT_RGBA_U8 || format == FORMAT_BGRA_U8) && W >= 2 && H >= 2)) {
             // 4-byte texels: the taps of a row are adjacent and the rows are one pitch apart: two 8-byte loads
             uint32_t t00, t10, t01, t11;
-            if (static_rgba8 && poly_base) {
+            if (static_rgba8 && static_poly) {
                 const float Sf = poly_S, invS = poly_invS, WSf = poly_WS;
                 const float xqf = floorf(ibf * invS), phf = __builtin_fmaf(xqf, -Sf, ibf);        // x = xq * S + ph, exact
                 const float permf = __builtin_fmaf(phf, WSf, xqf);
@@ -145,7 +146,6 @@ struct PolyCopy {
     const uint8_t* base = nullptr; float S = 1.0f, invS = 1.0f, WS = 0.0f;
     // grad_log2 = floor(log2(1.41 * |d coordinate / dx| per pixel)); scalar integer work only (everything is uniform)
     RH_DEVICE void pick(const rh_slot_dev& slot, int grad_log2) {
-        if (!slot.poly) { base = nullptr; return; }
         int k = grad_log2 + (31 - __builtin_clz(slot.width | 1u));
         k = k < 0 ? 0 : (k > RH_POLY_COPIES - 1 ? RH_POLY_COPIES - 1 : k);
         base = reinterpret_cast<const uint8_t*>(slot.poly) + (size_t)((uint32_t)k * slot.size_bytes);    // size_bytes of a texture slot: bytes of one copy
@@ -168,7 +168,7 @@ struct BindingContext {
         const rh_slot_dev& s = p->slots[set * 4 + binding];
         const PolyCopy& c = poly[set * 4 + binding];
         return Texture2D{ reinterpret_cast<const uint8_t*>(s.ptr), s.width, s.height, s.layers, s.format, static_rgba8,
-                          static_poly ? c.base : nullptr, c.S, c.invS, c.WS };
+                          c.base, c.S, c.invS, c.WS, static_poly };
     }
     RH_DEVICE Sampler sampler(uint32_t set, uint32_t binding) const {
         return Sampler{ p->slots[set * 4 + binding].filter, static_filter };

@@ -8,7 +8,7 @@ librenderer_hip.so.  Inputs (instance buffer, attributes, texture) are resident 
 N > 1 (launched by torch.distributed.run, one rank per GPU): the path shards by frame -- every rank renders its own
 frames with no data-path collective -- so the job value is the sum over ranks ("weak" scaling).
 
-After the quads/s leg the same process measures the second half of the metric, recorded frames/s: 128 frames of
+After the quads/s leg the same process measures the second half of the metric, recorded frames/s: frames of
 BASELINE.json configs[4]'s scene (100,000 animated 32x32 quads at 4K, recording attachment) are rendered, captured on
 the device and LZ4F-compressed there into stream files; the result is the "capture" object of the same JSON line.
 
@@ -45,15 +45,19 @@ def pmc_traffic_bytes(tag="c1"):
 
 
 def capture_plan(n_ranks, dist, local_rank):
-    """(frames, streams, untimed warm-up rounds) per GPU for the recorded-frames/s leg.  The frames of the leg's scene
-    hardly compress (about 28 MB each), every rank writes its stream files to the host's /tmp and pins up to two
-    host buffers of one round's bytes: the largest plan is taken that leaves half of the free disk space and of the
-    available memory untouched with all ranks of the host running it; the ranks settle on the most careful choice."""
+    """(frames, streams, untimed warm-up rounds, directory) per GPU for the recorded-frames/s leg.  The frames of the leg's
+    scene hardly compress (about 28 MB each) and a GPU fills its stream files at more than 10 GB/s, which no disk of the
+    box takes: the files go to /dev/shm (memory) when it exists, else to /tmp.  Every rank also pins up to two host
+    buffers of one round's bytes.  The largest plan is taken that leaves half of the available memory (and of the free
+    disk space, if the files go there) untouched with all ranks of the host running it; the ranks settle on the most
+    careful choice.  (1024 streams: four wavefronts per CU, one per SIMD.)"""
     import shutil
-    plans = [(512, 256, 2), (256, 256, 1), (128, 128, 1)]
+    plans = [(2048, 1024, 1), (1024, 512, 1), (512, 256, 2), (256, 256, 1), (128, 128, 1)]
     frame_bytes = 30e6
+    in_memory = os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK)
+    root = "/dev/shm" if in_memory else "/tmp"
     try:
-        disk = shutil.disk_usage("/tmp").free
+        disk = shutil.disk_usage(root).free
     except OSError:
         disk = 0
     try:
@@ -63,9 +67,9 @@ def capture_plan(n_ranks, dist, local_rank):
         ram = 64e9
     choice = len(plans) - 1
     for i, (frames, streams, rounds) in enumerate(plans):
-        on_disk = n_ranks * max(frames, rounds * streams) * frame_bytes           # warm-up bytes are dropped before the timed frames
+        files = n_ranks * max(frames, rounds * streams) * frame_bytes             # warm-up bytes are dropped before the timed frames
         pinned = n_ranks * 2 * streams * frame_bytes * 1.25
-        if on_disk <= 0.5 * disk and pinned <= 0.5 * ram:
+        if files <= 0.5 * disk and pinned + (files if in_memory else 0) <= 0.5 * ram:
             choice = i
             break
     if dist is not None:
@@ -73,7 +77,7 @@ def capture_plan(n_ranks, dist, local_rank):
         t = torch.tensor([choice], dtype=torch.int64, device=f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         choice = int(t.item())
-    return plans[choice]
+    return plans[choice] + (root,)
 
 
 def main():
@@ -98,11 +102,11 @@ def main():
     ap.add_argument("--filter", choices=["linear", "nearest"], default="linear", help="experiment: sampler filter (headline: linear)")
     ap.add_argument("--capture-frames", type=int, default=-1,
                     help="frames of the recorded-frames/s leg (BASELINE.json configs[4] shape, per GPU); 0 skips it; "
-                         "default: 512 frames into 256 streams, or less when the ranks of this host would not find "
-                         "room for their stream files in /tmp or for their pinned buffers in memory (see capture_plan)")
+                         "default: 2048 frames into 1024 streams, or less when the ranks of this host would not find "
+                         "room for their stream files and their pinned buffers in memory (see capture_plan)")
     ap.add_argument("--capture-streams", type=int, default=-1,
-                    help="stream files per GPU; default 256 (the LZ4 kernel holds one stream per compute unit at a time: "
-                         "a round of up to 256 streams takes as long as a round of one)")
+                    help="stream files per GPU; default 1024 (one wavefront per stream: four per compute unit; a round of up "
+                         "to 1024 streams takes about as long as a round of one)")
     args = ap.parse_args()
 
     capture_auto = args.capture_frames < 0 and args.capture_streams < 0      # sized below, once the ranks can agree
@@ -186,8 +190,9 @@ def main():
     # Second half of the metric: recorded frames/s.  Every rank renders, records and GPU-compresses its own frames into
     # its own stream files (frame-parallel, no data-path collective); the job value is the sum over ranks.
     capture = None
+    capture_root = "/tmp"
     if capture_auto:
-        args.capture_frames, args.capture_streams, capture_warm_rounds = capture_plan(n_gpus, dist, local_rank)
+        args.capture_frames, args.capture_streams, capture_warm_rounds, capture_root = capture_plan(n_gpus, dist, local_rank)
     elif args.capture_streams < 0:
         args.capture_streams = 256
     elif args.capture_frames < 0:
@@ -197,7 +202,7 @@ def main():
         cap_s, cap_info, cap_error = float("inf"), None, None
         try:
             cap_s, cap_info, cap_last = bench_capture.run_capture(
-                frames=args.capture_frames, streams=args.capture_streams, out=f"/tmp/rh_bench_capture_{os.getpid()}_{rank}",
+                frames=args.capture_frames, streams=args.capture_streams, out=f"{capture_root}/rh_bench_capture_{os.getpid()}_{rank}",
                 hip_ordinal=local_rank, seed=4 + rank,
                 # untimed rounds first: the compressor pins its host buffers in them
                 warmup=capture_warm_rounds * args.capture_streams)
@@ -216,7 +221,8 @@ def main():
                        "frames_per_gpu": args.capture_frames, "streams_per_gpu": args.capture_streams,
                        "ms_per_frame_per_gpu": cap_s / args.capture_frames * 1e3, "workload": cap_info["workload"],
                        "raw_MB_per_frame": cap_info["raw_MB_per_frame"], "compressed_MB_per_frame": cap_info["compressed_MB_per_frame"],
-                       "frames_dropped": cap_info["frames_dropped"], "budget_MB": cap_info["budget_MB"]}
+                       "frames_dropped": cap_info["frames_dropped"], "budget_MB": cap_info["budget_MB"],
+                       "stream_files_in": capture_root}
             # rh_lz4f_compress against the HBM roofline: the bytes it must read and write (raw frames in, LZ4F streams
             # out) over the HIP-event time of its launches (this rank's)
             k = cap_info["kernel"]
@@ -226,7 +232,8 @@ def main():
                                        "frac": achieved / HBM_PEAK_GBS, "traffic": None, "launches": k["rounds"],
                                        "algorithmic_bytes_per_launch": (k["bytes_in"] + k["bytes_out"]) / max(1, k["rounds"]),
                                        "kernel_ms_per_launch": k["kernel_ms"] / max(1, k["rounds"]),
-                                       "note": "latency-bound: one wavefront per stream walks LZ4's sequential match search"}
+                                       "note": "latency-bound: one wavefront per stream walks LZ4's sequential match search; "
+                                               "the launches share the GPU with the rendering of the next round's frames"}
             if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
                 _, multi = bench_capture.liblz4_baseline(np.ascontiguousarray(cap_last).tobytes(), cpu_frames=4)
                 capture["cpu_baseline"] = multi

@@ -265,6 +265,10 @@ int rh_compressor_write_packet(rh_compressor* c, uint32_t stream, const void* me
  * caller goes on rendering, and writes the ready bytes to the stream files meanwhile. */
 int rh_compressor_submit(rh_compressor* c);
 /* Compresses everything queued and waits: afterwards every byte is ready. */
+/* Waits for the round that rh_compressor_submit started: its compressed bytes are on their way to the host when this
+ * returns (what is still queued stays queued).  For callers that would rather have the GPU to themselves while they
+ * render the next round's frames than share it with the compression kernel. */
+int rh_compressor_wait(rh_compressor* c);
 int rh_compressor_flush(rh_compressor* c);
 /* Bytes of `stream` ready to be read (the 7-byte frame header precedes the first block). */
 size_t rh_compressor_pending(rh_compressor* c, uint32_t stream);

@@ -131,6 +131,7 @@ SIGNATURES = {
     "rh_compressor_write_packet": (C.c_int, [_P, C.c_uint32, _P, C.c_size_t, _P]),
     "rh_compressor_submit": (C.c_int, [_P]),
     "rh_compressor_flush": (C.c_int, [_P]),
+    "rh_compressor_wait": (C.c_int, [_P]),
     "rh_compressor_peek": (C.c_int, [_P, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "rh_compressor_consume": (C.c_int, [_P, C.c_uint32, C.c_size_t]),
     "rh_compressor_pending": (C.c_size_t, [_P, C.c_uint32]),

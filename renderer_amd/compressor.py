@@ -23,11 +23,14 @@ def generate_timestamp(now=None):
 
 class Compressor:
     def __init__(self, renderer, directory, max_frames_queued=None, lz4_compression_level=0, print_stats=False,
-                 n_streams=64, timestamp=None, max_buffer_size_in_megabytes=None):
+                 n_streams=64, timestamp=None, max_buffer_size_in_megabytes=None, wait_for_rounds=False):
         if lz4_compression_level > CLEVEL_MAX:
             raise AssertionError(f"Please choose a compression level in the range 0..={CLEVEL_MAX}")
         os.makedirs(directory, exist_ok=True)
         self.directory = directory
+        # wait_for_rounds: a hand-off returns when its round has been compressed, so that rendering and compression take
+        # turns on the GPU instead of sharing it (the file writes still go on beside the rendering)
+        self.wait_for_rounds = wait_for_rounds
         self.timestamp = timestamp or generate_timestamp()
         self.n_streams = n_streams
         # packets are compressed when every stream has one queued, or when this many frames wait
@@ -91,6 +94,10 @@ class Compressor:
         _ffi.check(_ffi.lib().rh_compressor_submit(self.handle))    # waits for the round in flight, then starts the queued one
         self._release(self.in_flight)   # compressed: the reference's worker drops a frame once it has written it
         self.in_flight, self.queued = self.queued, []
+        if self.wait_for_rounds:
+            _ffi.check(_ffi.lib().rh_compressor_wait(self.handle))
+            self._release(self.in_flight)
+            self.in_flight = []
         # The file writes go to a background thread: until the next hand-off this thread only queues packets
         # (rh_compressor_write_packet), which touches none of the state that peek/consume use.
         if self._background is None:

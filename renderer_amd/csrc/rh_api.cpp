@@ -190,7 +190,8 @@ void device_release(rh_device* dev);
 int device_alloc(rh_device* dev, size_t size, void** out) {
     auto it = dev->free_device.find(size);
     if (it != dev->free_device.end()) { *out = it->second; dev->free_device.erase(it); dev->free_device_bytes -= size; return 0; }
-    RH_HIP(hipMalloc(out, size ? size : 1));
+    // (64 spare bytes: kernels that read whole dwords or look a few bytes ahead -- the LZ4 match finder -- may touch them)
+    RH_HIP(hipMalloc(out, size + 64));
     return 0;
 }
 void device_free(rh_device* dev, size_t size, void* p) {
@@ -1146,8 +1147,10 @@ struct rh_compressor {
     rh_lz4_stream_state* d_states = nullptr;
     struct Packet { std::vector<uint8_t> meta; rh_buffer* image = nullptr; };
     std::vector<std::deque<Packet>> queue;           // per stream: not yet submitted
-    struct RoundBuf { void* h = nullptr; size_t cap = 0; size_t live = 0; };
+    // (`ready` is recorded behind the copies that fill the buffer; `pending`: nobody has waited for it yet)
+    struct RoundBuf { void* h = nullptr; size_t cap = 0; size_t live = 0; hipEvent_t ready = nullptr; bool pending = false; };
     std::vector<RoundBuf> bufs;
+    hipEvent_t out_copied[2] = { nullptr, nullptr };    // the last copy out of each output area (a round that writes the area waits for it)
     struct Segment { const uint8_t* ptr = nullptr; size_t len = 0; int buf = -1; std::vector<uint8_t> own; };
     std::vector<std::deque<Segment>> ready;          // per stream: compressed bytes not yet consumed
     // the round in flight
@@ -1243,6 +1246,7 @@ int compressor_submit_round(rh_compressor* c) {
     RH_HIP(hipStreamSynchronize(c->stream));        // the pageable staging vectors go out of scope below
     c->round_bytes_in = 0;
     for (const rh_lz4_job& jb : jobs) for (uint32_t w = 0; w < jb.n_writes; w++) c->round_bytes_in += jb.write_len[w];
+    if (c->out_copied[R.out_buf]) RH_HIP(hipStreamWaitEvent(c->stream, c->out_copied[R.out_buf], 0));     // the area's previous bytes have left
     RH_HIP(hipEventRecord(c->k0, c->stream));
     int rc = rhk::lz4f_compress_launch(c->d_jobs.as<rh_lz4_job>(), n, c->d_states, c->stream);
     if (rc) return fail("rh_compressor: kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
@@ -1300,7 +1304,11 @@ int compressor_collect_round(rh_compressor* c, rh_compressor::Round& R) {
         if (len) RH_HIP(hipMemcpyAsync((uint8_t*)b.h + off, c->d_out[R.out_buf].as<uint8_t>() + R.out_off[j], len, hipMemcpyDeviceToHost, c->copy_stream));
         off += len;
     }
-    RH_HIP(hipStreamSynchronize(c->copy_stream));
+    // The copies run beside whatever the caller does next; whoever reads the bytes waits for them (compressor_wait_bytes).
+    if (!b.ready) RH_HIP(hipEventCreateWithFlags(&b.ready, hipEventDisableTiming));
+    RH_HIP(hipEventRecord(b.ready, c->copy_stream));
+    b.pending = true;
+    c->out_copied[R.out_buf] = b.ready;
     off = 0;
     for (uint32_t j = 0; j < n; j++) {
         const size_t len = (size_t)R.lens[j];
@@ -1311,6 +1319,15 @@ int compressor_collect_round(rh_compressor* c, rh_compressor::Round& R) {
         }
         off += len;
     }
+    return 0;
+}
+
+// Before the bytes of a segment are read on the host: the copies that fill its buffer have finished.
+int compressor_wait_bytes(rh_compressor* c, const rh_compressor::Segment& sg) {
+    if (sg.buf < 0 || !c->bufs[sg.buf].pending) return 0;
+    RH_HIP(hipSetDevice(c->dev->ordinal));
+    RH_HIP(hipEventSynchronize(c->bufs[sg.buf].ready));
+    c->bufs[sg.buf].pending = false;
     return 0;
 }
 
@@ -1378,7 +1395,7 @@ void rh_compressor_destroy(rh_compressor* c) {
     (void)hipStreamSynchronize(c->copy_stream);
     Scratch* all[] = { &c->d_jobs, &c->d_stage, &c->d_out[0], &c->d_out[1], &c->d_lens };
     for (Scratch* s : all) s->release();
-    for (auto& b : c->bufs) if (b.h) (void)hipHostFree(b.h);
+    for (auto& b : c->bufs) { if (b.h) (void)hipHostFree(b.h); if (b.ready) (void)hipEventDestroy(b.ready); }
     if (c->h_lens) (void)hipHostFree(c->h_lens);
     if (c->d_states) (void)hipFree(c->d_states);
     (void)hipEventDestroy(c->frames_ready);
@@ -1416,6 +1433,12 @@ int rh_compressor_submit(rh_compressor* c) {
     }
 }
 
+int rh_compressor_wait(rh_compressor* c) {
+    if (!c) return fail("rh_compressor_wait: null compressor");
+    if (set_device(c->dev)) return 1;
+    return compressor_complete_round(c);
+}
+
 int rh_compressor_flush(rh_compressor* c) {
     if (!c) return fail("rh_compressor_flush: null compressor");
     if (rh_compressor_submit(c)) return 1;
@@ -1433,6 +1456,7 @@ int rh_compressor_peek(rh_compressor* c, uint32_t stream, const uint8_t** ptr, s
     if (!c || !ptr || !len) return fail("rh_compressor_peek: bad argument");
     if (stream >= c->n_streams) return fail("rh_compressor_peek: stream %u out of range", stream);
     if (c->ready[stream].empty()) { *ptr = nullptr; *len = 0; return 0; }
+    if (compressor_wait_bytes(c, c->ready[stream].front())) return 1;
     *ptr = c->ready[stream].front().ptr; *len = c->ready[stream].front().len;
     return 0;
 }
@@ -1459,6 +1483,7 @@ int rh_compressor_read(rh_compressor* c, uint32_t stream, void* dst, size_t cap,
     size_t done = 0;
     while (done < cap && !c->ready[stream].empty()) {
         const rh_compressor::Segment& sg = c->ready[stream].front();
+        if (compressor_wait_bytes(c, sg)) return 1;
         const size_t k = std::min(cap - done, sg.len);
         memcpy((uint8_t*)dst + done, sg.ptr, k);
         done += k;

@@ -5,8 +5,10 @@
 // (reference src/compressor.rs:88-144, via the lzzzz crate = liblz4): preferences level 0, auto-flush, block-linked,
 // 64 KiB blocks, no checksums; every Write::write_all is one LZ4F_compressUpdate.  A stream's bytes depend only on its
 // own write sequence, so streams are independent: each stream's state (hash table, 64 KiB dictionary, offsets) lives
-// in device memory and one wavefront replays the LZ4 "fast" algorithm for its stream with the current 64 KiB block,
-// the 64 KiB of history before it and the hash table resident in LDS.
+// in device memory and one wavefront replays the LZ4 "fast" algorithm for its stream.  Only the hash table (16 KiB) is
+// held in LDS; the bytes of the block and of the 64 KiB of history before it are read where they are, in the captured
+// frame (through L1/L2), so a CU holds as many streams as it has room for wavefronts and hash tables (eight) instead of
+// one, and the latencies of one stream's dependent steps are filled by the others.
 //
 // The match search of LZ4 is a sequential walk (position, hash, table look-up, table insert, compare, advance by a
 // step that grows with the number of misses).  The walk without a match is known in advance, so the 64 lanes evaluate
@@ -39,37 +41,44 @@ constexpr int HASHLOG = 12;
 constexpr uint32_t DISTANCE_MAX = 65535u, ML_MASK = 15u, RUN_MASK = 15u;
 constexpr uint32_t BLOCK_UNCOMPRESSED_FLAG = 0x80000000u;
 constexpr uint32_t CUR = KB64;                // virtual offset of the current block
-constexpr uint32_t RING_DWORDS = 2 * KB64 / 4;
 
-// LDS: a 128 KiB ring of bytes and the hash table.  Code addresses the ring with *virtual* offsets: the current block
-// starts at CUR, the history byte at distance d before the block is at CUR - d, so a match index maps to one flat offset
-// whether it lies in the dictionary, in the previous blocks of the same write, or in the current block.  The byte at
-// virtual offset v is stored at (v + rot) mod 128 KiB; after a full 64 KiB block `rot` advances by 64 KiB, which turns
-// the block into the history of the next one without moving a byte.
-// The ring's first two dwords are repeated behind its end (`again`), so that the unaligned 4- and 8-byte reads take
-// the dwords i, i+1, i+2 without wrapping each index: one address computation and one paired LDS read.
+// Code addresses the bytes of a block and of its history with *virtual* offsets: the current block starts at CUR, the
+// history byte at distance d before the block is at CUR - d, so a match index maps to one flat offset whether it lies in
+// the dictionary, in the previous blocks of the same write, or in the current block.  Behind the offsets are two
+// addresses: `cur` for the block, and `hist` for what lies before it -- the same address inside a write (the previous
+// block precedes the current one in the source), or the end of the stream's saved dictionary for the first block of a
+// write.  Lanes read unconditionally and mask afterwards, so offsets are clamped to the 64 KiB before the block and
+// the few bytes behind it that every source buffer is padded with.
 struct Lds {
-    uint32_t ring[RING_DWORDS];
-    uint32_t again[2];
     uint32_t hash[(1 << HASHLOG) + 64];       // + one private slot per lane: lanes past the end of the walk go there,
 };                                            //   so every lane runs the table protocol and no step needs a lane mask
 
+constexpr uint32_t READ_SLACK = 16;           // bytes behind the end of a source that may be read (and are ignored)
+
 struct Ring {
-    const uint32_t* w;
-    uint32_t rot;
+    g_cu8* cur;
+    g_cu8* hist;
+    uint32_t hi;                              // last virtual offset that may be read (the block's end + slack - 12)
+    bool split;                               // hist != cur: a read that starts in the history may end in the block
+    __device__ __forceinline__ g_cu8* at(uint32_t v) const {
+        v = v < CUR - KB64 ? CUR - KB64 : (v > hi ? hi : v);
+        return (v >= CUR ? cur : hist) + (int32_t)(v - CUR);
+    }
     __device__ __forceinline__ uint32_t rd32(uint32_t v) const {
-        const uint32_t a = v + rot, i = (a >> 2) & (RING_DWORDS - 1u);
-        return __builtin_amdgcn_alignbyte(w[i + 1u], w[i], a & 3u);
+        if (split) return (uint32_t)*at(v) | ((uint32_t)*at(v + 1u) << 8) | ((uint32_t)*at(v + 2u) << 16) | ((uint32_t)*at(v + 3u) << 24);
+        g_cu8* const a = at(v);
+        const g_u32* const q = (const g_u32*)((uintptr_t)a & ~(uintptr_t)3);
+        return __builtin_amdgcn_alignbyte(q[1], q[0], (uint32_t)(uintptr_t)a & 3u);
     }
     __device__ __forceinline__ uint64_t rd64(uint32_t v) const {
-        const uint32_t a = v + rot, i = (a >> 2) & (RING_DWORDS - 1u), s = a & 3u;
-        const uint32_t x = w[i], y = w[i + 1u], z = w[i + 2u];
+        if (split) return (uint64_t)rd32(v) | ((uint64_t)rd32(v + 4u) << 32);
+        g_cu8* const a = at(v);
+        const g_u32* const q = (const g_u32*)((uintptr_t)a & ~(uintptr_t)3);
+        const uint32_t s = (uint32_t)(uintptr_t)a & 3u;
+        const uint32_t x = q[0], y = q[1], z = q[2];
         return (uint64_t)__builtin_amdgcn_alignbyte(y, x, s) | ((uint64_t)__builtin_amdgcn_alignbyte(z, y, s) << 32);
     }
-    __device__ __forceinline__ uint32_t byte(uint32_t v) const {
-        const uint32_t a = (v + rot) & (2u * KB64 - 1u);
-        return reinterpret_cast<const uint8_t*>(w)[a];
-    }
+    __device__ __forceinline__ uint32_t byte(uint32_t v) const { return *at(v); }
     __device__ __forceinline__ uint32_t hash5(uint32_t v) const { return hash5_of(rd64(v)); }
     // LZ4_hash5: ((sequence << 24) * 889523592379) >> (64 - HASHLOG), i.e. bits 28..39 of x * P for the five low bytes x
     // of the sequence.  With x = a + b * 2^32 and P = p0 + p1 * 2^32 those bits need one 32x32 product (both halves) and two
@@ -365,28 +374,22 @@ last_literals:
 } // namespace
 
 // One workgroup (one wave) per job.  A job is a sequence of writes to one stream; every write is one
-// LZ4F_compressUpdate: full 64 KiB blocks, then the remainder, then the dictionary save.
+// LZ4F_compressUpdate: full 64 KiB blocks, then the remainder, then the dictionary save.  Every source is readable up
+// to READ_SLACK bytes behind its end.
 extern "C" __global__ __launch_bounds__(64) void rh_lz4f_compress(const rh_lz4_job* jobs, rh_lz4_stream_state* states) {
     extern __shared__ uint8_t lds_raw[];
     Lds& L = *reinterpret_cast<Lds*>(lds_raw);
-    uint8_t* const ring8 = reinterpret_cast<uint8_t*>(L.ring);
     const int lane = (int)threadIdx.x;
     // (a reference, not a copy: a local copy with its run-time indexed arrays would live in per-lane memory, and
     // everything derived from it -- block sizes, positions, every branch of the match loop -- would be treated as
     // varying across the lanes instead of running on the scalar unit)
     const rh_lz4_job& job = jobs[blockIdx.x];
     rh_lz4_stream_state& S = states[job.stream];
-    Ring R; R.w = L.ring; R.rot = 0;
+    g_u8* const dict = (g_u8*)S.dict;
 
-    // bring the stream state into LDS
+    // bring the hash table into LDS
     for (int i = lane; i < (1 << HASHLOG); i += 64) L.hash[i] = S.hash[i];
     Stream st; st.current_offset = __builtin_amdgcn_readfirstlane(S.current_offset); st.dict_size = __builtin_amdgcn_readfirstlane(S.dict_size);
-    {   const uint32_t d = st.dict_size;              // <= 64 KiB, stored at the end of S.dict
-        for (uint32_t i = (uint32_t)lane * 16u; i < d; i += 64u * 16u) {
-            const uint32_t off = KB64 - ((d + 15u) & ~15u) + i;
-            *reinterpret_cast<uint4*>(ring8 + off) = *reinterpret_cast<const uint4*>(S.dict + off);
-        }
-    }
     __syncthreads();
 
     g_u8* out = (g_u8*)job.out;
@@ -409,20 +412,12 @@ extern "C" __global__ __launch_bounds__(64) void rh_lz4f_compress(const rh_lz4_j
                 // a dictionary shorter than 4 bytes is dropped (LZ4_compress_fast_continue)
                 if (st.dict_size - 1u < 3u) st.dict_size = 0;
             }
-            // load the block behind the history: `rot` is 0 or 64 KiB, so the block is one contiguous, 16-byte aligned
-            // half of the ring (the byte loop handles unaligned sources and tails)
-            {   g_cu8* s = src + done;
-                uint8_t* const blk8 = ring8 + ((CUR + R.rot) & (2u * KB64 - 1u));
-                if ((reinterpret_cast<uintptr_t>(s) & 15u) == 0) {
-                    for (uint32_t i = (uint32_t)lane * 16u; i + 16u <= n; i += 64u * 16u)
-                        *reinterpret_cast<u32x4*>(blk8 + i) = *(g_cu32x4*)(s + i);
-                    const uint32_t tail = n & ~15u;
-                    for (uint32_t i = tail + (uint32_t)lane; i < n; i += 64u) blk8[i] = s[i];
-                } else {
-                    for (uint32_t i = (uint32_t)lane; i < n; i += 64u) blk8[i] = s[i];
-                }
-            }
-            if (lane == 0) { L.again[0] = L.ring[0]; L.again[1] = L.ring[1]; }        // (after every write to the ring: dictionary, block, slide)
+            // the block where it is; before it the previous block of the same write, or the stream's saved dictionary
+            Ring R;
+            R.cur = src + done;
+            R.hist = first_block ? (g_cu8*)(dict + KB64) : R.cur;
+            R.split = first_block;
+            R.hi = CUR + n + READ_SLACK - 12u;
             __syncthreads();
             const bool small = st.dict_size < KB64 && st.dict_size < st.current_offset;
             const bool ext = first_block;
@@ -440,40 +435,23 @@ extern "C" __global__ __launch_bounds__(64) void rh_lz4f_compress(const rh_lz4_j
             op += 4u + c;
             done += n;
             first_block = false;
-            // the block just compressed becomes history
-            {   const uint32_t keep = st.dict_size < KB64 ? st.dict_size : KB64;      // == LZ4_saveDict size after the last block
-                if (n == KB64) {
-                    R.rot ^= KB64;                          // the full block is now the 64 KiB before CUR
-                } else if (n > 0) {
-                    // slide the last `keep` bytes of [history | block] down by n: virtual [CUR + n - keep, CUR + n) ->
-                    // [CUR - keep, CUR), ascending, 1 KiB per step, reads before writes
-                    const uint32_t src_off = CUR + n - keep + R.rot, dst_off = CUR - keep + R.rot;
-                    for (uint32_t i = 0; i < keep; i += 64u * 16u) {
-                        const uint32_t j = i + (uint32_t)lane * 16u;
-                        uint8_t tmp[16];
-                        const bool act = j < keep;
-                        if (act) for (int k = 0; k < 16; k++) tmp[k] = (j + k < keep) ? ring8[(src_off + j + k) & (2u * KB64 - 1u)] : 0;
-                        __syncthreads();
-                        if (act) for (int k = 0; k < 16; k++) if (j + k < keep) ring8[(dst_off + j + k) & (2u * KB64 - 1u)] = tmp[k];
-                        __syncthreads();
-                    }
-                }
-                if (done >= size) st.dict_size = keep;      // LZ4_saveDict at the end of the update
+            if (done >= size) {
+                // LZ4_saveDict at the end of the update: the last `keep` bytes of what the write's blocks saw as [history |
+                // data] -- after the first block that is the write's own data -- go to the end of the dictionary buffer
+                const uint32_t keep = st.dict_size < KB64 ? st.dict_size : KB64;
+                copy_out(dict + (KB64 - keep), R, CUR + n - keep, keep, lane);
+                st.dict_size = keep;
+                // (the next write of this job reads the dictionary through other lanes than the ones that wrote it)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __syncthreads();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             }
-            __syncthreads();
         }
     }
 
-    // persist the stream state: the history is the 64 KiB half before the block position
+    // persist the stream state (the dictionary is already in place)
     __syncthreads();
     for (int i = lane; i < (1 << HASHLOG); i += 64) S.hash[i] = L.hash[i];
-    {   const uint32_t d = st.dict_size;
-        const uint8_t* const hist8 = ring8 + (R.rot & (2u * KB64 - 1u));          // virtual [0, 64 KiB)
-        for (uint32_t i = (uint32_t)lane * 16u; i < ((d + 15u) & ~15u); i += 64u * 16u) {
-            const uint32_t off = KB64 - ((d + 15u) & ~15u) + i;
-            *reinterpret_cast<uint4*>(S.dict + off) = *reinterpret_cast<const uint4*>(hist8 + off);
-        }
-    }
     if (lane == 0) { S.current_offset = st.current_offset; S.dict_size = st.dict_size; *job.out_len = op; }
 }
 

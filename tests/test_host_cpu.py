@@ -141,8 +141,9 @@ def test_cpp_host_mirror_builds():
 
 
 def test_bench_capture_plan_shrinks_with_ranks_and_room(monkeypatch):
-    """bench.py sizes its recorded-frames leg from the free space in /tmp and the available memory: the largest plan
-    when there is room, smaller ones as more ranks share the host, never below the smallest."""
+    """bench.py sizes its recorded-frames leg from the available memory (the stream files go to /dev/shm when there is one,
+    and a round's bytes are pinned twice) and the free space where the files go: the largest plan when there is room,
+    smaller ones as more ranks share the host, never below the smallest."""
     import collections
     import importlib.util
     import shutil
@@ -152,9 +153,16 @@ def test_bench_capture_plan_shrinks_with_ranks_and_room(monkeypatch):
     Usage = collections.namedtuple("Usage", "total used free")
     import psutil
     Mem = collections.namedtuple("Mem", "available")
+    root = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else "/tmp"
+    in_memory = root == "/dev/shm"
     monkeypatch.setattr(psutil, "virtual_memory", lambda: Mem(available=300e9))
-    monkeypatch.setattr(shutil, "disk_usage", lambda path: Usage(252e9, 172e9, 80e9))
+    monkeypatch.setattr(shutil, "disk_usage", lambda path: Usage(300e9, 0, 300e9))
     plans = [bench.capture_plan(n, None, 0) for n in (1, 2, 4, 8)]
-    assert plans == [(512, 256, 2), (512, 256, 2), (256, 256, 1), (128, 128, 1)]
+    assert all(p[3] == root for p in plans)
+    if in_memory:
+        # one rank: 2048 frames of 30 MB in memory + two pinned rounds of 1024 = 138 GB of the 150 GB it may take
+        assert [p[:3] for p in plans] == [(2048, 1024, 1), (1024, 512, 1), (512, 256, 2), (128, 128, 1)]
+    else:
+        assert [p[:3] for p in plans] == [(2048, 1024, 1), (2048, 1024, 1), (1024, 512, 1), (512, 256, 2)]
     monkeypatch.setattr(shutil, "disk_usage", lambda path: Usage(252e9, 251e9, 1e9))
-    assert bench.capture_plan(1, None, 0) == (128, 128, 1)
+    assert bench.capture_plan(1, None, 0)[:3] == (128, 128, 1)

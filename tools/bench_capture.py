@@ -40,7 +40,7 @@ def run_capture(frames=128, streams=64, quads=100_000, side=32, width=3840, heig
     # budget: two rounds of the streams' frames may be held on the device at once (33 MB each at 4K): one being
     # compressed, one being captured
     budget_mb = (2 * streams + 2) * W * H * 4 / (1024.0 * 1024.0) if budget_mb is None else budget_mb
-    comp = Compressor(r, out, n_streams=streams, max_buffer_size_in_megabytes=budget_mb)
+    comp = Compressor(r, out, n_streams=streams, max_buffer_size_in_megabytes=budget_mb, wait_for_rounds=os.environ.get("RH_CAPTURE_TURNS", "0") == "1")
     t_compress = [0.0]
 
     def sink(frame):
@@ -181,7 +181,8 @@ def main():
            "frames": args.frames, "streams": args.streams, "config": {"workload": info["workload"]},
            "ms_per_frame": elapsed / args.frames * 1e3, "compress_ms_per_frame": info["compress_ms_per_frame"],
            "raw_MB_per_frame": info["raw_MB_per_frame"], "compressed_MB_per_frame": info["compressed_MB_per_frame"],
-           "raw_GBps": info["raw_MB_per_frame"] * args.frames / elapsed / 1e3}
+           "raw_GBps": info["raw_MB_per_frame"] * args.frames / elapsed / 1e3, "kernel": info["kernel"],
+           "frames_dropped": info["frames_dropped"]}
 
     if args.cpu_frames > 0:
         single, multi = liblz4_baseline(np.ascontiguousarray(last).tobytes(), args.cpu_frames)

@@ -58,7 +58,7 @@ constexpr uint32_t READ_SLACK = 16;           // bytes behind the end of a sourc
 struct Ring {
     g_cu8* cur;
     g_cu8* hist;
-    uint32_t hi;                              // last virtual offset that may be read (the block's end + slack - 12)
+    uint32_t hi;                              // last virtual offset that may be read (the block's end + slack - 8)
     bool split;                               // hist != cur: a read that starts in the history may end in the block
     __device__ __forceinline__ g_cu8* at(uint32_t v) const {
         v = v < CUR - KB64 ? CUR - KB64 : (v > hi ? hi : v);
@@ -66,17 +66,14 @@ struct Ring {
     }
     __device__ __forceinline__ uint32_t rd32(uint32_t v) const {
         if (split) return (uint32_t)*at(v) | ((uint32_t)*at(v + 1u) << 8) | ((uint32_t)*at(v + 2u) << 16) | ((uint32_t)*at(v + 3u) << 24);
-        g_cu8* const a = at(v);
-        const g_u32* const q = (const g_u32*)((uintptr_t)a & ~(uintptr_t)3);
-        return __builtin_amdgcn_alignbyte(q[1], q[0], (uint32_t)(uintptr_t)a & 3u);
+        // (global loads take any address: one instruction whatever the alignment)
+        uint32_t x; __builtin_memcpy(&x, (const void*)at(v), 4);
+        return x;
     }
     __device__ __forceinline__ uint64_t rd64(uint32_t v) const {
         if (split) return (uint64_t)rd32(v) | ((uint64_t)rd32(v + 4u) << 32);
-        g_cu8* const a = at(v);
-        const g_u32* const q = (const g_u32*)((uintptr_t)a & ~(uintptr_t)3);
-        const uint32_t s = (uint32_t)(uintptr_t)a & 3u;
-        const uint32_t x = q[0], y = q[1], z = q[2];
-        return (uint64_t)__builtin_amdgcn_alignbyte(y, x, s) | ((uint64_t)__builtin_amdgcn_alignbyte(z, y, s) << 32);
+        uint64_t x; __builtin_memcpy(&x, (const void*)at(v), 8);
+        return x;
     }
     __device__ __forceinline__ uint32_t byte(uint32_t v) const { return *at(v); }
     __device__ __forceinline__ uint32_t hash5(uint32_t v) const { return hash5_of(rd64(v)); }
@@ -417,7 +414,7 @@ extern "C" __global__ __launch_bounds__(64) void rh_lz4f_compress(const rh_lz4_j
             R.cur = src + done;
             R.hist = first_block ? (g_cu8*)(dict + KB64) : R.cur;
             R.split = first_block;
-            R.hi = CUR + n + READ_SLACK - 12u;
+            R.hi = CUR + n + READ_SLACK - 8u;
             __syncthreads();
             const bool small = st.dict_size < KB64 && st.dict_size < st.current_offset;
             const bool ext = first_block;

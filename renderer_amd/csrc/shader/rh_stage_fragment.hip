@@ -139,8 +139,10 @@ struct TriSetup {
 // otherwise fills `t` and grows the tile-relative bbox.  `big` is set when an edge coefficient is too large for the
 // f32 coverage path.  cf: inside at sub-pixel position P <=> A*Px + B*Py + cf >= 0; multisampled passes derive
 // per-sample constants from it.
+// `edges`: bit K set = the constant of edge K is needed (an axis-aligned quad with affine varyings is drawn from its
+// shared diagonal alone: the 64-bit work of the other edges is skipped; their coefficients still decide `big`).
 RH_DEVICE bool setup_triangle(const rh_draw_params& p, SnappedVertex a, SnappedVertex b, SnappedVertex c, int ox, int oy,
-                              TriSetup& t, bool& persp, bool& big, int& bx0, int& by0, int& bx1, int& by1) {
+                              TriSetup& t, bool& persp, bool& big, int& bx0, int& by0, int& bx1, int& by1, uint32_t edges = 7u) {
     int x0, y0, x1, y1;
     if (!tri_pixel_bbox(p, a, b, c, x0, y0, x1, y1)) return false;
     x0 = max(x0, ox); y0 = max(y0, oy); x1 = min(x1, ox + TILE - 1); y1 = min(y1, oy + TILE - 1);
@@ -152,11 +154,14 @@ RH_DEVICE bool setup_triangle(const rh_draw_params& p, SnappedVertex a, SnappedV
     // keeps the sign (and the sum inside 32 bits).
 #define RH_EDGE(P, Q, K) { \
         const int32_t A_ = P.Y - Q.Y, B_ = Q.X - P.X; \
-        const int64_t C_ = -((int64_t)A_ * P.X + (int64_t)B_ * P.Y); \
-        const bool tl_ = (A_ > 0) || (A_ == 0 && B_ > 0); \
-        t.cf[K] = C_ + (tl_ ? 0 : -1); \
-        const int64_t Cq_ = t.cf[K] >> RH_SUBPIXEL_BITS; \
-        t.ei[K] = A_; t.ei[3 + K] = B_; t.ei[6 + K] = (int32_t)clamp_i64(Cq_ + (int64_t)A_ * ox + (int64_t)B_ * oy, (int64_t)1 << 30); \
+        t.ei[K] = A_; t.ei[3 + K] = B_; \
+        if (edges & (1u << K)) { \
+            const int64_t C_ = -((int64_t)A_ * P.X + (int64_t)B_ * P.Y); \
+            const bool tl_ = (A_ > 0) || (A_ == 0 && B_ > 0); \
+            t.cf[K] = C_ + (tl_ ? 0 : -1); \
+            const int64_t Cq_ = t.cf[K] >> RH_SUBPIXEL_BITS; \
+            t.ei[6 + K] = (int32_t)clamp_i64(Cq_ + (int64_t)A_ * ox + (int64_t)B_ * oy, (int64_t)1 << 30); \
+        } \
         if (A_ >= F32_EDGE_LIMIT || A_ <= -F32_EDGE_LIMIT || B_ >= F32_EDGE_LIMIT || B_ <= -F32_EDGE_LIMIT) big = true; }
     RH_EDGE(a, b, 0)
     RH_EDGE(b, c, 1)
@@ -235,7 +240,7 @@ RH_DEVICE void store_ms_edges(MsRecord<S>& m, int t, const TriSetup& ts, int ox,
 // Sets up both triangles of `cluster` for the tile at (ox, oy) and writes the pair's records.  S > 1 (multisampled
 // pass) also writes the per-sample constants and never takes the exact-box shortcut.
 template <int S>
-RH_DEVICE void setup_pair(const rh_draw_params& p, uint32_t cluster, int ox, int oy, uint32_t* rec, uint32_t* ext) {
+RH_DEVICE void setup_pair(const rh_draw_params& p, uint32_t cluster, int ox, int oy, uint32_t* w, uint32_t* ext) {
     const uint32_t instance = cluster / p.cpi, local = cluster - instance * p.cpi;
     const uint32_t tri0 = local * 2;
     const bool has_second = tri0 + 1 < p.tpi;
@@ -249,19 +254,25 @@ RH_DEVICE void setup_pair(const rh_draw_params& p, uint32_t cluster, int ox, int
     int bx0 = 255, by0 = 255, bx1 = -1, by1 = -1;
     bool persp_a = false, persp_b = false, big = false;
     TriSetup ta, tb;
-    const bool has_a = setup_triangle(p, v0, v1, v2, ox, oy, ta, persp_a, big, bx0, by0, bx1, by1);
-    bool has_b = false, rect = false;
+    bool has_a = false, has_b = false, rect = false;
     int32_t rminX = 0, rmaxX = 0, rminY = 0, rmaxY = 0;
-    if (has_second) {
+    if (has_second && strip) {
         const SnappedVertex v3 = run_vertex(p, first + 3, instance);
-        if (strip) {
-            has_b = setup_triangle(p, v1, v3, v2, ox, oy, tb, persp_b, big, bx0, by0, bx1, by1);
-            // a strip quad whose snapped corners form an axis-aligned rectangle split along v1-v2
-            const bool columns = v0.X == v1.X && v2.X == v3.X && v0.Y == v2.Y && v1.Y == v3.Y;
-            const bool rows = v0.Y == v1.Y && v2.Y == v3.Y && v0.X == v2.X && v1.X == v3.X;
-            rect = S == 1 && has_a && has_b && !big && (columns || rows) && v0.X != v3.X && v0.Y != v3.Y;
-            rminX = min(v0.X, v3.X); rmaxX = max(v0.X, v3.X); rminY = min(v0.Y, v3.Y); rmaxY = max(v0.Y, v3.Y);
-        } else {
+        // a strip quad whose snapped corners form an axis-aligned rectangle split along v1-v2: with affine varyings and
+        // sides short enough for the f32 coverage path it is drawn from the shared diagonal alone (edge 1 of triangle A)
+        const bool columns = v0.X == v1.X && v2.X == v3.X && v0.Y == v2.Y && v1.Y == v3.Y;
+        const bool rows = v0.Y == v1.Y && v2.Y == v3.Y && v0.X == v2.X && v1.X == v3.X;
+        rminX = min(v0.X, v3.X); rmaxX = max(v0.X, v3.X); rminY = min(v0.Y, v3.Y); rmaxY = max(v0.Y, v3.Y);
+        const bool shape = S == 1 && (columns || rows) && v0.X != v3.X && v0.Y != v3.Y;
+        const bool lean = shape && rmaxX - rminX < F32_EDGE_LIMIT && rmaxY - rminY < F32_EDGE_LIMIT &&
+                          v0.rw == 1.0f && v1.rw == 1.0f && v2.rw == 1.0f && v3.rw == 1.0f;
+        has_a = setup_triangle(p, v0, v1, v2, ox, oy, ta, persp_a, big, bx0, by0, bx1, by1, lean ? 2u : 7u);
+        has_b = setup_triangle(p, v1, v3, v2, ox, oy, tb, persp_b, big, bx0, by0, bx1, by1, lean ? 0u : 7u);
+        rect = shape && has_a && has_b && !big;
+    } else {
+        has_a = setup_triangle(p, v0, v1, v2, ox, oy, ta, persp_a, big, bx0, by0, bx1, by1);
+        if (has_second) {
+            const SnappedVertex v3 = run_vertex(p, first + 3, instance);
             const SnappedVertex v4 = run_vertex(p, first + 4, instance);
             const SnappedVertex v5 = run_vertex(p, first + 5, instance);
             has_b = setup_triangle(p, v3, v4, v5, ox, oy, tb, persp_b, big, bx0, by0, bx1, by1);
@@ -282,7 +293,6 @@ RH_DEVICE void setup_pair(const rh_draw_params& p, uint32_t cluster, int ox, int
     }
     if (bbox == BBOX_EMPTY) flags = 0u;
     // the record (the planes of a missing triangle are zeros: never used, masked by the flags)
-    uint32_t w[REC_WORDS];
 #pragma unroll
     for (int i = 0; i < REC_WORDS; i++) w[i] = 0u;
     w[0] = bbox; w[1] = flags;
@@ -303,9 +313,6 @@ RH_DEVICE void setup_pair(const rh_draw_params& p, uint32_t cluster, int ox, int
             o[OFF_V0 + v] = __float_as_uint(ts[t]->v0[v]); o[OFF_DVDX + v] = __float_as_uint(ts[t]->dvdx[v]); o[OFF_DVDY + v] = __float_as_uint(ts[t]->dvdy[v]);
         }
     }
-    uint4* const rec4 = reinterpret_cast<uint4*>(rec);
-#pragma unroll
-    for (int i = 0; i < REC_WORDS / 4; i++) rec4[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
     // the extended record: only for clusters whose fragments read it
     if (bbox != BBOX_EMPTY && (!rect || persp_a || persp_b)) {
 #pragma unroll
@@ -327,15 +334,26 @@ template <int S>
 RH_DEVICE void setup_kernel(const rh_setup_args& a) {
     uint32_t n = a.n_pairs;
     if (a.pair_total) { if (*a.pair_total > n) return; n = (uint32_t)*a.pair_total; }   // (n arrives as the room for the pairs)
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t tile = a.tiles[i];
-    // the ends of a tile's run of pairs
-    if (i == 0u || a.tiles[i - 1u] != tile) a.tile_start[tile] = i;
-    if (i == n - 1u || a.tiles[i + 1u] != tile) a.tile_end[tile] = i + 1u;
-    const int ox = (int)(tile % a.p.tiles_x) * TILE, oy = (int)(tile / a.p.tiles_x) * TILE;
-    setup_pair<S>(a.p, a.clusters[i], ox, oy, reinterpret_cast<uint32_t*>(a.rec + (size_t)i * (REC_WORDS * 4)),
-                  reinterpret_cast<uint32_t*>(a.ext + (size_t)i * a.ext_bytes));
+    // The records of the workgroup's 256 pairs are gathered in LDS and leave as one contiguous run of 16-byte pieces
+    // (a thread's own record is 96 bytes: stored directly, the lanes of a store would be 96 bytes apart).
+    __shared__ uint4 stage[256 * (REC_WORDS / 4)];
+    const uint32_t first = blockIdx.x * 256u, i = first + threadIdx.x;
+    if (first >= n) return;
+    if (i < n) {
+        const uint32_t tile = a.tiles[i];
+        // the ends of a tile's run of pairs
+        if (i == 0u || a.tiles[i - 1u] != tile) a.tile_start[tile] = i;
+        if (i == n - 1u || a.tiles[i + 1u] != tile) a.tile_end[tile] = i + 1u;
+        const int ox = (int)(tile % a.p.tiles_x) * TILE, oy = (int)(tile / a.p.tiles_x) * TILE;
+        uint32_t w[REC_WORDS];
+        setup_pair<S>(a.p, a.clusters[i], ox, oy, w, reinterpret_cast<uint32_t*>(a.ext + (size_t)i * a.ext_bytes));
+#pragma unroll
+        for (int q = 0; q < REC_WORDS / 4; q++) stage[threadIdx.x * (REC_WORDS / 4) + q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+    }
+    __syncthreads();
+    const uint32_t pieces = min(256u, n - first) * (REC_WORDS / 4);
+    uint4* const out = reinterpret_cast<uint4*>(a.rec + (size_t)first * (REC_WORDS * 4));
+    for (uint32_t q = threadIdx.x; q < pieces; q += 256u) out[q] = stage[q];
 }
 
 // f32 coverage: with |A|, |B| < 2^17 and lx, ly < 32 every product is an exactly representable integer below 2^22,

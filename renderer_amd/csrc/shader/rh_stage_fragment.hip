@@ -46,18 +46,17 @@ static_assert(ROUND == 16 || ROUND == 32 || ROUND == 64, "a round is at most one
 
 // ---- record layout (dwords) -------------------------------------------------------------------------------------------
 // Set-up record, staged through LDS by the tile wave:
-//   [0] box x0 | y0 << 8 | x1 << 16 | y1 << 24 (tile-relative, inclusive; BBOX_EMPTY: contributes nothing)
-//   [1] flags
-//   [2] floor(log2(1.41 * largest |d varying / dx| per pixel)) over the cluster's planes, as an integer: how far apart
-//       neighbouring fragments sample a texture, in units of its size   [3] unused
-//   [4..6] shared diagonal of a rectangle (edge 1 of triangle A): A, B, T   [7] unused
+//   [0] header: box x0 | y0 << 5 | x1 << 10 | y1 << 15 (tile-relative, inclusive, 0..31 each; x0 > x1: contributes
+//       nothing) | flags << 20 | g << 26, g = floor(log2(1.41 * largest |d varying / dx| per pixel)) over the cluster's
+//       planes clamped to -32..31: how far apart neighbouring fragments sample a texture, in units of its size
+//   [1..3] shared diagonal of a rectangle (edge 1 of triangle A): A, B, T
 //   then per triangle TRI_WORDS: XR, YR (reference vertex in 24.8 fixed point relative to the tile origin, as f32, exact),
 //   v0[NV], dvdx[NV], dvdy[NV] (gradients per 1/256 pixel)
 // Extended record (global memory, read only by the clusters that need it), per triangle EXT_TRI_WORDS:
 //   A[3], B[3], T[3]: edge e is inside <=> A*lx + B*ly + T >= 0 at tile-relative pixel (lx, ly), as f32 or (FLAG_BIG) i32
 //   q0, qx, qy: the 1/w plane of a perspective triangle
 // followed in a multisampled pass by RH_MS_EXTRA_WORDS(S) dwords: MsRecord<S>.
-constexpr int HDR_WORDS = 8;
+constexpr int HDR_WORDS = 4;
 constexpr int TRI_WORDS = (2 + 3 * NV + 3) & ~3;
 constexpr int REC_WORDS = HDR_WORDS + 2 * TRI_WORDS;
 constexpr int EXT_TRI_WORDS = 12;
@@ -66,7 +65,16 @@ constexpr int OFF_XR = 0, OFF_YR = 1, OFF_V0 = 2, OFF_DVDX = 2 + NV, OFF_DVDY = 
 constexpr int EOFF_A = 0, EOFF_B = 3, EOFF_T = 6, EOFF_Q = 9;
 static_assert(REC_WORDS % 4 == 0 && EXT_WORDS % 4 == 0, "records move as 16-byte pieces");
 
-constexpr uint32_t BBOX_EMPTY = 0x000000ffu;    // x0 = 255 > x1 = 0
+constexpr uint32_t BBOX_EMPTY = 0x000000ffu;    // x0 = 255 > x1 = 0 (the kernels work with boxes as x0 | y0 << 8 | x1 << 16 | y1 << 24)
+constexpr uint32_t HDR_EMPTY = 31u;             // header of a record that contributes nothing: x0 = 31 > x1 = 0, no flags
+RH_DEVICE uint32_t hdr_pack(uint32_t box, uint32_t flags, int g) {
+    if (box == BBOX_EMPTY) return HDR_EMPTY;
+    g = g < -32 ? -32 : (g > 31 ? 31 : g);
+    return (box & 31u) | (((box >> 8) & 31u) << 5) | (((box >> 16) & 31u) << 10) | (((box >> 24) & 31u) << 15) | (flags << 20) | ((uint32_t)g << 26);
+}
+RH_DEVICE uint32_t hdr_box(uint32_t h) { return (h & 31u) | (((h >> 5) & 31u) << 8) | (((h >> 10) & 31u) << 16) | (((h >> 15) & 31u) << 24); }
+RH_DEVICE uint32_t hdr_flags(uint32_t h) { return (h >> 20) & 63u; }
+RH_DEVICE int hdr_grad(uint32_t h) { return (int)h >> 26; }
 constexpr uint32_t FLAG_PERSP_A = 1u, FLAG_PERSP_B = 2u, FLAG_HAS_A = 4u, FLAG_HAS_B = 8u, FLAG_BIG = 16u, FLAG_RECT = 32u;
 // Edge coefficients below this magnitude (512 px) make f32 edge evaluation exact; see edges_inside_f32.
 constexpr int32_t F32_EDGE_LIMIT = 1 << 17;
@@ -295,14 +303,13 @@ RH_DEVICE void setup_pair(const rh_draw_params& p, uint32_t cluster, int ox, int
     // the record (the planes of a missing triangle are zeros: never used, masked by the flags)
 #pragma unroll
     for (int i = 0; i < REC_WORDS; i++) w[i] = 0u;
-    w[0] = bbox; w[1] = flags;
-    w[4] = edge_word(ta, 1, false); w[5] = edge_word(ta, 4, false); w[6] = edge_word(ta, 7, false);      // the shared diagonal (used when RECT: never BIG)
     {   float g = 0.0f;
         const TriSetup& tg = has_a ? ta : tb;
 #pragma unroll
         for (int v = 0; v < NV; v++) g = fmaxf(g, fabsf(tg.dvdx[v]));
-        w[2] = (uint32_t)((int)((__float_as_uint(g * (256.0f * 1.41421356f)) >> 23) & 0xffu) - 127);
+        w[0] = hdr_pack(bbox, flags, (int)((__float_as_uint(g * (256.0f * 1.41421356f)) >> 23) & 0xffu) - 127);
     }
+    w[1] = edge_word(ta, 1, false); w[2] = edge_word(ta, 4, false); w[3] = edge_word(ta, 7, false);      // the shared diagonal (used when RECT: never BIG)
     const TriSetup* const ts[2] = { &ta, &tb };
 #pragma unroll
     for (int t = 0; t < 2; t++) {
@@ -516,8 +523,8 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
         stage_records(lds.rec, a.rec, base, n, lane);
         RH_PHASE_MARK(1)
         // lane = record of this round (all wave-parallel)
-        const uint32_t bb = lane < n ? lds.rec[lane * REC_WORDS] : BBOX_EMPTY;
-        const uint32_t fl = lane < n ? lds.rec[lane * REC_WORDS + 1] : 0u;
+        const uint32_t hdr = lane < n ? lds.rec[lane * REC_WORDS] : HDR_EMPTY;
+        const uint32_t bb = hdr_box(hdr), fl = hdr_flags(hdr);
         const int hx0 = (int)(bb & 0xffu), hy0 = (int)((bb >> 8) & 0xffu), hx1 = (int)((bb >> 16) & 0xffu), hy1 = (int)(bb >> 24);
         const bool hit = hx0 <= hx1;
         const int npx = (hx1 - hx0 + 1) * (hy1 - hy0 + 1);
@@ -591,7 +598,7 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
                 npass = 1;
                 rf = recf + (int)(m.y & 0xffu) * REC_WORDS;
                 flags = FLAG_RECT | FLAG_HAS_A | FLAG_HAS_B;
-                grad_log2 = (int)lds.rec[(int)(info & 0xffu) * REC_WORDS + 2];      // (the first member's: a hint only)
+                grad_log2 = hdr_grad(lds.rec[(int)(info & 0xffu) * REC_WORDS]);      // (the first member's: a hint only)
                 k += (int)(run & 7u);
             } else {
                 const uint32_t box = __builtin_amdgcn_readlane(box_v, k);
@@ -602,7 +609,7 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
                 npass = (npix + 63) >> 6;
                 rf = recf + (int)(info & 0xffu) * REC_WORDS;
                 flags = (info >> 8) & 0x3fu;
-                grad_log2 = (int)lds.rec[(int)(info & 0xffu) * REC_WORDS + 2];
+                grad_log2 = hdr_grad(lds.rec[(int)(info & 0xffu) * REC_WORDS]);
                 if ((flags & (FLAG_RECT | FLAG_PERSP_A | FLAG_PERSP_B)) != FLAG_RECT)
                     ef = reinterpret_cast<const float*>(a.ext + (size_t)(base + (info & 0xffu)) * a.ext_bytes);
                 k++;
@@ -619,7 +626,8 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
                 // Axis-aligned rectangle with affine varyings (what the reference's quads are): every pixel of the box is
                 // covered and the shared diagonal alone says by which triangle.  The SIMD issues one instruction of ANY
                 // kind per ~2.3 cycles (scalar ones and branches included), so this loop is kept free of per-pass tests.
-                const float4 dg = *reinterpret_cast<const float4*>(rf + 4);                 // diagonal A, B, T
+                const float4 dh = *reinterpret_cast<const float4*>(rf);                     // header, diagonal A, B, T
+                const float3 dg = make_float3(dh.y, dh.z, dh.w);
                 const float pbase_f = __builtin_fmaf(hy0f, (float)(TILE * 4), hx0f * 4.0f);  // byte offset of the box origin in the tile
                 uint8_t* const px_bytes = reinterpret_cast<uint8_t*>(tile_px);
                 for (int pass = 0; pass < npass; pass++, idx_f += 64.0f) {
@@ -659,7 +667,7 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
                 bool cov_a, cov_b, overlap = false;
                 if (flags & FLAG_RECT) {
                     // every pixel of the box is covered; the shared diagonal (edge 1 of A) says by which triangle
-                    const bool in_a = __float_as_int(__builtin_fmaf(rf[4], lxf, __builtin_fmaf(rf[5], lyf, rf[6]))) >= 0;
+                    const bool in_a = __float_as_int(__builtin_fmaf(rf[1], lxf, __builtin_fmaf(rf[2], lyf, rf[3]))) >= 0;
                     cov_a = live && in_a; cov_b = live && !in_a;
                 } else {
                     // (a missing triangle's record holds zeros: masked by has_*)
@@ -775,14 +783,14 @@ RH_DEVICE void tile_kernel_ms(const rh_tile_args& a) {
     for (uint32_t base = start; base < end; base += ROUND) {
         const int n = (int)min((uint32_t)ROUND, end - base);
         stage_records(lds.rec, a.rec, base, n, lane);
-        const uint32_t bb = lane < n ? lds.rec[lane * REC_WORDS] : BBOX_EMPTY;
+        const uint32_t bb = hdr_box(lane < n ? lds.rec[lane * REC_WORDS] : HDR_EMPTY);
         unsigned long long mask = __ballot((bb & 0xffu) <= ((bb >> 16) & 0xffu));
         while (mask) {
             const int ci = __builtin_ctzll(mask);
             mask &= mask - 1;
             const float* const rf = recf + ci * REC_WORDS;
-            const uint32_t flags = __builtin_amdgcn_readfirstlane(lds.rec[ci * REC_WORDS + 1]);
-            const uint32_t hb = __builtin_amdgcn_readfirstlane(lds.rec[ci * REC_WORDS]);
+            const uint32_t hdr = __builtin_amdgcn_readfirstlane(lds.rec[ci * REC_WORDS]);
+            const uint32_t flags = hdr_flags(hdr), hb = hdr_box(hdr);
             const float* const ef = reinterpret_cast<const float*>(a.ext + (size_t)(base + (uint32_t)ci) * a.ext_bytes);
             const MsRecord<S>& m = *reinterpret_cast<const MsRecord<S>*>(ef + EXT_WORDS);
             const bool has_a = (flags & FLAG_HAS_A) != 0u, has_b = (flags & FLAG_HAS_B) != 0u;

@@ -534,12 +534,12 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
         // Small axis-aligned quads may share one pass (see below); anything else runs alone, 64 pixels per pass.
         const bool small = (fl & (FLAG_RECT | FLAG_PERSP_A | FLAG_PERSP_B)) == FLAG_RECT && npx <= 64;
         // Compact the hits, in submission order, into the first nh lanes (a lane permutation, no memory):
-        //   box = the box, info = record of the round | flags << 8 | pixels << 16 | small << 31
+        //   box = the box, info = record of the round | flags << 6 | gradient hint (6 bits) << 12 | pixels << 18 | small << 31
         uint32_t box_v, info_v;
         {
             const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
             const int dest = hit ? below : nh + lane - below;
-            const uint32_t info = (uint32_t)lane | (fl << 8) | ((uint32_t)npx << 16) | (small ? 0x80000000u : 0u);
+            const uint32_t info = (uint32_t)lane | (fl << 6) | ((hdr >> 26) << 12) | ((uint32_t)npx << 18) | (small ? 0x80000000u : 0u);
             box_v = (uint32_t)__builtin_amdgcn_ds_permute(dest << 2, (int)bb);
             info_v = (uint32_t)__builtin_amdgcn_ds_permute(dest << 2, (int)(hit ? info : 0u));
         }
@@ -549,7 +549,7 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
         //   run = length | pixels << 3 | lane at which member 1, 2, 3 starts << 10, 17, 24 (127 = no such member)
         uint32_t run_v;
         {
-            const uint32_t n0 = (info_v >> 16) & 0x7ffu;
+            const uint32_t n0 = (info_v >> 18) & 0x7ffu;
             uint32_t len = 1u, total = n0, c1 = 127u, c2 = 127u, c3 = 127u;
             const unsigned long long sm = __ballot((info_v >> 31) != 0u);
             if (sm & (sm >> 1)) {
@@ -562,7 +562,7 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
                     return (p & 0xffu) > ((q >> 16) & 0xffu) || ((p >> 16) & 0xffu) < (q & 0xffu) ||
                            ((p >> 8) & 0xffu) > (q >> 24) || (p >> 24) < ((q >> 8) & 0xffu);
                 };
-                const uint32_t n1 = (m1.y >> 16) & 0x7ffu, n2 = (m2.y >> 16) & 0x7ffu, n3 = (m3.y >> 16) & 0x7ffu;
+                const uint32_t n1 = (m1.y >> 18) & 0x7ffu, n2 = (m2.y >> 18) & 0x7ffu, n3 = (m3.y >> 18) & 0x7ffu;
                 const bool ok1 = (info_v >> 31) != 0u && lane + 1 < nh && (m1.y >> 31) != 0u && n0 + n1 <= 64u && apart(box_v, m1.x);
                 const bool ok2 = ok1 && lane + 2 < nh && (m2.y >> 31) != 0u && n0 + n1 + n2 <= 64u && apart(box_v, m2.x) && apart(m1.x, m2.x);
                 const bool ok3 = ok2 && lane + 3 < nh && (m3.y >> 31) != 0u && n0 + n1 + n2 + n3 <= 64u &&
@@ -596,27 +596,27 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
                 idx0_f = (float)(lane - st);
                 limit_f = (float)((int)((run >> 3) & 127u) - st);         // lane < total <=> lane - st < total - st
                 npass = 1;
-                rf = recf + (int)(m.y & 0xffu) * REC_WORDS;
+                rf = recf + (int)(m.y & 0x3fu) * REC_WORDS;
                 flags = FLAG_RECT | FLAG_HAS_A | FLAG_HAS_B;
-                grad_log2 = hdr_grad(lds.rec[(int)(info & 0xffu) * REC_WORDS]);      // (the first member's: a hint only)
+                grad_log2 = (int)(info << 14) >> 26;                        // (the first member's: a hint only)
                 k += (int)(run & 7u);
             } else {
                 const uint32_t box = __builtin_amdgcn_readlane(box_v, k);
-                const int w = (int)((box >> 16) & 0xffu) - (int)(box & 0xffu) + 1, npix = (int)((info >> 16) & 0x7ffu);
+                const int w = (int)((box >> 16) & 0xffu) - (int)(box & 0xffu) + 1, npix = (int)((info >> 18) & 0x7ffu);
                 hx0f = (float)(box & 0xffu); hy0f = (float)((box >> 8) & 0xffu); wf = (float)w;
                 idx0_f = lane_f;
                 limit_f = (float)npix;
                 npass = (npix + 63) >> 6;
-                rf = recf + (int)(info & 0xffu) * REC_WORDS;
-                flags = (info >> 8) & 0x3fu;
-                grad_log2 = hdr_grad(lds.rec[(int)(info & 0xffu) * REC_WORDS]);
+                rf = recf + (int)(info & 0x3fu) * REC_WORDS;
+                flags = (info >> 6) & 0x3fu;
+                grad_log2 = (int)(info << 14) >> 26;
                 if ((flags & (FLAG_RECT | FLAG_PERSP_A | FLAG_PERSP_B)) != FLAG_RECT)
-                    ef = reinterpret_cast<const float*>(a.ext + (size_t)(base + (info & 0xffu)) * a.ext_bytes);
+                    ef = reinterpret_cast<const float*>(a.ext + (size_t)(base + (info & 0x3fu)) * a.ext_bytes);
                 k++;
             }
             if (TEX == 3) {
                 // the footprint copy of every texture slot for this primitive (uniform; unused slots fold away)
-                const int g = __builtin_amdgcn_readfirstlane(grad_log2);
+                const int g = grad_log2;
 #pragma unroll
                 for (int i = 0; i < RH_DEV_MAX_SLOTS; i++) fctx.poly[i].pick(p.slots[i], g);
             }

@@ -158,8 +158,18 @@ struct BindingContext {
     const rh_draw_params* p;
     uint32_t static_rgba8 = 0, static_filter = 0, static_poly = 0;
     PolyCopy poly[RH_DEV_MAX_SLOTS];     // (static_poly) per texture slot; slots a shader does not sample cost nothing
-    template <typename T> RH_DEVICE const T* storage(uint32_t set, uint32_t binding) const {
-        return reinterpret_cast<const T*>(p->slots[set * 4 + binding].ptr);
+    // A read-only storage buffer as an array of T.  An element that does not lie inside the bound buffer reads as
+    // zeros (what wgpu's robust buffer access guarantees at worst), so a draw with more instances than the buffer
+    // holds cannot touch memory outside it.
+    template <typename T> struct StorageView {
+        const T* data; uint32_t count;
+        // (an unconditional load from a clamped index, then a select: no branch around the load; every allocation of the
+        // library has spare bytes behind it, so element 0 of an empty buffer can be read)
+        RH_DEVICE T operator[](uint32_t i) const { T zero{}; const T v = data[i < count ? i : (count ? count - 1u : 0u)]; return i < count ? v : zero; }
+    };
+    template <typename T> RH_DEVICE StorageView<T> storage(uint32_t set, uint32_t binding) const {
+        const rh_slot_dev& s = p->slots[set * 4 + binding];
+        return StorageView<T>{ reinterpret_cast<const T*>(s.ptr), s.size_bytes / (uint32_t)sizeof(T) };
     }
     template <typename T> RH_DEVICE const T* uniform(uint32_t set, uint32_t binding) const {
         return reinterpret_cast<const T*>(p->slots[set * 4 + binding].ptr);

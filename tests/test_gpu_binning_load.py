@@ -165,5 +165,10 @@ def test_unset_and_oversized_instance_buffers_read_zeros(oracle):
         hs.draw()
         padded = dict(scene, instances=np.concatenate([scene["instances"], np.zeros((20, 2), dtype=np.float32)]))
         assert_same(hs.read_color(), scenes.draw_oracle(padded)["color"], "instances past the data read zeros")
+        # 300 instances: 44 of them past the END of the 2048-byte buffer (256 records): zeros as well, nothing outside is read
+        hs.count = (300, 4)
+        hs.draw()
+        padded = dict(scene, instances=np.concatenate([scene["instances"], np.zeros((200, 2), dtype=np.float32)]))
+        assert_same(hs.read_color(), scenes.draw_oracle(padded)["color"], "instances past the buffer read zeros")
     finally:
         r.close()

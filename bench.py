@@ -48,11 +48,13 @@ def capture_plan(n_ranks, dist, local_rank):
     """(frames, streams, untimed warm-up rounds, directory) per GPU for the recorded-frames/s leg.  The frames of the leg's
     scene hardly compress (about 28 MB each) and a GPU fills its stream files at more than 10 GB/s, which no disk of the
     box takes: the files go to /dev/shm (memory) when it exists, else to /tmp.  Every rank also pins up to two host
-    buffers of one round's bytes.  The largest plan is taken that leaves half of the available memory (and of the free
-    disk space, if the files go there) untouched with all ranks of the host running it; the ranks settle on the most
+    buffers of one round's bytes.  The largest plan is taken that leaves three tenths of the available memory (and of the
+    free disk space, if the files go there) untouched with all ranks of the host running it; the ranks settle on the most
     careful choice.  (1024 streams: four wavefronts per CU, one per SIMD.)"""
     import shutil
-    plans = [(2048, 1024, 1), (1024, 512, 1), (512, 256, 2), (256, 256, 1), (128, 128, 1)]
+    # (four timed rounds of 1024: a round is compressed while the next one is rendered, so the first and the last round
+    # of a run are not overlapped with anything, and a run of two rounds is mostly fill and drain)
+    plans = [(4096, 1024, 1), (2048, 1024, 1), (1024, 512, 1), (512, 256, 2), (256, 256, 1), (128, 128, 1)]
     frame_bytes = 30e6
     in_memory = os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK)
     root = "/dev/shm" if in_memory else "/tmp"
@@ -69,7 +71,7 @@ def capture_plan(n_ranks, dist, local_rank):
     for i, (frames, streams, rounds) in enumerate(plans):
         files = n_ranks * max(frames, rounds * streams) * frame_bytes             # warm-up bytes are dropped before the timed frames
         pinned = n_ranks * 2 * streams * frame_bytes * 1.25
-        if files <= 0.5 * disk and pinned + (files if in_memory else 0) <= 0.5 * ram:
+        if files <= 0.7 * disk and pinned + (files if in_memory else 0) <= 0.7 * ram:
             choice = i
             break
     if dist is not None:
@@ -102,7 +104,7 @@ def main():
     ap.add_argument("--filter", choices=["linear", "nearest"], default="linear", help="experiment: sampler filter (headline: linear)")
     ap.add_argument("--capture-frames", type=int, default=-1,
                     help="frames of the recorded-frames/s leg (BASELINE.json configs[4] shape, per GPU); 0 skips it; "
-                         "default: 2048 frames into 1024 streams, or less when the ranks of this host would not find "
+                         "default: 4096 frames into 1024 streams, or less when the ranks of this host would not find "
                          "room for their stream files and their pinned buffers in memory (see capture_plan)")
     ap.add_argument("--capture-streams", type=int, default=-1,
                     help="stream files per GPU; default 1024 (one wavefront per stream: four per compute unit; a round of up "

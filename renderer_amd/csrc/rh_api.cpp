@@ -94,6 +94,9 @@ struct rh_device {
     // allocation caches (exact-size reuse; capture buffers come and go every frame)
     std::multimap<size_t, void*> free_device, free_pinned;
     size_t free_device_bytes = 0, free_pinned_bytes = 0;
+    // freed device blocks kept for reuse: up to half of the device's memory (a recording run with a thousand streams has
+    // two thousand capture buffers of 33 MB coming and going; hipFree waits for every kernel on the device)
+    size_t device_cache_max_bytes = (size_t)48 << 30;
     std::vector<rh_buffer*> pending_maps;
     rh_pass_stats stats{};
     // optional per-pass HIP-event timing
@@ -181,7 +184,6 @@ struct rh_cmdbuf { rh_device* dev = nullptr; std::vector<Cmd> cmds; };
 namespace {
 
 constexpr size_t RH_CACHE_MAX_BLOCKS = 4096;
-constexpr size_t RH_DEVICE_CACHE_MAX_BYTES = (size_t)48 << 30;      // of 288 GB
 constexpr size_t RH_PINNED_CACHE_MAX_BYTES = (size_t)8 << 30;
 
 void device_retain(rh_device* dev) { dev->refs.fetch_add(1); }
@@ -199,7 +201,7 @@ void device_free(rh_device* dev, size_t size, void* p) {
     // Freed blocks wait for the next request of the same size (hipFree waits for the whole device and hipMalloc of a 4K
     // frame takes about a millisecond: a recording run with hundreds of capture buffers in flight would pay both per
     // frame).  The cache is bounded in blocks and in bytes.
-    if (dev->free_device.size() < RH_CACHE_MAX_BLOCKS && dev->free_device_bytes + size <= RH_DEVICE_CACHE_MAX_BYTES) {
+    if (dev->free_device.size() < RH_CACHE_MAX_BLOCKS && dev->free_device_bytes + size <= dev->device_cache_max_bytes) {
         dev->free_device.emplace(size, p); dev->free_device_bytes += size;
     } else (void)hipFree(p);
 }
@@ -257,6 +259,7 @@ int rh_device_create(int hip_ordinal, uint32_t width, uint32_t height, rh_device
     }
     dev->h_total[0] = 0; dev->h_total[1] = 0;
     dev->compute_units = (uint32_t)prop.multiProcessorCount;
+    dev->device_cache_max_bytes = (size_t)prop.totalGlobalMem / 2;
     dev->resident_sort_parts = rhk::sort_pass_resident_parts(dev->compute_units);
     if (rh_texture_create(dev, width, height, 1, RH_FORMAT_BGRA_U8, 1,
                           RH_TEXTURE_RENDER_ATTACHMENT | RH_TEXTURE_COPY_SRC | RH_TEXTURE_BINDING, &dev->screen)) { delete dev; return 1; }

@@ -160,9 +160,9 @@ def test_bench_capture_plan_shrinks_with_ranks_and_room(monkeypatch):
     plans = [bench.capture_plan(n, None, 0) for n in (1, 2, 4, 8)]
     assert all(p[3] == root for p in plans)
     if in_memory:
-        # one rank: 2048 frames of 30 MB in memory + two pinned rounds of 1024 = 138 GB of the 150 GB it may take
-        assert [p[:3] for p in plans] == [(2048, 1024, 1), (1024, 512, 1), (512, 256, 2), (128, 128, 1)]
+        # one rank: 4096 frames of 30 MB in memory + two pinned rounds of 1024 = 200 GB of the 210 GB it may take
+        assert [p[:3] for p in plans] == [(4096, 1024, 1), (1024, 512, 1), (512, 256, 2), (128, 128, 1)]
     else:
-        assert [p[:3] for p in plans] == [(2048, 1024, 1), (2048, 1024, 1), (1024, 512, 1), (512, 256, 2)]
+        assert [p[:3] for p in plans] == [(4096, 1024, 1), (2048, 1024, 1), (1024, 512, 1), (512, 256, 2)]
     monkeypatch.setattr(shutil, "disk_usage", lambda path: Usage(252e9, 251e9, 1e9))
     assert bench.capture_plan(1, None, 0)[:3] == (128, 128, 1)

@@ -51,14 +51,22 @@ def run_capture(frames=128, streams=64, quads=100_000, side=32, width=3840, heig
     r.start_recording([hs.pipeline], Renderer.clear_color(0., 0., 0., 1.), budget_mb, sink, keep_on_device=True)
     r.flush()
 
+    phases = {"animate": 0.0, "upload": 0.0, "render": 0.0, "finish_frame": 0.0}      # host seconds per part of a frame
+
     def step():
         nonlocal pos, vel
+        t_a = time.perf_counter()
         pos = (pos + vel).astype(np.float32)                       # the example's bounce rule, vectorised in f32
         outside = (pos > np.float32(0.9)) | (pos < np.float32(-0.9))
         vel = np.where(outside, -vel, vel).astype(np.float32)
+        t_b = time.perf_counter()
         r.set_instanced(hs.pipeline, (0, 0), pos)
+        t_c = time.perf_counter()
         r.render(hs.pipeline, hs.clear, hs.viewport, hs.count)
+        t_d = time.perf_counter()
         r.finish_frame()
+        t_e = time.perf_counter()
+        phases["animate"] += t_b - t_a; phases["upload"] += t_c - t_b; phases["render"] += t_d - t_c; phases["finish_frame"] += t_e - t_d
 
     for _ in range(2 * streams if warmup is None else warmup):
         step()
@@ -68,6 +76,8 @@ def run_capture(frames=128, streams=64, quads=100_000, side=32, width=3840, heig
         f.truncate(0)
         f.seek(0)
     t_compress[0] = 0.0
+    for key in phases:
+        phases[key] = 0.0
     raw0, packed0 = comp.raw_video_size, comp.compressed_size
     comp.drain_kernel_stats()
 
@@ -94,6 +104,7 @@ def run_capture(frames=128, streams=64, quads=100_000, side=32, width=3840, heig
             "workload": f"{quads} animated quads {side}x{side} px, {W}x{H}, recording attachment, GPU LZ4F level 0 into "
                         f"{streams} stream files per GPU",
             "compress_ms_per_frame": t_compress[0] / frames * 1e3, "kernel": kernel,
+            "host_ms_per_frame": {k: v / frames * 1e3 for k, v in phases.items()},
             "raw_MB_per_frame": raw / frames / 1e6, "compressed_MB_per_frame": packed / frames / 1e6}
     return elapsed, info, last
 
@@ -182,7 +193,7 @@ def main():
            "ms_per_frame": elapsed / args.frames * 1e3, "compress_ms_per_frame": info["compress_ms_per_frame"],
            "raw_MB_per_frame": info["raw_MB_per_frame"], "compressed_MB_per_frame": info["compressed_MB_per_frame"],
            "raw_GBps": info["raw_MB_per_frame"] * args.frames / elapsed / 1e3, "kernel": info["kernel"],
-           "frames_dropped": info["frames_dropped"]}
+           "host_ms_per_frame": info["host_ms_per_frame"], "frames_dropped": info["frames_dropped"]}
 
     if args.cpu_frames > 0:
         single, multi = liblz4_baseline(np.ascontiguousarray(last).tobytes(), args.cpu_frames)

@@ -209,6 +209,9 @@ __device__ uint32_t compress_block(Lds& L, const Ring& R, Stream& st, uint32_t n
                 asm volatile("" ::: "memory");
                 atomicMin(&table[h], (uint32_t)lane);
                 asm volatile("" ::: "memory");
+                // the four bytes at the table's candidate are asked for now: the read is under way during the rest of the
+                // election (a candidate inside the round needs no read: its bytes are that lane's own sequence)
+                const uint32_t old4 = R.rd32(old + bias);
                 const uint32_t leader = table[h];
                 asm volatile("" ::: "memory");
                 if (leader == (uint32_t)lane) table[h] = old;               // the table is as it was
@@ -221,13 +224,15 @@ __device__ uint32_t compress_block(Lds& L, const Ring& R, Stream& st, uint32_t n
                 // usually stops at or before f and the lanes behind it never matter.
                 const int f = repeats ? __builtin_ctzll(repeats) : 64;
                 const uint32_t from_leader = (uint32_t)__shfl((int)mine, (int)leader);          // all lanes take part
-                if (lane == f) mi = from_leader;
-                auto test = [&](uint32_t cand) {
-                    // (the ring read is unconditional: any address is inside the ring, the result only counts when in reach)
+                const uint32_t leader4 = (uint32_t)__shfl((int)seq, (int)leader);
+                uint32_t mi4 = old4;                                        // the four bytes at the candidate
+                if (lane == f) { mi = from_leader; mi4 = leader4; }
+                auto test = [&](uint32_t cand, uint32_t cand4) {
+                    // (the bytes were read unconditionally: the result only counts when the candidate is in reach)
                     const bool ok = !(dict_small && cand < prefix_idx_limit) && (cand + DISTANCE_MAX >= mine);
-                    return valid && tests && ok && R.rd32(cand + bias) == seq;
+                    return valid && tests && ok && cand4 == seq;
                 };
-                unsigned long long hits = __ballot(test(mi));
+                unsigned long long hits = __ballot(test(mi, mi4));
                 bool general = false;
                 if (repeats) {
                     const unsigned long long upto_f = f >= 63 ? ~0ull : (2ull << f) - 1ull;
@@ -245,9 +250,12 @@ __device__ uint32_t compress_block(Lds& L, const Ring& R, Stream& st, uint32_t n
                             losers &= ~group;
                         }
                         const unsigned long long prev = valid ? (same & below) : 0ull;
-                        const uint32_t from_lane = (uint32_t)__shfl((int)mine, prev ? 63 - __builtin_clzll(prev) : lane);   // all lanes take part
+                        const int prev_lane = prev ? 63 - __builtin_clzll(prev) : lane;
+                        const uint32_t from_lane = (uint32_t)__shfl((int)mine, prev_lane);      // all lanes take part
+                        const uint32_t lane4 = (uint32_t)__shfl((int)seq, prev_lane);
                         mi = prev ? from_lane : old;
-                        hits = __ballot(test(mi));
+                        mi4 = prev ? lane4 : old4;
+                        hits = __ballot(test(mi, mi4));
                     }
                 }
                 const int last_insert = hits ? __builtin_ctzll(hits) : first_invalid - 1;

@@ -35,6 +35,28 @@ typedef __attribute__((address_space(1))) const uint8_t g_cu8;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) const u32x4 g_cu32x4;
 
+#ifdef RH_LZ4_STAMPS        // diagnostic build (tools/probe_lz4.hip): cycles of a stream's wave per phase of a sequence, summed over all streams
+__device__ unsigned long long rh_lz4_stamp_acc[16];
+struct Stamps {
+    unsigned long long last, acc[8];
+    __device__ __forceinline__ void start() { last = __builtin_readcyclecounter(); for (int k = 0; k < 8; k++) acc[k] = 0; }
+    // `dep`: a value the phase ends with (the stamp is taken when it is there)
+    __device__ __forceinline__ void mark(int k, uint32_t dep) {
+        unsigned long long t;
+        asm volatile("s_nop 0 ; %1\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : "v"(dep) : "memory");
+        acc[k] += t - last; last = t;
+    }
+    __device__ __forceinline__ void flush(int lane) { if (lane == 0) for (int k = 0; k < 8; k++) atomicAdd(&rh_lz4_stamp_acc[k], acc[k]); }
+};
+#define RH_STAMP(k, dep) stamps.mark(k, (uint32_t)(dep))
+#define RH_STAMP_ARG , Stamps& stamps
+#define RH_STAMP_PASS , stamps
+#else
+#define RH_STAMP(k, dep)
+#define RH_STAMP_ARG
+#define RH_STAMP_PASS
+#endif
+
 constexpr uint32_t KB64 = 65536u;
 constexpr int MINMATCH = 4, LASTLITERALS = 5, MFLIMIT = 12, LZ4_MINLENGTH = MFLIMIT + 1;
 constexpr int HASHLOG = 12;
@@ -49,9 +71,32 @@ constexpr uint32_t CUR = KB64;                // virtual offset of the current b
 // block precedes the current one in the source), or the end of the stream's saved dictionary for the first block of a
 // write.  Lanes read unconditionally and mask afterwards, so offsets are clamped to the 64 KiB before the block and
 // the few bytes behind it that every source buffer is padded with.
+constexpr uint32_t WIN = 4096u, WIN_DWORDS = WIN / 4u, WIN_CHUNK = 1024u;
 struct Lds {
     uint32_t hash[(1 << HASHLOG) + 64];       // + one private slot per lane: lanes past the end of the walk go there,
-};                                            //   so every lane runs the table protocol and no step needs a lane mask
+                                              //   so every lane runs the table protocol and no step needs a lane mask
+    // The bytes around the current position of a block whose history precedes it in the same source: the byte at
+    // virtual offset v at index v mod 4 KiB.  What the search reads of the block itself (the sequences at the walk's
+    // positions, literal runs, the bytes around a nearby match) comes from here at LDS latency; only candidates further
+    // back are read from memory.  The first two dwords are repeated behind the end, so that an unaligned read takes the
+    // dwords i, i+1, i+2 without wrapping.
+    uint32_t win[WIN_DWORDS + 2];
+};
+static_assert(CUR % WIN == 0, "a virtual offset's place in the window is its low bits");
+
+struct Window {
+    const uint32_t* w;
+    __device__ __forceinline__ uint32_t rd32(uint32_t v) const {
+        const uint32_t i = (v >> 2) & (WIN_DWORDS - 1u);
+        return __builtin_amdgcn_alignbyte(w[i + 1u], w[i], v & 3u);
+    }
+    __device__ __forceinline__ uint64_t rd64(uint32_t v) const {
+        const uint32_t i = (v >> 2) & (WIN_DWORDS - 1u), s = v & 3u;
+        const uint32_t x = w[i], y = w[i + 1u], z = w[i + 2u];
+        return (uint64_t)__builtin_amdgcn_alignbyte(y, x, s) | ((uint64_t)__builtin_amdgcn_alignbyte(z, y, s) << 32);
+    }
+    __device__ __forceinline__ uint32_t byte(uint32_t v) const { return reinterpret_cast<const uint8_t*>(w)[v & (WIN - 1u)]; }
+};
 
 constexpr uint32_t READ_SLACK = 16;           // bytes behind the end of a source that may be read (and are ignored)
 
@@ -76,6 +121,12 @@ struct Ring {
         return x;
     }
     __device__ __forceinline__ uint32_t byte(uint32_t v) const { return *at(v); }
+    // sixteen bytes of the block's own source with one load (hist == cur); they may end READ_SLACK bytes past the block
+    __device__ __forceinline__ u32x4 rd128(uint32_t v) const {
+        v = v < CUR - KB64 ? CUR - KB64 : (v > hi - 8u ? hi - 8u : v);
+        u32x4 x; __builtin_memcpy(&x, (const void*)(cur + (int32_t)(v - CUR)), 16);
+        return x;
+    }
     __device__ __forceinline__ uint32_t hash5(uint32_t v) const { return hash5_of(rd64(v)); }
     // LZ4_hash5: ((sequence << 24) * 889523592379) >> (64 - HASHLOG), i.e. bits 28..39 of x * P for the five low bytes x
     // of the sequence.  With x = a + b * 2^32 and P = p0 + p1 * 2^32 those bits need one 32x32 product (both halves) and two
@@ -111,7 +162,8 @@ __device__ __forceinline__ uint32_t count_match(const Ring& R, uint32_t ip, uint
 
 // Cooperative copy of n bytes from the ring (virtual offset v) to global memory: bytes up to the first 4-byte boundary
 // of dst, then whole dwords, then the tail.
-__device__ __forceinline__ void copy_out(g_u8* dst, const Ring& R, uint32_t v, uint32_t n, int lane) {
+template <class Src>
+__device__ __forceinline__ void copy_out(g_u8* dst, const Src& R, uint32_t v, uint32_t n, int lane) {
     if (n <= 64u) {                                   // the usual literal run: one byte per lane
         if ((uint32_t)lane < n) dst[lane] = (uint8_t)R.byte(v + (uint32_t)lane);
         return;
@@ -376,6 +428,307 @@ last_literals:
     return op;
 }
 
+// Backward catch-up and match length of a match the short form could not decide, from memory: the bytes before ip and
+// match and the dwords behind the four matching bytes are asked for together, then 64 / 256 bytes per step.  Every load
+// is consumed in here.
+__device__ __noinline__ uint2 long_match(const Ring& R, uint32_t ip, uint32_t match, uint32_t anchor, uint32_t low_limit, uint32_t matchlimit,
+                                         bool immediate, int lane) {
+    const uint32_t fwd_ip = ip + MINMATCH, fwd_match = match + MINMATCH;
+    const uint32_t cu_a = R.byte(ip - 1u - (uint32_t)lane), cu_b = R.byte(match - 1u - (uint32_t)lane);
+    const uint32_t cm_a = R.rd32(fwd_ip + (uint32_t)lane * 4u), cm_b = R.rd32(fwd_match + (uint32_t)lane * 4u);
+    uint32_t caught_up = 0, fwd;
+    if (!immediate)
+        for (bool first = true; ip > anchor; first = false) {
+            const uint32_t d = (uint32_t)lane + 1u;
+            const bool room = (int32_t)(ip - anchor) >= (int32_t)d && (int32_t)(match - low_limit) >= (int32_t)d;
+            const bool equal = first ? cu_a == cu_b : R.byte(ip - d) == R.byte(match - d);      // (first: wave-uniform)
+            const unsigned long long stop = __ballot(!(room && equal));
+            const uint32_t c = stop ? (uint32_t)__builtin_ctzll(stop) : 64u;
+            ip -= c; match -= c; caught_up += c;
+            if (c < 64u) break;
+        }
+    {   const uint32_t q = fwd_ip + (uint32_t)lane * 4u;
+        uint32_t avail = q < matchlimit ? matchlimit - q : 0u; if (avail > 4u) avail = 4u;
+        const uint32_t x = cm_a ^ cm_b;
+        uint32_t same = x ? (uint32_t)__builtin_ctz(x) >> 3 : 4u;
+        if (same > avail) same = avail;
+        const unsigned long long stop = __ballot(same < 4u);
+        if (stop) { const int first = __builtin_ctzll(stop); fwd = (uint32_t)first * 4u + (uint32_t)__builtin_amdgcn_readlane((int)same, first); }
+        else fwd = count_match(R, fwd_ip, fwd_match, matchlimit, lane, 256u);
+    }
+    return make_uint2(caught_up, fwd);
+}
+
+// compress_block for a block whose history lies before it in the same source (every block of a write but the first:
+// the withPrefix64k rules).  What the search reads of the block itself comes from the window in LDS, which follows the
+// position a kilobyte at a time; the chunk behind it is always on its way, so the sequential reads cost LDS latency.
+// With the test's four bytes a lane brings the sixteen bytes from four before its table candidate: a match whose
+// candidate came from the table, or lies inside the window, and that is short (as nearly all are in rendered frames:
+// backwards at most three bytes, forwards at most seven behind the first four) is decided without a trip to memory.
+__device__ uint32_t compress_block_w(Lds& L, const Ring& R, Stream& st, uint32_t n, g_u8* out, uint32_t max_out, bool dict_small, int lane RH_STAMP_ARG) {
+    const uint32_t start_index = st.current_offset;
+    const uint32_t dict_size = st.dict_size;
+    const uint32_t bias = CUR - start_index;
+    const uint32_t prefix_idx_limit = start_index - dict_size;
+    const uint32_t low_limit = CUR - (dict_size < KB64 ? dict_size : KB64);
+    const uint32_t iend = CUR + n;
+    const uint32_t mflimit_plus_one = iend - MFLIMIT + 1;
+    const uint32_t matchlimit = iend - LASTLITERALS;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const unsigned long long above = ~((2ull << lane) - 1ull);
+    uint32_t ip = CUR, anchor = CUR;
+    uint32_t op = 0;
+    uint32_t match = 0, token_pos = 0, token = 0;
+    uint32_t pre = 1;
+    uint32_t* const table = L.hash;
+    const Window W{L.win};
+
+    // The window holds [max(w_filled - WIN, w_start), w_filled); the chunk behind w_filled was asked for when the chunk
+    // before it was stored.
+    uint32_t w_filled = CUR, w_start = CUR;
+    u32x4 w_next;
+    auto w_load = [&](uint32_t from) -> u32x4 {
+        uint32_t v = from + (uint32_t)lane * 16u;
+        if (v > iend) v = iend;                                             // (a source is readable READ_SLACK bytes past its end)
+        u32x4 x; __builtin_memcpy(&x, (const void*)(R.cur + (int32_t)(v - CUR)), 16);
+        return x;
+    };
+    auto w_store = [&](uint32_t from, const u32x4& x) {
+        const uint32_t i = ((from & (WIN - 1u)) >> 2) + (uint32_t)lane * 4u;
+        *reinterpret_cast<u32x4*>(&L.win[i]) = x;
+        if (i == 0u) { L.win[WIN_DWORDS] = x.x; L.win[WIN_DWORDS + 1u] = x.y; }
+    };
+    // makes [lo, hi) readable from the window (hi - lo <= WIN - WIN_CHUNK)
+    auto w_cover = [&](uint32_t lo, uint32_t hi) {
+        if (hi > iend + READ_SLACK) hi = iend + READ_SLACK;
+        if (hi > w_filled + 2u * WIN_CHUNK) {
+            // far ahead (a long match, or a walk with long steps): the whole window from lo's chunk on, in one trip
+            const uint32_t base = lo & ~(WIN_CHUNK - 1u);
+            const u32x4 a = w_load(base), b = w_load(base + WIN_CHUNK), c = w_load(base + 2u * WIN_CHUNK), d = w_load(base + 3u * WIN_CHUNK);
+            w_store(base, a); w_store(base + WIN_CHUNK, b); w_store(base + 2u * WIN_CHUNK, c); w_store(base + 3u * WIN_CHUNK, d);
+            w_start = base; w_filled = base + WIN;
+            w_next = w_load(w_filled);
+        }
+        while (w_filled < hi) {
+            w_store(w_filled, w_next);
+            w_filled += WIN_CHUNK;
+            w_next = w_load(w_filled);
+        }
+        asm volatile("" ::: "memory");
+    };
+    w_next = w_load(CUR);
+
+    st.dict_size += n;
+    st.current_offset += n;
+
+    if ((int)n < LZ4_MINLENGTH) goto last_literals;
+
+    for (;;) {
+        // ---- match search (see compress_block): 64 steps of the sequential walk per round
+        bool found = false, immediate = false, near = false, from_table = false;
+        uint32_t c_back = 0, c_lo = 0, c_hi = 0;
+        {   const uint32_t w0 = ip + 1u;
+            for (uint32_t r0 = 0; ; r0 += 64u) {
+                uint32_t p, lo, hi; bool valid, tests;
+                if (r0 == 0u) {
+                    // the first `pre` lanes take the positions that come before the walk: [the block's first position]
+                    // or [insert ip - 2; test-and-insert ip]; the walk's first 65 steps advance by one
+                    const bool special = (uint32_t)lane < pre;
+                    const uint32_t pw = w0 + (uint32_t)lane - pre;
+                    p = special ? ((pre == 2u && lane == 0) ? ip - 2u : ip) : pw;
+                    valid = special || pw + 1u <= mflimit_plus_one;
+                    tests = !special || (pre == 2u && lane == 1);
+                    lo = ip - 8u; hi = w0 + 64u + 16u;
+                } else {
+                    const uint32_t k = r0 + (uint32_t)lane - pre;
+                    p = w0 + walk(k); valid = w0 + walk(k + 1u) <= mflimit_plus_one; tests = true;
+                    lo = w0 + walk(r0 - pre) - 8u; hi = w0 + walk(r0 + 64u - pre) + 16u;
+                }
+                w_cover(lo, hi);
+                const unsigned long long vm = __ballot(valid);
+                const uint64_t s8 = W.rd64(p);
+                const uint32_t seq = (uint32_t)s8;
+                // (every lane hashes, so that the window reads are not split by a branch around the hash)
+                uint32_t hashed = Ring::hash5_of(s8);
+                asm volatile("" : "+v"(hashed));
+                const uint32_t h = valid ? hashed : (uint32_t)(1 << HASHLOG) + (uint32_t)lane;
+                const uint32_t mine = p - bias;
+                RH_STAMP(0, h);
+                const uint32_t old = table[h];
+                table[h] = 0xffffffffu;
+                asm volatile("" ::: "memory");
+                atomicMin(&table[h], (uint32_t)lane);
+                asm volatile("" ::: "memory");
+                // the bytes around the table's candidate are asked for now: the read is under way during the rest of the
+                // election (a candidate within four bytes of the history's start has no bytes before it)
+                const uint32_t cv = old + bias;
+                const bool cand_edge = cv < CUR - KB64 + 4u;
+                const u32x4 cand16 = R.rd128(cand_edge ? cv : cv - 4u);
+                const uint32_t leader = table[h];
+                asm volatile("" ::: "memory");
+                if (leader == (uint32_t)lane) table[h] = old;
+                const unsigned long long repeats = __ballot(leader != (uint32_t)lane);
+                const int first_invalid = (~vm) ? __builtin_ctzll(~vm) : 64;
+                uint32_t mi = old;
+                unsigned long long same = 1ull << lane;
+                const int f = repeats ? __builtin_ctzll(repeats) : 64;
+                const uint32_t from_leader = (uint32_t)__shfl((int)mine, (int)leader);
+                const uint32_t leader4 = (uint32_t)__shfl((int)seq, (int)leader);
+                uint32_t mi4 = cand_edge ? cand16.x : cand16.y;
+                if (lane == f) { mi = from_leader; mi4 = leader4; }
+                auto test = [&](uint32_t cand, uint32_t cand4) {
+                    const bool ok = !(dict_small && cand < prefix_idx_limit) && (cand + DISTANCE_MAX >= mine);
+                    return valid && tests && ok && cand4 == seq;
+                };
+                unsigned long long hits = __ballot(test(mi, mi4));
+                RH_STAMP(1, (uint32_t)hits | (uint32_t)(hits >> 32));
+                bool general = false;
+                if (repeats) {
+                    const unsigned long long upto_f = f >= 63 ? ~0ull : (2ull << f) - 1ull;
+                    if (hits & upto_f) hits &= upto_f;
+                    else {
+                        general = true;
+                        unsigned long long losers = repeats;
+                        while (losers) {
+                            const uint32_t hl = (uint32_t)__builtin_amdgcn_readlane((int)h, __builtin_ctzll(losers));
+                            const bool in_group = valid && h == hl;
+                            const unsigned long long group = __ballot(in_group);
+                            if (in_group) same = group;
+                            losers &= ~group;
+                        }
+                        const unsigned long long prev = valid ? (same & below) : 0ull;
+                        const int prev_lane = prev ? 63 - __builtin_clzll(prev) : lane;
+                        const uint32_t from_lane = (uint32_t)__shfl((int)mine, prev_lane);
+                        const uint32_t lane4 = (uint32_t)__shfl((int)seq, prev_lane);
+                        if (prev) { mi = from_lane; mi4 = lane4; } else { mi = old; mi4 = cand_edge ? cand16.x : cand16.y; }
+                        hits = __ballot(test(mi, mi4));
+                    }
+                }
+                const int last_insert = hits ? __builtin_ctzll(hits) : first_invalid - 1;
+                if (general) {
+                    const unsigned long long inserting = last_insert < 0 ? 0ull : (last_insert >= 63 ? ~0ull : (2ull << last_insert) - 1ull);
+                    if (valid && lane <= last_insert && (same & above & inserting) == 0ull) table[h] = mine;
+                } else {
+                    const uint32_t leader_of_f = (uint32_t)__builtin_amdgcn_readlane((int)leader, f < 64 ? f : 0);
+                    const bool shadowed = f <= last_insert && (uint32_t)lane == leader_of_f;
+                    if (valid && lane <= last_insert && !shadowed) table[h] = mine;
+                }
+                RH_STAMP(2, last_insert);
+                if (hits) {
+                    const int e = __builtin_ctzll(hits);
+                    ip = (uint32_t)__builtin_amdgcn_readlane((int)p, e);
+                    const uint32_t match_index = (uint32_t)__builtin_amdgcn_readlane((int)mi, e);
+                    match = match_index + bias;
+                    found = true;
+                    immediate = (pre == 2u && r0 == 0u && e == 1);
+                    // where the bytes around the candidate are: in the window, or in the registers of the lane that hit
+                    const uint32_t held = w_filled - w_start > WIN ? w_filled - WIN : w_start;
+                    near = match >= held + 4u;
+                    from_table = match_index == (uint32_t)__builtin_amdgcn_readlane((int)old, e) && __builtin_amdgcn_readlane((int)cand_edge, e) == 0;
+                    c_back = (uint32_t)__builtin_amdgcn_readlane((int)cand16.x, e);
+                    c_lo = (uint32_t)__builtin_amdgcn_readlane((int)cand16.z, e);
+                    c_hi = (uint32_t)__builtin_amdgcn_readlane((int)cand16.w, e);
+                    break;
+                }
+                if (first_invalid < 64) break;
+            }
+        }
+        if (!found) goto last_literals;
+        // ---- lengths
+        uint32_t caught_up = 0, fwd = 0;
+        bool decided = false;
+        const uint32_t lit_byte = W.byte(anchor + (uint32_t)lane);          // (used when the run is short and inside the window)
+        if (near || from_table) {
+            const uint32_t cur_back = W.rd32(ip - 4u);
+            const uint64_t cur_fwd = W.rd64(ip + MINMATCH);
+            if (near) { c_back = W.rd32(match - 4u); const uint64_t c = W.rd64(match + MINMATCH); c_lo = (uint32_t)c; c_hi = (uint32_t)(c >> 32); }
+            bool more = false;
+            uint32_t back = 0;
+            if (!immediate) {
+                const int32_t ra = (int32_t)(ip - anchor), rb = (int32_t)(match - low_limit);
+                const uint32_t room = (uint32_t)(ra < rb ? (ra < 0 ? 0 : ra) : (rb < 0 ? 0 : rb));
+                const uint32_t x = cur_back ^ c_back;
+                back = x ? (uint32_t)__builtin_clz(x) >> 3 : 4u;
+                if (back >= room) back = room; else if (back == 4u) more = true;
+            }
+            const uint64_t y = cur_fwd ^ ((uint64_t)c_lo | ((uint64_t)c_hi << 32));
+            uint32_t fw = y ? (uint32_t)__builtin_ctzll(y) >> 3 : 8u;
+            const uint32_t avail = matchlimit - (ip + MINMATCH);
+            if (fw >= avail) fw = avail; else if (fw == 8u) more = true;
+            if (!more) { decided = true; caught_up = back; fwd = fw; }
+        }
+        RH_STAMP(3, fwd + caught_up + lit_byte);
+        if (!decided) {
+            // (what a function returns counts as different from lane to lane: say that it is not)
+            const uint2 r = long_match(R, ip, match, anchor, low_limit, matchlimit, immediate, lane);
+            caught_up = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.x); fwd = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.y);
+        }
+        ip -= caught_up; match -= caught_up;
+        RH_STAMP(4, caught_up + fwd);
+        // ---- the sequence: token, literal run, offset, match length
+        if (immediate) { token_pos = op++; token = 0; }
+        else {
+            const uint32_t lit = ip - anchor;
+            token_pos = op++;
+            if (op + lit + (2 + 1 + LASTLITERALS) + lit / 255 > max_out) return 0;
+            if (lit >= RUN_MASK) {
+                uint32_t len = lit - RUN_MASK;
+                token = RUN_MASK << 4;
+                const uint32_t n255 = len / 255u;
+                for (uint32_t i = (uint32_t)lane; i < n255; i += 64u) out[op + i] = 255;
+                op += n255;
+                if (lane == 0) out[op] = (uint8_t)(len - n255 * 255u);
+                op++;
+            } else token = lit << 4;
+            // (a hit far along the walk leaves the anchor behind the window, however short the run after the catch-up)
+            const uint32_t held = w_filled - w_start > WIN ? w_filled - WIN : w_start;
+            if (anchor < held) copy_out(out + op, R, anchor, lit, lane);
+            else if (lit <= 64u) { if ((uint32_t)lane < lit) out[op + lane] = (uint8_t)lit_byte; }
+            else copy_out(out + op, W, anchor, lit, lane);
+            op += lit;
+        }
+        {   const uint32_t offset = ip - match;
+            if (lane == 0) { out[op] = (uint8_t)offset; out[op + 1] = (uint8_t)(offset >> 8); }
+            op += 2;
+        }
+        {   uint32_t match_code = caught_up + fwd;
+            ip += match_code + MINMATCH;
+            if (op + (1 + LASTLITERALS) + (match_code + 240) / 255 > max_out) return 0;
+            if (match_code >= ML_MASK) {
+                token += ML_MASK;
+                match_code -= ML_MASK;
+                const uint32_t n255 = match_code / 255u;
+                for (uint32_t i = (uint32_t)lane; i < n255; i += 64u) out[op + i] = 255;
+                op += n255;
+                if (lane == 0) out[op] = (uint8_t)(match_code - n255 * 255u);
+                op++;
+            } else token += match_code;
+            if (lane == 0) out[token_pos] = (uint8_t)token;
+        }
+        anchor = ip;
+        RH_STAMP(5, ip);
+        if (ip >= mflimit_plus_one) break;
+        pre = 2;
+    }
+last_literals:
+    {   const uint32_t last_run = iend - anchor;
+        if (op + last_run + 1 + ((last_run + 255 - RUN_MASK) / 255) > max_out) return 0;
+        if (last_run >= RUN_MASK) {
+            uint32_t acc = last_run - RUN_MASK;
+            if (lane == 0) out[op] = (uint8_t)(RUN_MASK << 4);
+            op++;
+            const uint32_t n255 = acc / 255u;
+            for (uint32_t i = (uint32_t)lane; i < n255; i += 64u) out[op + i] = 255;
+            op += n255;
+            if (lane == 0) out[op] = (uint8_t)(acc - n255 * 255u);
+            op++;
+        } else { if (lane == 0) out[op] = (uint8_t)(last_run << 4); op++; }
+        copy_out(out + op, R, anchor, last_run, lane);
+        op += last_run;
+    }
+    return op;
+}
+
 } // namespace
 
 // One workgroup (one wave) per job.  A job is a sequence of writes to one stream; every write is one
@@ -399,6 +752,9 @@ extern "C" __global__ __launch_bounds__(64) void rh_lz4f_compress(const rh_lz4_j
 
     g_u8* out = (g_u8*)job.out;
     uint64_t op = 0;
+#ifdef RH_LZ4_STAMPS
+    Stamps stamps; stamps.start();
+#endif
     for (uint32_t wi = 0; wi < job.n_writes; wi++) {
         g_cu8* src = (g_cu8*)job.write_ptr[wi];
         const uint64_t size = job.write_len[wi];
@@ -428,7 +784,9 @@ extern "C" __global__ __launch_bounds__(64) void rh_lz4f_compress(const rh_lz4_j
             const bool ext = first_block;
             g_u8* blk = out + op;
             Stream before = st;
-            uint32_t c = compress_block(L, R, st, n, blk + 4, n - 1, ext, small, lane);
+            RH_STAMP(6, n);
+            uint32_t c = first_block ? compress_block(L, R, st, n, blk + 4, n - 1, ext, small, lane)
+                                     : compress_block_w(L, R, st, n, blk + 4, n - 1, small, lane RH_STAMP_PASS);
             if (c == 0) { st = before; st.dict_size += n; st.current_offset += n; }      // state advances even when the block is stored
             if (ext) st.dict_size = n;                      // external-dictionary mode: the block becomes the new dictionary
             __syncthreads();
@@ -454,6 +812,9 @@ extern "C" __global__ __launch_bounds__(64) void rh_lz4f_compress(const rh_lz4_j
         }
     }
 
+#ifdef RH_LZ4_STAMPS
+    stamps.mark(6, 0u); stamps.flush(lane);
+#endif
     // persist the stream state (the dictionary is already in place)
     __syncthreads();
     for (int i = lane; i < (1 << HASHLOG); i += 64) S.hash[i] = L.hash[i];

@@ -16,7 +16,8 @@ def test_random_scenes_match_the_oracle(oracle, first_seed):
 
 def test_random_lz4_streams_match_liblz4(oracle):
     import fuzz_codec
-    for seed in range(5):
+    # (91016: a match found far along the walk whose backward catch-up leaves a short literal run)
+    for seed in list(range(5)) + [91016]:
         err = fuzz_codec.run_round(seed)
         assert err is None, f"seed {seed}: {err}"
 

@@ -5,10 +5,14 @@
 // (reference src/compressor.rs:88-144, via the lzzzz crate = liblz4): preferences level 0, auto-flush, block-linked,
 // 64 KiB blocks, no checksums; every Write::write_all is one LZ4F_compressUpdate.  A stream's bytes depend only on its
 // own write sequence, so streams are independent: each stream's state (hash table, 64 KiB dictionary, offsets) lives
-// in device memory and one wavefront replays the LZ4 "fast" algorithm for its stream.  Only the hash table (16 KiB) is
-// held in LDS; the bytes of the block and of the 64 KiB of history before it are read where they are, in the captured
-// frame (through L1/L2), so a CU holds as many streams as it has room for wavefronts and hash tables (eight) instead of
-// one, and the latencies of one stream's dependent steps are filled by the others.
+// in device memory and one wavefront replays the LZ4 "fast" algorithm for its stream.  LDS holds the hash table
+// (16 KiB), fifteen bits of the sequence behind every table entry (8 KiB) and a 4 KiB window of the block around the
+// current position; the 64 KiB of history are read where they are, in the captured frame (through L1/L2), so a CU
+// holds four or five streams instead of one.  A wavefront alone on its SIMD issues one instruction every four or five
+// cycles whatever the instruction is, so what a sequence costs is the number of instructions on its path and the
+// round trips it waits for: the usual sequence (a short run of literals, a match found in the first round of the walk
+// whose candidate lies in the window) takes one straight piece of code with LDS reads only; everything else takes the
+// general code.
 //
 // The match search of LZ4 is a sequential walk (position, hash, table look-up, table insert, compare, advance by a
 // step that grows with the number of misses).  The walk without a match is known in advance, so the 64 lanes evaluate
@@ -36,17 +40,17 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) const u32x4 g_cu32x4;
 
 #ifdef RH_LZ4_STAMPS        // diagnostic build (tools/probe_lz4.hip): cycles of a stream's wave per phase of a sequence, summed over all streams
-__device__ unsigned long long rh_lz4_stamp_acc[16];
+__device__ unsigned long long rh_lz4_stamp_acc[24];
 struct Stamps {
-    unsigned long long last, acc[8];
-    __device__ __forceinline__ void start() { last = __builtin_readcyclecounter(); for (int k = 0; k < 8; k++) acc[k] = 0; }
+    unsigned long long last, acc[12]; unsigned cnt[12];
+    __device__ __forceinline__ void start() { last = __builtin_readcyclecounter(); for (int k = 0; k < 12; k++) { acc[k] = 0; cnt[k] = 0; } }
     // `dep`: a value the phase ends with (the stamp is taken when it is there)
     __device__ __forceinline__ void mark(int k, uint32_t dep) {
         unsigned long long t;
         asm volatile("s_nop 0 ; %1\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : "v"(dep) : "memory");
-        acc[k] += t - last; last = t;
+        acc[k] += t - last; last = t; cnt[k]++;
     }
-    __device__ __forceinline__ void flush(int lane) { if (lane == 0) for (int k = 0; k < 8; k++) atomicAdd(&rh_lz4_stamp_acc[k], acc[k]); }
+    __device__ __forceinline__ void flush(int lane) { if (lane == 0) for (int k = 0; k < 12; k++) { atomicAdd(&rh_lz4_stamp_acc[k], acc[k]); atomicAdd(&rh_lz4_stamp_acc[12 + k], (unsigned long long)cnt[k]); } }
 };
 #define RH_STAMP(k, dep) stamps.mark(k, (uint32_t)(dep))
 #define RH_STAMP_ARG , Stamps& stamps
@@ -75,6 +79,10 @@ constexpr uint32_t WIN = 4096u, WIN_DWORDS = WIN / 4u, WIN_CHUNK = 1024u;
 struct Lds {
     uint32_t hash[(1 << HASHLOG) + 64];       // + one private slot per lane: lanes past the end of the walk go there,
                                               //   so every lane runs the table protocol and no step needs a lane mask
+    // Beside every table entry, fifteen bits of the four bytes at its position (0: the entry was never written).  A
+    // candidate whose bits differ from the position's own cannot match, so its bytes need not be read at all: the
+    // straight piece of the search reads the bytes of one candidate -- the first that can match -- instead of 64.
+    uint16_t tag[(1 << HASHLOG) + 64];
     // The bytes around the current position of a block whose history precedes it in the same source: the byte at
     // virtual offset v at index v mod 4 KiB.  What the search reads of the block itself (the sequences at the walk's
     // positions, literal runs, the bytes around a nearby match) comes from here at LDS latency; only candidates further
@@ -97,6 +105,8 @@ struct Window {
     }
     __device__ __forceinline__ uint32_t byte(uint32_t v) const { return reinterpret_cast<const uint8_t*>(w)[v & (WIN - 1u)]; }
 };
+
+__device__ __forceinline__ uint32_t tag_of(uint32_t seq) { return 0x8000u | ((seq * 2654435761u) >> 17); }
 
 constexpr uint32_t READ_SLACK = 16;           // bytes behind the end of a source that may be read (and are ignored)
 
@@ -314,12 +324,12 @@ __device__ uint32_t compress_block(Lds& L, const Ring& R, Stream& st, uint32_t n
                 // the inserts of the lanes up to the stop, in order: per hash value the last of them stays
                 if (general) {
                     const unsigned long long inserting = last_insert < 0 ? 0ull : (last_insert >= 63 ? ~0ull : (2ull << last_insert) - 1ull);
-                    if (valid && lane <= last_insert && (same & above & inserting) == 0ull) table[h] = mine;
+                    if (valid && lane <= last_insert && (same & above & inserting) == 0ull) { table[h] = mine; L.tag[h] = (uint16_t)tag_of(seq); }
                 } else {
                     // hashes are distinct among the lanes up to f, except f and its group's first lane
                     const uint32_t leader_of_f = (uint32_t)__builtin_amdgcn_readlane((int)leader, f < 64 ? f : 0);
                     const bool shadowed = f <= last_insert && (uint32_t)lane == leader_of_f;
-                    if (valid && lane <= last_insert && !shadowed) table[h] = mine;
+                    if (valid && lane <= last_insert && !shadowed) { table[h] = mine; L.tag[h] = (uint16_t)tag_of(seq); }
                 }
                 if (hits) {
                     const int e = __builtin_ctzll(hits);
@@ -524,11 +534,122 @@ __device__ uint32_t compress_block_w(Lds& L, const Ring& R, Stream& st, uint32_t
     if ((int)n < LZ4_MINLENGTH) goto last_literals;
 
     for (;;) {
+        // ---- The usual sequence in one straight piece of code: after a match, away from the block's end, the walk's first
+        // round [insert ip - 2; test-and-insert ip; ip + 1 ...] finds a hit that the lanes before the first repeated hash
+        // decide, the match is short, and the run before it fits one byte per lane.  Nothing is written (the election
+        // leaves the table as it was) until all of that is known; if any of it fails, the general code below does the
+        // sequence from the start.
+        bool committed = false;
+        uint32_t first_round = 0;
+        if (pre == 2u && ip + 400u <= mflimit_plus_one && op + 96u <= max_out) {
+            w_cover(ip - 8u, ip + 352u);
+            const uint32_t p = ip + (uint32_t)lane - (lane == 0 ? 2u : 1u);
+            const uint64_t s8 = W.rd64(p);
+            const uint32_t seq = (uint32_t)s8;
+            const uint32_t h = Ring::hash5_of(s8);
+            const uint32_t my_tag = tag_of(seq);
+            const uint32_t mine = p - bias;
+            const uint32_t old = table[h];
+            const uint32_t old_tag = L.tag[h];
+            table[h] = 0xffffffffu;
+            asm volatile("" ::: "memory");
+            atomicMin(&table[h], (uint32_t)lane);
+            asm volatile("" ::: "memory");
+            const uint32_t leader = table[h];
+            asm volatile("" ::: "memory");
+            if (leader == (uint32_t)lane) table[h] = old;
+            const unsigned long long repeats = __ballot(leader != (uint32_t)lane);
+            const int f = repeats ? __builtin_ctzll(repeats) : 64;
+            const uint32_t from_leader = (uint32_t)__shfl((int)mine, (int)leader);
+            const uint32_t leader4 = (uint32_t)__shfl((int)seq, (int)leader);
+            // lanes that can be the hit: the table's candidate is in reach and its bits are the position's own (or unknown);
+            // the first repeated hash's candidate is the lane that leads its group, whose bytes are at hand
+            uint32_t mi = old;
+            bool maybe = old_tag == my_tag || old_tag == 0u, sure = false;
+            if (lane == f) { mi = from_leader; maybe = sure = leader4 == seq; }
+            maybe = maybe && lane != 0 && !(dict_small && mi < prefix_idx_limit) && (mi + DISTANCE_MAX >= mine);
+            unsigned long long cands = __ballot(maybe);
+            if (f < 63) cands &= (2ull << f) - 1ull;                         // behind the first repeated hash nothing is known
+            const unsigned long long sure_mask = __ballot(sure);
+            const uint32_t held = w_filled - w_start > WIN ? w_filled - WIN : w_start;
+            RH_STAMP(7, (uint32_t)cands | (uint32_t)(cands >> 32));
+            while (cands) {
+                // the first of them: its candidate's bytes from four before it (window, or one read from memory)
+                const int e = __builtin_ctzll(cands);
+                const uint32_t ip_hit = ip + (uint32_t)e - 1u;
+                const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)mi, e) + bias;
+                uint32_t cb, c4; uint64_t cf;
+                if (m >= held + 4u) { cb = W.rd32(m - 4u); c4 = W.rd32(m); cf = W.rd64(m + MINMATCH); }
+                else if (m >= CUR - KB64 + 4u) {
+                    const u32x4 c16 = R.rd128(m - 4u);
+                    cb = c16.x; c4 = c16.y; cf = (uint64_t)c16.z | ((uint64_t)c16.w << 32);
+                } else break;                                               // (no bytes before the history's start: general code)
+                const uint32_t lit_byte = W.byte(ip + (uint32_t)lane);
+                const uint32_t cur_back = W.rd32(ip_hit - 4u);
+                const uint64_t cur_fwd = W.rd64(ip_hit + MINMATCH);
+                const uint32_t seq_e = (uint32_t)__builtin_amdgcn_readlane((int)seq, e);
+                if (!((sure_mask >> e) & 1ull) && (uint32_t)__builtin_amdgcn_readfirstlane((int)c4) != seq_e) { cands &= cands - 1ull; continue; }
+                cb = (uint32_t)__builtin_amdgcn_readfirstlane((int)(cb ^ cur_back));
+                const uint64_t y = cf ^ cur_fwd;
+                const uint32_t y_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)y), y_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(y >> 32));
+                // backwards: at most to the anchor and to the history's first byte; four equal bytes with room left
+                // mean that the catch-up goes on (general code); forwards likewise with eight (the block's end is far)
+                const int32_t ra = (int32_t)(ip_hit - ip), rb = (int32_t)(m - low_limit);
+                const uint32_t room = (uint32_t)(ra < rb ? ra : (rb < 0 ? 0 : rb));
+                uint32_t back = cb ? (uint32_t)__builtin_clz(cb) >> 3 : 4u;
+                const bool more_back = back < room && back == 4u;
+                if (back > room) back = room;
+                uint32_t fw = y_lo ? (uint32_t)__builtin_ctz(y_lo) >> 3 : (y_hi ? 4u + ((uint32_t)__builtin_ctz(y_hi) >> 3) : 8u);
+                if (more_back) break;
+                if (fw == 8u) {
+                    // the match goes on: the next 256 bytes of both sides, when the candidate is inside the window too
+                    if (m < held + 4u) break;
+                    const uint32_t d = W.rd32(ip_hit + 12u + (uint32_t)lane * 4u) ^ W.rd32(m + 12u + (uint32_t)lane * 4u);
+                    const unsigned long long stop = __ballot(d != 0u);
+                    if (!stop) break;                                       // (longer still: general code)
+                    const int first = __builtin_ctzll(stop);
+                    fw += (uint32_t)first * 4u + ((uint32_t)__builtin_ctz((uint32_t)__builtin_amdgcn_readlane((int)d, first)) >> 3);
+                }
+                // ---- decided: the inserts of the lanes up to the hit (per hash value the last of them stays) ...
+                const uint32_t leader_of_f = (uint32_t)__builtin_amdgcn_readlane((int)leader, f < 64 ? f : 0);
+                const bool shadowed = f <= e && (uint32_t)lane == leader_of_f;
+                if (lane <= e && !shadowed) { table[h] = mine; L.tag[h] = (uint16_t)my_tag; }
+                // ... and the sequence: token, one length byte for a run of 15 or more, the run, the offset
+                const uint32_t lit = ip_hit - back - ip;
+                const uint32_t long_run = lit >= RUN_MASK ? 1u : 0u;
+                const uint32_t match_code = back + fw;
+                const uint32_t long_match = match_code >= ML_MASK ? 1u : 0u;
+                const uint32_t tok = ((long_run ? RUN_MASK : lit) << 4) + (long_match ? ML_MASK : match_code);
+                const uint32_t offset = ip_hit - m;
+                g_u8* const o = out + op;
+                if ((uint32_t)lane <= long_run) o[lane] = (uint8_t)(lane == 0 ? tok : lit - RUN_MASK);
+                if ((uint32_t)lane < lit) o[1u + long_run + (uint32_t)lane] = (uint8_t)lit_byte;
+                // (a match code of 15 or more: one length byte, its length is below 270 here)
+                if ((uint32_t)lane < 2u + long_match) o[1u + long_run + lit + (uint32_t)lane] = (uint8_t)(lane == 2 ? match_code - ML_MASK : offset >> (8 * lane));
+                op += 3u + long_run + lit + long_match;
+                ip = ip_hit + MINMATCH + fw;
+                anchor = ip;
+                committed = true;
+                break;
+            }
+            if (committed) {
+                RH_STAMP(8, ip);
+                if (ip >= mflimit_plus_one) break;
+                continue;
+            }
+            if (!cands && !repeats) {
+                // nothing in this round can match and its hashes are all different: every lane inserts, and the general
+                // code goes on with the walk's second round
+                table[h] = mine; L.tag[h] = (uint16_t)my_tag;
+                first_round = 64u;
+            }
+            RH_STAMP(9, ip);
+        }
         // ---- match search (see compress_block): 64 steps of the sequential walk per round
         bool found = false, immediate = false, near = false, from_table = false;
         uint32_t c_back = 0, c_lo = 0, c_hi = 0;
         {   const uint32_t w0 = ip + 1u;
-            for (uint32_t r0 = 0; ; r0 += 64u) {
+            for (uint32_t r0 = first_round; ; r0 += 64u) {
                 uint32_t p, lo, hi; bool valid, tests;
                 if (r0 == 0u) {
                     // the first `pre` lanes take the positions that come before the walk: [the block's first position]
@@ -607,11 +728,11 @@ __device__ uint32_t compress_block_w(Lds& L, const Ring& R, Stream& st, uint32_t
                 const int last_insert = hits ? __builtin_ctzll(hits) : first_invalid - 1;
                 if (general) {
                     const unsigned long long inserting = last_insert < 0 ? 0ull : (last_insert >= 63 ? ~0ull : (2ull << last_insert) - 1ull);
-                    if (valid && lane <= last_insert && (same & above & inserting) == 0ull) table[h] = mine;
+                    if (valid && lane <= last_insert && (same & above & inserting) == 0ull) { table[h] = mine; L.tag[h] = (uint16_t)tag_of(seq); }
                 } else {
                     const uint32_t leader_of_f = (uint32_t)__builtin_amdgcn_readlane((int)leader, f < 64 ? f : 0);
                     const bool shadowed = f <= last_insert && (uint32_t)lane == leader_of_f;
-                    if (valid && lane <= last_insert && !shadowed) table[h] = mine;
+                    if (valid && lane <= last_insert && !shadowed) { table[h] = mine; L.tag[h] = (uint16_t)tag_of(seq); }
                 }
                 RH_STAMP(2, last_insert);
                 if (hits) {
@@ -746,7 +867,7 @@ extern "C" __global__ __launch_bounds__(64) void rh_lz4f_compress(const rh_lz4_j
     g_u8* const dict = (g_u8*)S.dict;
 
     // bring the hash table into LDS
-    for (int i = lane; i < (1 << HASHLOG); i += 64) L.hash[i] = S.hash[i];
+    for (int i = lane; i < (1 << HASHLOG); i += 64) { L.hash[i] = S.hash[i]; L.tag[i] = S.tag[i]; }
     Stream st; st.current_offset = __builtin_amdgcn_readfirstlane(S.current_offset); st.dict_size = __builtin_amdgcn_readfirstlane(S.dict_size);
     __syncthreads();
 
@@ -817,7 +938,7 @@ extern "C" __global__ __launch_bounds__(64) void rh_lz4f_compress(const rh_lz4_j
 #endif
     // persist the stream state (the dictionary is already in place)
     __syncthreads();
-    for (int i = lane; i < (1 << HASHLOG); i += 64) S.hash[i] = L.hash[i];
+    for (int i = lane; i < (1 << HASHLOG); i += 64) { S.hash[i] = L.hash[i]; S.tag[i] = L.tag[i]; }
     if (lane == 0) { S.current_offset = st.current_offset; S.dict_size = st.dict_size; *job.out_len = op; }
 }
 

@@ -53,7 +53,7 @@ int main(int argc, char** argv) {
     for (int rep = 0; rep < 2; rep++) {
         CHECK(hipMemset(d_states, 0, sizeof(rh_lz4_stream_state) * n_streams));
 #ifdef RH_LZ4_STAMPS
-        unsigned long long zero[16] = {0}; CHECK(hipMemcpyToSymbol(HIP_SYMBOL(rh_lz4_stamp_acc), zero, sizeof(zero)));
+        unsigned long long zero[24] = {0}; CHECK(hipMemcpyToSymbol(HIP_SYMBOL(rh_lz4_stamp_acc), zero, sizeof(zero)));
 #endif
         CHECK(hipEventRecord(e0, 0));
         if (rhk::lz4f_compress_launch(d_jobs, n_streams, d_states, 0) != 0) { fprintf(stderr, "launch failed\n"); return 1; }
@@ -66,10 +66,11 @@ int main(int argc, char** argv) {
     printf("streams %u  MiB/stream %zu  kernel %.2f ms  (%.1f MB/s per stream, %.1f GB/s in)  out %llu bytes (%.4f)  fnv %016llx\n", n_streams, bytes >> 20, best,
            bytes / 1e3 / best, bytes * (double)n_streams / 1e6 / best, len0, (double)len0 / bytes, (unsigned long long)h);
 #ifdef RH_LZ4_STAMPS
-    unsigned long long acc[16]; CHECK(hipMemcpyFromSymbol(acc, HIP_SYMBOL(rh_lz4_stamp_acc), sizeof(acc)));
-    const char* names[8] = {"window + sequence + hash", "election + candidate bytes", "resolution + inserts", "short form", "general loads + catch-up", "emit + match length", "block frame, last literals, dictionary", "-"};
-    double total = 0; for (int k = 0; k < 8; k++) total += (double)acc[k];
-    for (int k = 0; k < 7; k++) printf("  %-40s %5.1f %%   %.0f cycles per KiB of input\n", names[k], 100.0 * acc[k] / total, (double)acc[k] / n_streams / (bytes / 1024.0));
+    unsigned long long acc[24]; CHECK(hipMemcpyFromSymbol(acc, HIP_SYMBOL(rh_lz4_stamp_acc), sizeof(acc)));
+    const char* names[12] = {"window + sequence + hash", "election + candidate bytes", "resolution + inserts", "short form", "general loads + catch-up", "emit + match length", "block frame, last literals, dictionary", "straight piece: up to the hits", "straight piece: lengths + sequence", "straight piece: given up", "-", "-"};
+    double total = 0; for (int k = 0; k < 12; k++) total += (double)acc[k];
+    for (int k = 0; k < 10; k++) printf("  %-40s %5.1f %%   %7.0f cycles per KiB of input  %6.2f times per KiB, %5.0f cycles each\n", names[k], 100.0 * acc[k] / total, (double)acc[k] / n_streams / (bytes / 1024.0),
+                                        (double)acc[12 + k] / n_streams / (bytes / 1024.0), acc[12 + k] ? (double)acc[k] / acc[12 + k] : 0.0);
 #endif
     return 0;
 }

@@ -17,7 +17,7 @@ FMT_R_U8, FMT_BGRA_U8, FMT_RGBA_U8, FMT_RGBA_F16, FMT_RGBA_F32 = range(5)
 FILTER_LINEAR, FILTER_NEAREST = 0, 1
 TOPO_TRIANGLE_LIST, TOPO_TRIANGLE_STRIP = 0, 1
 BF_ZERO, BF_ONE, BF_SRC_ALPHA, BF_ONE_MINUS_SRC_ALPHA = range(4)
-SHADER_HELLO, SHADER_SIZED, SHADER_HELLO_LAYER, SHADER_TILTED = 0, 1, 2, 3
+SHADER_HELLO, SHADER_SIZED, SHADER_HELLO_LAYER, SHADER_TILTED, SHADER_SPACE = 0, 1, 2, 3, 4
 
 
 def build():

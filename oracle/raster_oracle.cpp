@@ -42,6 +42,7 @@ enum {
     ORC_SHADER_SIZED = 1,        // hello with a vec4 {x, y, half_w, half_h} instance record
     ORC_SHADER_HELLO_NEAREST_LAYER = 2, // hello sampling layer `uniform[0]` of a 2D-array texture
     ORC_SHADER_TILTED = 3,       // projective quads: per-vertex w, a third varying, a uniform read by both stages
+    ORC_SHADER_SPACE = 4,        // quads in space: a 4x4 matrix from a uniform, z and w from the vertex stage
 };
 
 struct orc_texture {
@@ -239,15 +240,30 @@ void tilted_fs(const orc_draw& d, const float* var, float out[][4]) {
     for (uint32_t a = 0; a < 2; a++) for (int k = 0; k < 4; k++) out[a][k] = (c[k] * u[k]) * var[2];
 }
 
+// Quads in space.  Storage record vec4 {cx, cy, half, depth}; uniform floats {tint r, g, b, a, m[16] (column-major)}:
+//   local = (a_position.x * half + cx, a_position.y * half + cy, depth, 1);  gl_Position = M * local
+//   varyings: tex_coord, shade = 1;  fragment stage as for the projective quads
+void space_vs(const orc_draw& d, uint32_t v, uint32_t inst, VsOut& o) {
+    const float* pos = d.attr[0] + (size_t)v * d.attr_size[0];
+    const float* uv = d.attr[1] + (size_t)v * d.attr_size[1];
+    const float* r = d.storage[0] + (size_t)inst * 4;
+    const float* m = d.uniform[0] + 4;
+    const float lx = fmaf(pos[0], r[2], r[0]), ly = fmaf(pos[1], r[2], r[1]), lz = r[3];
+    for (int i = 0; i < 4; i++) o.pos[i] = fmaf(m[i], lx, fmaf(m[4 + i], ly, fmaf(m[8 + i], lz, m[12 + i])));
+    o.var[0] = uv[0]; o.var[1] = uv[1]; o.var[2] = 1.0f;
+}
+
 const Shader SHADERS[] = {
     { 2, 2, hello_vs, hello_fs },
     { 2, 2, sized_vs, hello_fs },
     { 2, 2, hello_vs, layer_fs },
     { 3, 2, tilted_vs, tilted_fs },
+    { 3, 2, space_vs, tilted_fs },
 };
 
 // ---- triangle setup ----------------------------------------------------------------------------------------------
-struct Vert { int32_t X, Y; float rw; bool ok; float var[MAX_VARYINGS]; };
+// `out`: the clip planes the vertex is outside of (OUT_*; 0 = inside the clip volume = `ok`); `clip`: what the clipper starts from.
+struct Vert { int32_t X, Y; float rw; bool ok; float var[MAX_VARYINGS]; float clip[4]; uint32_t out; };
 
 struct Tri {
     int32_t A[3], B[3]; int64_t Cq[3];   // inside <=> A*i + B*j + Cq >= 0 for all three edges (i, j = pixel indices)
@@ -269,20 +285,102 @@ inline int32_t snap(float w) {
     return (int32_t)rintf(t);                      // round half to even
 }
 
+// ---- clip volume -------------------------------------------------------------------------------------------------------
+// The pipeline state the reference selects clips primitives to the view volume (reference src/pipeline.rs:197-207:
+// `unclipped_depth` unset).  A vertex is inside when w >= W_MIN, 0 <= z <= w (Vulkan 1.3 "Primitive Clipping" with the
+// 0..1 depth range) and its window position lies within [BAND_LO, BAND_HI] pixels on both axes (a band inside the
+// snapping guard band; fragments outside the viewport are removed by the scissor, which equals clipping at the
+// viewport's edges).  A triangle with all three vertices inside is drawn as it is; one with a NaN coordinate or with all
+// three vertices outside the same plane is dropped; any other is clipped against the seven planes (Sutherland-Hodgman,
+// in the order of clip_distance) and the convex polygon that is left is drawn as a fan (0, i+1, i+2), in that order.
+constexpr float W_MIN = 1.0f / 1048576.0f;
+constexpr float BAND_LO = -8000.0f, BAND_HI = 24000.0f;
+constexpr int CLIP_PLANES = 7, CLIP_MAX_VERTS = 3 + CLIP_PLANES;
+
+enum : uint32_t { OUT_W = 1u, OUT_NEAR = 2u, OUT_FAR = 4u, OUT_LEFT = 8u, OUT_RIGHT = 16u, OUT_TOP = 32u, OUT_BOTTOM = 64u, OUT_NAN = 128u };
+
 Vert run_vertex(const orc_draw& d, const Shader& sh, const ViewXf& xf, uint32_t v, uint32_t inst) {
     VsOut o; std::memset(&o, 0, sizeof o);
     sh.vs(d, v, inst, o);
-    Vert r; r.ok = true;
-    float x = o.pos[0], y = o.pos[1], w = o.pos[3];
-    if (!(w > 0.0f) || std::isnan(x) || std::isnan(y)) { r.ok = false; r.X = r.Y = 0; r.rw = 1.0f; return r; }
+    Vert r; r.ok = false; r.X = r.Y = 0;
+    float x = o.pos[0], y = o.pos[1], z = o.pos[2], w = o.pos[3];
+    for (int k = 0; k < 4; k++) r.clip[k] = o.pos[k];
+    for (int k = 0; k < sh.n_varyings; k++) r.var[k] = o.var[k];
+    const bool nan = std::isnan(x) || std::isnan(y) || std::isnan(z) || std::isnan(w);
+    const bool front = !nan && w >= W_MIN;      // only then does the vertex have a window position
     float rw = 1.0f;
-    if (w != 1.0f) { rw = 1.0f / w; x = x * rw; y = y * rw; }
+    if (w != 1.0f && front) { rw = 1.0f / w; x = x * rw; y = y * rw; }
     // Vulkan viewport transform with wgpu's y-up NDC: x_w = x*w/2 + (vx + w/2), y_w = -y*h/2 + (vy + h/2)
     float xw = fmaf(x, xf.hw, xf.ox);
     float yw = fmaf(y, -xf.hh, xf.oy);
-    r.X = snap(xw); r.Y = snap(yw); r.rw = rw;
-    for (int k = 0; k < sh.n_varyings; k++) r.var[k] = o.var[k];
+    r.rw = rw;
+    uint32_t out = nan ? OUT_NAN : (w >= W_MIN ? 0u : OUT_W);
+    if (!nan) out |= (z < 0.0f ? OUT_NEAR : 0u) | (z > w ? OUT_FAR : 0u);
+    if (front) out |= (xw < BAND_LO ? OUT_LEFT : 0u) | (xw > BAND_HI ? OUT_RIGHT : 0u) | (yw < BAND_LO ? OUT_TOP : 0u) | (yw > BAND_HI ? OUT_BOTTOM : 0u);
+    r.out = out; r.ok = out == 0u;
+    if (r.ok) { r.X = snap(xw); r.Y = snap(yw); }
     return r;
+}
+
+struct ClipVert { float c[4]; float var[MAX_VARYINGS]; };
+
+// Signed distance to clip plane `plane`; inside: not negative.  Plane 0 comes first so that w is positive for the rest.
+inline float clip_distance(const ViewXf& xf, const ClipVert& v, int plane) {
+    const float x = v.c[0], y = v.c[1], z = v.c[2], w = v.c[3];
+    switch (plane) {
+    case 0: return w - W_MIN;
+    case 1: return z;
+    case 2: return w - z;
+    case 3: return fmaf(x, xf.hw, (xf.ox - BAND_LO) * w);      // x_w >= BAND_LO
+    case 4: return fmaf(-x, xf.hw, (BAND_HI - xf.ox) * w);     // x_w <= BAND_HI
+    case 5: return fmaf(-y, xf.hh, (xf.oy - BAND_LO) * w);     // y_w >= BAND_LO
+    default: return fmaf(y, xf.hh, (BAND_HI - xf.oy) * w);     // y_w <= BAND_HI
+    }
+}
+
+// The part of triangle (a, b, c) inside the clip volume as projected, snapped vertices; returns their number (0: nothing).
+// A new vertex is computed from the inside end of its edge towards the outside end: t = d_in / (d_in - d_out), every
+// coordinate and varying fma(t, out - in, in) -- neighbours that share the clipped edge get the same point.
+int clip_triangle(const Shader& sh, const ViewXf& xf, const Vert& a, const Vert& b, const Vert& c, Vert out[CLIP_MAX_VERTS]) {
+    // a NaN coordinate, or all three vertices outside one plane: nothing to draw
+    if (((a.out | b.out | c.out) & OUT_NAN) || (a.out & b.out & c.out)) return 0;
+    ClipVert bufs[2][CLIP_MAX_VERTS];
+    const Vert* in3[3] = { &a, &b, &c };
+    for (int k = 0; k < 3; k++) {
+        for (int j = 0; j < 4; j++) bufs[0][k].c[j] = in3[k]->clip[j];
+        for (int j = 0; j < sh.n_varyings; j++) bufs[0][k].var[j] = in3[k]->var[j];
+    }
+    int n = 3, cur_buf = 0;
+    for (int plane = 0; plane < CLIP_PLANES && n >= 3; plane++) {
+        const ClipVert* src = bufs[cur_buf]; ClipVert* dst = bufs[cur_buf ^ 1];
+        int m = 0;
+        for (int i = 0; i < n; i++) {
+            const ClipVert& cur = src[i]; const ClipVert& nxt = src[(i + 1) % n];
+            const float dc = clip_distance(xf, cur, plane), dn = clip_distance(xf, nxt, plane);
+            const bool cin = !(dc < 0.0f), nin = !(dn < 0.0f);
+            if (cin) dst[m++] = cur;
+            if (cin != nin) {
+                const ClipVert& vi = cin ? cur : nxt; const ClipVert& vo = cin ? nxt : cur;
+                const float di = cin ? dc : dn, dout = cin ? dn : dc;
+                const float t = di / (di - dout);
+                ClipVert nv;
+                for (int j = 0; j < 4; j++) nv.c[j] = fmaf(t, vo.c[j] - vi.c[j], vi.c[j]);
+                for (int j = 0; j < sh.n_varyings; j++) nv.var[j] = fmaf(t, vo.var[j] - vi.var[j], vi.var[j]);
+                dst[m++] = nv;
+            }
+        }
+        cur_buf ^= 1; n = m;
+    }
+    if (n < 3) return 0;
+    for (int i = 0; i < n; i++) {
+        const ClipVert& v = bufs[cur_buf][i];
+        const float w = fmaxf(v.c[3], W_MIN), rw = 1.0f / w;
+        const float x = v.c[0] * rw, y = v.c[1] * rw;
+        Vert& r = out[i];
+        r.X = snap(fmaf(x, xf.hw, xf.ox)); r.Y = snap(fmaf(y, -xf.hh, xf.oy)); r.rw = rw; r.ok = true; r.out = 0u;
+        for (int j = 0; j < sh.n_varyings; j++) r.var[j] = v.var[j];
+    }
+    return n;
 }
 
 inline int64_t asr8(int64_t v) { return v >> SUBPIXEL_BITS; }   // floor division by 256
@@ -528,7 +626,15 @@ extern "C" int orc_render(orc_draw* d) {
             for (uint32_t i = 0; i < tpi; i++) {
                 uint32_t idx[3]; tri_vertices(*d, i, idx);
                 Tri t;
-                if (setup_tri(sh, verts[idx[0]], verts[idx[1]], verts[idx[2]], sc, S > 1 ? 128 : 0, t)) tris.push_back(t);
+                const Vert& a = verts[idx[0]]; const Vert& b = verts[idx[1]]; const Vert& c = verts[idx[2]];
+                if (a.ok && b.ok && c.ok) {
+                    if (setup_tri(sh, a, b, c, sc, S > 1 ? 128 : 0, t)) tris.push_back(t);
+                } else {
+                    Vert poly[CLIP_MAX_VERTS];
+                    const int n = clip_triangle(sh, xf, a, b, c, poly);
+                    for (int f = 2; f < n; f++)
+                        if (setup_tri(sh, poly[0], poly[f - 1], poly[f], sc, S > 1 ? 128 : 0, t)) tris.push_back(t);
+                }
             }
         }
     }
@@ -559,7 +665,7 @@ extern "C" int orc_render(orc_draw* d) {
     return 0;
 }
 
-extern "C" int orc_abi_version(void) { return 3; }
+extern "C" int orc_abi_version(void) { return 4; }
 
 // test hook: the f32 -> f16 conversion used for RGBA16F targets
 extern "C" uint16_t orc_float_to_half(float f) { return float_to_half(f); }

@@ -4,7 +4,7 @@
 #pragma once
 #include <stdint.h>
 
-#define RH_DEVICE_ABI_VERSION 12u
+#define RH_DEVICE_ABI_VERSION 13u
 #define RH_MODULE_MAGIC 0x52484d4fu   // "RHMO"
 
 #define RH_DEV_MAX_ATTRIBUTES 8
@@ -73,13 +73,20 @@ struct rh_draw_params {
 };
 
 // Packed tile rectangle of a cluster: x0 | y0 << 16, x1 | y1 << 16 (inclusive); x0 > x1 marks "touches nothing".
+// RH_RANGE_CLIPPED in `lo`: a triangle of the cluster is clipped and the cluster makes 8 pairs per tile, the pair's value
+// carrying the number of the sub-record (0..7) in its top three bits (cluster indices stay below 2^29).
 struct rh_tile_range { uint32_t lo, hi; };
+#define RH_RANGE_CLIPPED 0x8000u
 
 struct rh_bin_count_args {
     rh_draw_params p;
     rh_tile_range* ranges;      // [n_clusters]
     uint32_t* block_sums;       // [ceil(n_clusters / 256)]
+    uint32_t* wants_clip;       // set to 1 by rh_bin_count when it left out a triangle that needs clipping (rh_bin_count_clip clips it)
 };
+// Added to the pair count of a pass by rh_bin_pairs when it left out a triangle that needs clipping: the count then exceeds
+// every capacity (the kernels behind it write nothing) and tells the host to run the pass with the clipping kernels.
+#define RH_WANTS_CLIP (1ull << 40)
 
 // ---- binning queued in three launches ------------------------------------------------------------------------------------
 // Once the host has a guess of how many (tile, cluster) pairs a pass makes, the pair array is built and sorted without
@@ -98,7 +105,8 @@ struct rh_bin_state {
     unsigned long long total;           // pairs of the pass (all of them, also when they do not fit the arrays)
     uint32_t ticket[1 + RH_SORT_MAX_PASSES];    // [0] pair kernel, [1 + i] sorting pass i
     uint32_t fault;                     // set when a look-back gave up (the results of the pass are then undefined)
-    uint32_t reserved[8];
+    uint32_t wants_clip;                // set by rh_bin_count (see rh_bin_count_args)
+    uint32_t reserved[7];
     uint32_t digit_count[RH_SORT_MAX_PASSES][RH_DIGIT_COPIES][256];    // pairs per value of every 8-bit digit of the tile number (sum of the copies)
 };
 // status words of the look-back chains: 2 flag bits on top, the count below

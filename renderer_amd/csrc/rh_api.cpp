@@ -81,7 +81,7 @@ struct rh_device {
     Scratch png_slots, png_rows, png_out;          // GPU PNG encoder scratch
     void* png_host = nullptr; size_t png_host_cap = 0;   // pinned
     unsigned long long* d_total = nullptr;
-    unsigned long long* h_total = nullptr;      // pinned: [0] pair count of the last pass, [1] set by a binning kernel that gave up
+    unsigned long long* h_total = nullptr;      // pinned: [0] pair count of the last pass, [1] set by a binning kernel that gave up, [2] rh_bin_state::wants_clip
     // A pass is queued whole, sized by `pair_guess`, before its pair count has come back; the count is looked at
     // before the next command runs (resolve_pending) and the pass runs again, waiting for the count, if it did not fit.
     uint32_t compute_units = 0, resident_sort_parts = 0;   // (workgroups of a chained sorting pass the device holds at once)
@@ -139,6 +139,8 @@ struct rh_module {
     hipModule_t module = nullptr;
     rh_module_info_t info{};
     hipFunction_t bin_count = nullptr, bin_pairs = nullptr;
+    hipFunction_t bin_count_clip = nullptr, bin_pairs_clip = nullptr;   // the kernels that clip (see rh_pipeline::clips)
+    hipFunction_t setup_clip[4] = {nullptr, nullptr, nullptr, nullptr};
     uint32_t resident_pair_parts = 0;           // workgroups of rh_bin_pairs the device holds at once
     hipFunction_t setup[4] = {nullptr, nullptr, nullptr, nullptr};   // 1, 2, 4, 8 samples
     hipFunction_t tile[RH_MAX_COLOR_TARGETS] = {nullptr, nullptr, nullptr, nullptr};
@@ -156,6 +158,9 @@ struct rh_pipeline {
     std::vector<SlotRef> slots;
     uint32_t topology = 0, samples = 1;
     std::vector<rh_color_target_desc> targets;
+    // Set when a pass of the pipeline met a triangle that crosses a clip plane: from then on its passes run the kernels
+    // that clip (their polygons live in private memory, which makes them several times slower than the usual ones).
+    bool clips = false;
 };
 
 namespace {
@@ -253,11 +258,11 @@ int rh_device_create(int hip_ordinal, uint32_t width, uint32_t height, rh_device
     dev->name = std::string(prop.name) + " (" + prop.gcnArchName + ")";
     hipError_t e = hipStreamCreateWithFlags(&dev->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete dev; return fail("hipStreamCreate failed: %s", hipGetErrorString(e)); }
-    if (hipMalloc((void**)&dev->d_total, 8) != hipSuccess || hipHostMalloc((void**)&dev->h_total, 16, hipHostMallocDefault) != hipSuccess ||
+    if (hipMalloc((void**)&dev->d_total, 8) != hipSuccess || hipHostMalloc((void**)&dev->h_total, 32, hipHostMallocDefault) != hipSuccess ||
         hipEventCreateWithFlags(&dev->counted, hipEventDisableTiming) != hipSuccess) {
         delete dev; return fail("rh_device_create: allocation failed");
     }
-    dev->h_total[0] = 0; dev->h_total[1] = 0;
+    dev->h_total[0] = 0; dev->h_total[1] = 0; dev->h_total[2] = 0; dev->h_total[3] = 0;
     dev->compute_units = (uint32_t)prop.multiProcessorCount;
     dev->device_cache_max_bytes = (size_t)prop.totalGlobalMem / 2;
     dev->resident_sort_parts = rhk::sort_pass_resident_parts(dev->compute_units);
@@ -575,6 +580,9 @@ int rh_module_load(rh_device* dev, const void* code_object, size_t size, rh_modu
         if (hipModuleGetFunction(&m->bin_count, m->module, "rh_bin_count") != hipSuccess || hipModuleGetFunction(&m->bin_pairs, m->module, "rh_bin_pairs") != hipSuccess) {
             (void)hipModuleUnload(m->module); delete m; return fail("rh_module_load: vertex code object lacks rh_bin_count / rh_bin_pairs");
         }
+        if (hipModuleGetFunction(&m->bin_count_clip, m->module, "rh_bin_count_clip") != hipSuccess || hipModuleGetFunction(&m->bin_pairs_clip, m->module, "rh_bin_pairs_clip") != hipSuccess) {
+            (void)hipModuleUnload(m->module); delete m; return fail("rh_module_load: vertex code object lacks rh_bin_count_clip / rh_bin_pairs_clip");
+        }
         int per_cu = 0;
         if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, m->bin_pairs, RH_PAIR_THREADS, 0) == hipSuccess && per_cu > 0)
             m->resident_pair_parts = (uint32_t)per_cu * dev->compute_units;
@@ -588,6 +596,9 @@ int rh_module_load(rh_device* dev, const void* code_object, size_t size, rh_modu
         const char* setup_names[4] = { "rh_setup", "rh_setup_ms2", "rh_setup_ms4", "rh_setup_ms8" };
         for (int i = 0; i < 4; i++)
             if (hipModuleGetFunction(&m->setup[i], m->module, setup_names[i]) != hipSuccess) { (void)hipModuleUnload(m->module); delete m; return fail("rh_module_load: fragment code object lacks %s", setup_names[i]); }
+        const char* clip_names[4] = { "rh_setup_clip", "rh_setup_clip_ms2", "rh_setup_clip_ms4", "rh_setup_clip_ms8" };
+        for (int i = 0; i < 4; i++)
+            if (hipModuleGetFunction(&m->setup_clip[i], m->module, clip_names[i]) != hipSuccess) { (void)hipModuleUnload(m->module); delete m; return fail("rh_module_load: fragment code object lacks %s", clip_names[i]); }
         if (m->info.rec_bytes == 0 || m->info.rec_bytes % 16 || m->info.ext_bytes % 16) { (void)hipModuleUnload(m->module); delete m; return fail("rh_module_load: fragment code object declares a malformed record size"); }
         const char* ms_names[3] = { "rh_tile_ms2", "rh_tile_ms4", "rh_tile_ms8" };
         for (int i = 0; i < 3; i++)
@@ -848,7 +859,8 @@ int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer, rh_device::Pa
     p.tpi = pl->topology == RH_TOPOLOGY_TRIANGLE_STRIP ? (c.vertex_count >= 3 ? c.vertex_count - 2 : 0) : c.vertex_count / 3;
     p.cpi = (p.tpi + 1) / 2;
     const uint64_t n_clusters64 = (uint64_t)p.cpi * c.instance_count;
-    if (n_clusters64 >= 0xffffff00ull) return fail("render pass: %llu triangle pairs exceed the 32-bit cluster index", (unsigned long long)n_clusters64);
+    // (the top three bits of a (tile, cluster) pair's value number the sub-records of a clipped cluster)
+    if (n_clusters64 >= (1ull << 29)) return fail("render pass: %llu triangle pairs exceed the 29-bit cluster index", (unsigned long long)n_clusters64);
     p.n_clusters = (uint32_t)n_clusters64;
     p.samples = pl->samples; p.bbox_pad = pl->samples > 1 ? 128 : 0;
     const bool empty_scissor = p.sc_x0 >= p.sc_x1 || p.sc_y0 >= p.sc_y1;
@@ -888,7 +900,7 @@ int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer, rh_device::Pa
         ba.keys = ss.keys_a.as<uint32_t>(); ba.vals = ss.vals_a.as<uint32_t>();
         ba.capacity = n; ba.sort_passes = sort_passes; ba.host_total = dev->h_total;
         ba.ticketed = (dev->binning_tickets || n_pair_parts > pl->vs->resident_pair_parts) ? 1u : 0u;
-        if (launch_module_kernel(pl->vs->bin_pairs, n_pair_parts, RH_PAIR_THREADS, &ba, sizeof ba, s)) return 1;
+        if (launch_module_kernel(pl->clips ? pl->vs->bin_pairs_clip : pl->vs->bin_pairs, n_pair_parts, RH_PAIR_THREADS, &ba, sizeof ba, s)) return 1;
         const int where = rhk::sort_passes_chained(ss.keys_a.as<uint32_t>(), ss.vals_a.as<uint32_t>(), ss.keys_b.as<uint32_t>(), ss.vals_b.as<uint32_t>(),
                                                    n, key_bits, state, reinterpret_cast<uint32_t*>(state_base + sort_status_at), dev->h_total, dev->binning_tickets ? 0u : dev->resident_sort_parts, s);
         RH_HIP(hipGetLastError());
@@ -902,11 +914,19 @@ int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer, rh_device::Pa
             ss.chunk_tmp.ensure((size_t)rhk::scan_chunks_for(n_parts) * 4)) return 1;
         rh_bin_count_args ba;
         ba.p = p; ba.p.n_clusters = n_clusters;
-        ba.ranges = ss.ranges.as<rh_tile_range>(); ba.block_sums = ss.block_sums.as<uint32_t>();
-        if (launch_module_kernel(pl->vs->bin_count, n_parts, 256, &ba, sizeof ba, s)) return 1;
+        ba.ranges = ss.ranges.as<rh_tile_range>(); ba.block_sums = ss.block_sums.as<uint32_t>(); ba.wants_clip = &state->wants_clip;
+        if (launch_module_kernel(pl->clips ? pl->vs->bin_count_clip : pl->vs->bin_count, n_parts, 256, &ba, sizeof ba, s)) return 1;
         rhk::exclusive_scan(ss.block_sums.as<uint32_t>(), n_parts, ss.chunk_tmp.as<uint32_t>(), dev->d_total, s, dev->general_kernels != 0);
         RH_HIP(hipMemcpyAsync(dev->h_total, dev->d_total, 8, hipMemcpyDeviceToHost, s));
+        RH_HIP(hipMemcpyAsync(dev->h_total + 2, &state->wants_clip, 4, hipMemcpyDeviceToHost, s));
         RH_HIP(hipStreamSynchronize(s));
+        if ((uint32_t)dev->h_total[2] != 0u && !pl->clips) {
+            // a triangle crosses a clip plane: the pass starts again with the kernels that clip
+            if (no_alloc) return fail("rh_submit_static: the pass has triangles that cross a clip plane; the kernels that clip them need private memory, which the runtime allocates");
+            pl->clips = true;
+            if (dev->timing && !dev->timing_events.empty()) { dev->event_pool.push_back(dev->timing_events.back()); dev->timing_events.pop_back(); }
+            return execute_pass(dev, c, false, ss, no_alloc, fused);
+        }
         total = dev->h_total[0];
         if (total >= 0x7fffffffull) return fail("render pass: %llu (tile, cluster) pairs exceed the 31-bit pair index", (unsigned long long)total);
         dev->pair_guess = std::max<uint64_t>(dev->pair_guess, std::min<uint64_t>(total + total / 4 + 4096, 0x7ffffffeull));
@@ -935,7 +955,7 @@ int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer, rh_device::Pa
         sa.n_pairs = n; sa.pair_total = pair_total;
         sa.tile_start = tile_start; sa.tile_end = tile_end;
         if (!no_alloc && timing_mark(dev)) return 1;
-        if (launch_module_kernel(pl->fs->setup[ms_index], (n + 255) / 256, 256, &sa, sizeof sa, s)) return 1;
+        if (launch_module_kernel(pl->clips ? pl->fs->setup_clip[ms_index] : pl->fs->setup[ms_index], (n + 255) / 256, 256, &sa, sizeof sa, s)) return 1;
     } else if (!no_alloc && timing_mark(dev)) return 1;
 
     rh_tile_args ta;
@@ -1030,6 +1050,13 @@ int resolve_pending(rh_device* dev, bool blocking) {
     const uint64_t total = dev->h_total[0];
     if (e != hipSuccess) rc = fail("render pass: waiting for the pair count failed: %s", hipGetErrorString(e));
     else if (dev->h_total[1]) { dev->h_total[1] = 0; rc = fail("render pass: a binning workgroup gave up waiting for its predecessors; the results of the pass are undefined"); }
+    else if (total >= RH_WANTS_CLIP && !c.pipeline->clips) {
+        // a triangle crosses a clip plane (nothing was written): the pass runs again, now and from now on with the kernels that clip
+        c.pipeline->clips = true;
+        for (int k = 0; k < 4 && dev->timing && !dev->timing_events.empty(); k++) { dev->event_pool.push_back(dev->timing_events.back()); dev->timing_events.pop_back(); }
+        dev->stats.reruns++;
+        rc = execute_pass(dev, c, false, dev->grown, false, fused);
+    }
     else if (total >= 0x7fffffffull) rc = fail("render pass: %llu (tile, cluster) pairs exceed the 31-bit pair index", (unsigned long long)total);
     else {
         dev->stats.bin_entries = total;

@@ -16,10 +16,26 @@ static_assert(N_VARYINGS >= 1 && N_VARYINGS <= 8, "1..8 varying floats supported
 constexpr float GB_LO = -8192.0f * 256.0f;
 constexpr float GB_HI = 24576.0f * 256.0f - 1.0f;
 
+// Clip volume.  A vertex is *inside* when w >= W_MIN, 0 <= z <= w (Vulkan depth clipping: the reference leaves
+// `unclipped_depth` unset, src/pipeline.rs:197-207) and its window position lies in the clip band [BAND_LO, BAND_HI]
+// pixels on both axes (inside the guard band, so snapping does not move it).  A triangle whose three vertices are inside
+// is rasterised as it is; a triangle with a NaN coordinate or with all three vertices outside one plane is dropped; any
+// other triangle is clipped against the seven planes first (clip_triangle) and the resulting convex polygon is drawn as a
+// fan.  Clipping lives in kernels of its own (rh_bin_count_clip, rh_bin_pairs_clip, rh_setup_clip*): their polygons need
+// private memory, which the kernels of the usual case do without; those report a triangle that needs clipping and the
+// host runs the pass again with the clipping kernels (and keeps them for the pipeline).
+constexpr float W_MIN = 1.0f / 1048576.0f;
+constexpr float BAND_LO = -8000.0f, BAND_HI = 24000.0f;
+
+// Which clip planes a vertex is outside of (0: inside the clip volume).  The band bits are only looked at for vertices
+// in front of the eye (w >= W_MIN), whose window position exists.
+enum : uint32_t { OUT_W = 1u, OUT_NEAR = 2u, OUT_FAR = 4u, OUT_LEFT = 8u, OUT_RIGHT = 16u, OUT_TOP = 32u, OUT_BOTTOM = 64u, OUT_NAN = 128u };
+
 struct SnappedVertex {
     int32_t X, Y;          // 24.8 fixed point, pixel centres on multiples of 256
     float rw;              // 1 / w
-    bool ok;               // w > 0 and position not NaN
+    bool ok;               // inside the clip volume: out == 0
+    uint32_t out;          // OUT_* bits
     Varyings var;
 };
 
@@ -34,14 +50,108 @@ RH_DEVICE SnappedVertex run_vertex(const rh_draw_params& p, uint32_t vertex, uin
     SnappedVertex r;
     float4 pos = vertex_main(c, r.var);
     float x = pos.x, y = pos.y, w = pos.w;
-    r.ok = (w > 0.0f) && !(x != x) && !(y != y);
+    const bool nan = (x != x) || (y != y) || (pos.z != pos.z) || (w != w);
+    const bool front = !nan && w >= W_MIN;
     float rw = 1.0f;
-    if (w != 1.0f && r.ok) { rw = 1.0f / w; x = x * rw; y = y * rw; }
+    if (w != 1.0f && front) { rw = 1.0f / w; x = x * rw; y = y * rw; }
     float xw = __builtin_fmaf(x, p.vp_hw, p.vp_ox);
     float yw = __builtin_fmaf(y, -p.vp_hh, p.vp_oy);
+    uint32_t out = nan ? OUT_NAN : (w >= W_MIN ? 0u : OUT_W);
+    if (!nan) out |= (pos.z < 0.0f ? OUT_NEAR : 0u) | (pos.z > w ? OUT_FAR : 0u);
+    if (front) out |= (xw < BAND_LO ? OUT_LEFT : 0u) | (xw > BAND_HI ? OUT_RIGHT : 0u) | (yw < BAND_LO ? OUT_TOP : 0u) | (yw > BAND_HI ? OUT_BOTTOM : 0u);
+    r.out = out; r.ok = out == 0u;
     r.X = r.ok ? snap(xw) : 0; r.Y = r.ok ? snap(yw) : 0; r.rw = rw;
     return r;
 }
+
+// What becomes of a triangle: drawn as it is (every vertex inside the clip volume), dropped (a NaN coordinate, or all
+// three vertices outside the same plane: nothing of it is inside), or clipped.
+enum { TRI_WHOLE = 0, TRI_DROPPED = 1, TRI_CLIPPED = 2 };
+RH_DEVICE int classify(const SnappedVertex& a, const SnappedVertex& b, const SnappedVertex& c) {
+    const uint32_t any = a.out | b.out | c.out;
+    if (any == 0u) return TRI_WHOLE;
+    if ((any & OUT_NAN) || (a.out & b.out & c.out)) return TRI_DROPPED;
+    return TRI_CLIPPED;
+}
+
+// ---- clipping (the rare path: kept out of line, its polygons live in private memory) -------------------------------------
+struct ClipVertex { float c[4]; float var[N_VARYINGS]; };       // clip-space x, y, z, w and the varyings
+constexpr int CLIP_PLANES = 7, CLIP_MAX_VERTS = 3 + CLIP_PLANES;
+struct ClipPolygon { int n; SnappedVertex v[CLIP_MAX_VERTS]; };
+
+// Signed distance of `v` to clip plane `plane` (inside: not negative).  Plane 0 keeps w positive for the others.
+RH_DEVICE float clip_distance(const rh_draw_params& p, const ClipVertex& v, int plane) {
+    const float x = v.c[0], y = v.c[1], z = v.c[2], w = v.c[3];
+    switch (plane) {
+        case 0: return w - W_MIN;
+        case 1: return z;
+        case 2: return w - z;
+        case 3: return __builtin_fmaf(x, p.vp_hw, (p.vp_ox - BAND_LO) * w);        // x_w >= BAND_LO
+        case 4: return __builtin_fmaf(-x, p.vp_hw, (BAND_HI - p.vp_ox) * w);       // x_w <= BAND_HI
+        case 5: return __builtin_fmaf(-y, p.vp_hh, (p.vp_oy - BAND_LO) * w);       // y_w = -y/w * hh + oy >= BAND_LO
+        default: return __builtin_fmaf(y, p.vp_hh, (BAND_HI - p.vp_oy) * w);       // y_w <= BAND_HI
+    }
+}
+
+// Clips triangle (vertex indices idx[0..2] of `instance`) against the clip volume (Sutherland-Hodgman, planes in the
+// order of clip_distance) and projects the polygon's vertices.  A new vertex is always computed from the inside end of
+// its edge towards the outside end, t = d_in / (d_in - d_out), every coordinate and varying as fma(t, out - in, in): two
+// triangles that share a clipped edge get the same point.  Vertices that were inside pass through unchanged and
+// project exactly as run_vertex projects them.  out.n = 0: nothing left (or a NaN coordinate: the triangle is dropped).
+__device__ __noinline__ void clip_triangle(const rh_draw_params& p, uint32_t instance, uint32_t i0, uint32_t i1, uint32_t i2, ClipPolygon& out) {
+    ClipVertex a[CLIP_MAX_VERTS], b[CLIP_MAX_VERTS];
+    out.n = 0;
+    const uint32_t idx[3] = { i0, i1, i2 };
+    for (int k = 0; k < 3; k++) {
+        VertexContext c; c.p = &p; c.vertex_index = idx[k]; c.instance_index = instance;
+        Varyings var;
+        const float4 pos = vertex_main(c, var);
+        if (pos.x != pos.x || pos.y != pos.y || pos.z != pos.z || pos.w != pos.w) return;
+        a[k].c[0] = pos.x; a[k].c[1] = pos.y; a[k].c[2] = pos.z; a[k].c[3] = pos.w;
+        const float* vf = reinterpret_cast<const float*>(&var);
+        for (int v = 0; v < N_VARYINGS; v++) a[k].var[v] = vf[v];
+    }
+    ClipVertex* src = a; ClipVertex* dst = b;
+    int n = 3;
+    for (int plane = 0; plane < CLIP_PLANES && n >= 3; plane++) {
+        int m = 0;
+        for (int i = 0; i < n; i++) {
+            const ClipVertex& cur = src[i];
+            const ClipVertex& nxt = src[i + 1 == n ? 0 : i + 1];
+            const float dc = clip_distance(p, cur, plane), dn = clip_distance(p, nxt, plane);
+            const bool cin = !(dc < 0.0f), nin = !(dn < 0.0f);
+            if (cin) dst[m++] = cur;
+            if (cin != nin) {
+                const ClipVertex& in = cin ? cur : nxt;
+                const ClipVertex& ou = cin ? nxt : cur;
+                const float di = cin ? dc : dn, dou = cin ? dn : dc;
+                const float t = di / (di - dou);
+                ClipVertex nv;
+                for (int k = 0; k < 4; k++) nv.c[k] = __builtin_fmaf(t, ou.c[k] - in.c[k], in.c[k]);
+                for (int v = 0; v < N_VARYINGS; v++) nv.var[v] = __builtin_fmaf(t, ou.var[v] - in.var[v], in.var[v]);
+                dst[m++] = nv;
+            }
+        }
+        ClipVertex* t = src; src = dst; dst = t;
+        n = m;
+    }
+    if (n < 3) return;
+    for (int i = 0; i < n; i++) {
+        const float w = fmaxf(src[i].c[3], W_MIN), rw = 1.0f / w;
+        const float x = src[i].c[0] * rw, y = src[i].c[1] * rw;
+        SnappedVertex& r = out.v[i];
+        r.X = snap(__builtin_fmaf(x, p.vp_hw, p.vp_ox)); r.Y = snap(__builtin_fmaf(y, -p.vp_hh, p.vp_oy)); r.rw = rw; r.ok = true; r.out = 0u;
+        float* vf = reinterpret_cast<float*>(&r.var);
+        for (int v = 0; v < N_VARYINGS; v++) vf[v] = src[i].var[v];
+    }
+    out.n = n;
+}
+
+// A cluster some of whose triangles are clipped makes CLIP_SUBS (tile, cluster) pairs per tile instead of one: pair
+// value = cluster | sub << CLIP_SUB_SHIFT; sub s covers triangles 2*(s mod 4) and 2*(s mod 4) + 1 of the fan of the
+// cluster's first (s < 4) or second triangle (a triangle that needs no clipping is a fan of one).
+constexpr uint32_t CLIP_SUB_SHIFT = 29u, CLIP_SUBS = 8u, CLIP_CLUSTER_MASK = (1u << CLIP_SUB_SHIFT) - 1u;
+static_assert((CLIP_MAX_VERTS - 2 + 1) / 2 == 4, "four records of two fan triangles per clipped triangle");
 
 // Vertex indices of triangle `i` of an instance.  Strip: (i, i+1, i+2) for even i, (i, i+2, i+1) for odd i
 // (Vulkan 1.3 primitive topologies); list: (3i, 3i+1, 3i+2).  The reference selects the topology at

@@ -245,72 +245,33 @@ RH_DEVICE void store_ms_edges(MsRecord<S>& m, int t, const TriSetup& ts, int ox,
     }
 }
 
-// Sets up both triangles of `cluster` for the tile at (ox, oy) and writes the pair's records.  S > 1 (multisampled
-// pass) also writes the per-sample constants and never takes the exact-box shortcut.
-template <int S>
-RH_DEVICE void setup_pair(const rh_draw_params& p, uint32_t cluster, int ox, int oy, uint32_t* w, uint32_t* ext) {
-    const uint32_t instance = cluster / p.cpi, local = cluster - instance * p.cpi;
-    const uint32_t tri0 = local * 2;
-    const bool has_second = tri0 + 1 < p.tpi;
-    // Strip: triangle A = (v0, v1, v2), triangle B = (v1, v3, v2) with v_i = vertex tri0 + i (4 vertex runs).
-    // List:  triangle A = (v0, v1, v2), triangle B = (v3, v4, v5) with v_i = vertex 3*tri0 + i.
-    const bool strip = p.topology == 1u;
-    const uint32_t first = strip ? tri0 : 3 * tri0;
-    const SnappedVertex v0 = run_vertex(p, first, instance);
-    const SnappedVertex v1 = run_vertex(p, first + 1, instance);
-    const SnappedVertex v2 = run_vertex(p, first + 2, instance);
-    int bx0 = 255, by0 = 255, bx1 = -1, by1 = -1;
-    bool persp_a = false, persp_b = false, big = false;
+// What the set-up of a pair's (at most) two triangles found.
+struct PairSetup {
     TriSetup ta, tb;
-    bool has_a = false, has_b = false, rect = false;
-    int32_t rminX = 0, rmaxX = 0, rminY = 0, rmaxY = 0;
-    if (has_second && strip) {
-        const SnappedVertex v3 = run_vertex(p, first + 3, instance);
-        // a strip quad whose snapped corners form an axis-aligned rectangle split along v1-v2: with affine varyings and
-        // sides short enough for the f32 coverage path it is drawn from the shared diagonal alone (edge 1 of triangle A)
-        const bool columns = v0.X == v1.X && v2.X == v3.X && v0.Y == v2.Y && v1.Y == v3.Y;
-        const bool rows = v0.Y == v1.Y && v2.Y == v3.Y && v0.X == v2.X && v1.X == v3.X;
-        rminX = min(v0.X, v3.X); rmaxX = max(v0.X, v3.X); rminY = min(v0.Y, v3.Y); rmaxY = max(v0.Y, v3.Y);
-        const bool shape = S == 1 && (columns || rows) && v0.X != v3.X && v0.Y != v3.Y;
-        const bool lean = shape && rmaxX - rminX < F32_EDGE_LIMIT && rmaxY - rminY < F32_EDGE_LIMIT &&
-                          v0.rw == 1.0f && v1.rw == 1.0f && v2.rw == 1.0f && v3.rw == 1.0f;
-        has_a = setup_triangle(p, v0, v1, v2, ox, oy, ta, persp_a, big, bx0, by0, bx1, by1, lean ? 2u : 7u);
-        has_b = setup_triangle(p, v1, v3, v2, ox, oy, tb, persp_b, big, bx0, by0, bx1, by1, lean ? 0u : 7u);
-        rect = shape && has_a && has_b && !big;
-    } else {
-        has_a = setup_triangle(p, v0, v1, v2, ox, oy, ta, persp_a, big, bx0, by0, bx1, by1);
-        if (has_second) {
-            const SnappedVertex v3 = run_vertex(p, first + 3, instance);
-            const SnappedVertex v4 = run_vertex(p, first + 4, instance);
-            const SnappedVertex v5 = run_vertex(p, first + 5, instance);
-            has_b = setup_triangle(p, v3, v4, v5, ox, oy, tb, persp_b, big, bx0, by0, bx1, by1);
-        }
-    }
-    uint32_t flags = (has_a ? FLAG_HAS_A : 0u) | (has_b ? FLAG_HAS_B : 0u) | (persp_a ? FLAG_PERSP_A : 0u) | (persp_b ? FLAG_PERSP_B : 0u) |
+    bool has_a = false, has_b = false, persp_a = false, persp_b = false, big = false, rect = false;
+    int bx0 = 255, by0 = 255, bx1 = -1, by1 = -1;          // tile-relative bounding box of the two
+    uint32_t bbox = BBOX_EMPTY;                              // the box the record gets
+};
+
+// Writes the pair's set-up record to `w` (REC_WORDS dwords) and, when the fragments will read it, the extended record.
+template <int S>
+RH_DEVICE void write_records(const PairSetup& s, int ox, int oy, uint32_t* w, uint32_t* ext) {
+    const bool has_a = s.has_a, has_b = s.has_b, rect = s.rect, big = s.big;
+    uint32_t flags = (has_a ? FLAG_HAS_A : 0u) | (has_b ? FLAG_HAS_B : 0u) | (s.persp_a ? FLAG_PERSP_A : 0u) | (s.persp_b ? FLAG_PERSP_B : 0u) |
                      (big ? FLAG_BIG : 0u) | (rect ? FLAG_RECT : 0u);
-    uint32_t bbox = BBOX_EMPTY;
-    if (has_a || has_b) {
-        if (rect) {
-            // Exact pixel set of the rectangle under the top-left rule: left and top edges take pixel centres on them,
-            // right and bottom edges do not.  Inside it every pixel belongs to exactly one of the two triangles, decided
-            // by the shared diagonal alone (edge 1 of triangle A).
-            const int ex0 = max(max(p.sc_x0, ox), (rminX + 255) >> 8), ex1 = min(min(p.sc_x1 - 1, ox + TILE - 1), (rmaxX - 1) >> 8);
-            const int ey0 = max(max(p.sc_y0, oy), (rminY + 255) >> 8), ey1 = min(min(p.sc_y1 - 1, oy + TILE - 1), (rmaxY - 1) >> 8);
-            if (ex0 <= ex1 && ey0 <= ey1) bbox = (uint32_t)(ex0 - ox) | ((uint32_t)(ey0 - oy) << 8) | ((uint32_t)(ex1 - ox) << 16) | ((uint32_t)(ey1 - oy) << 24);
-        } else bbox = (uint32_t)bx0 | ((uint32_t)by0 << 8) | ((uint32_t)bx1 << 16) | ((uint32_t)by1 << 24);
-    }
+    const uint32_t bbox = s.bbox;
     if (bbox == BBOX_EMPTY) flags = 0u;
     // the record (the planes of a missing triangle are zeros: never used, masked by the flags)
 #pragma unroll
     for (int i = 0; i < REC_WORDS; i++) w[i] = 0u;
     {   float g = 0.0f;
-        const TriSetup& tg = has_a ? ta : tb;
+        const TriSetup& tg = has_a ? s.ta : s.tb;
 #pragma unroll
         for (int v = 0; v < NV; v++) g = fmaxf(g, fabsf(tg.dvdx[v]));
         w[0] = hdr_pack(bbox, flags, (int)((__float_as_uint(g * (256.0f * 1.41421356f)) >> 23) & 0xffu) - 127);
     }
-    w[1] = edge_word(ta, 1, false); w[2] = edge_word(ta, 4, false); w[3] = edge_word(ta, 7, false);      // the shared diagonal (used when RECT: never BIG)
-    const TriSetup* const ts[2] = { &ta, &tb };
+    w[1] = edge_word(s.ta, 1, false); w[2] = edge_word(s.ta, 4, false); w[3] = edge_word(s.ta, 7, false);      // the shared diagonal (used when RECT: never BIG)
+    const TriSetup* const ts[2] = { &s.ta, &s.tb };
 #pragma unroll
     for (int t = 0; t < 2; t++) {
         uint32_t* o = w + HDR_WORDS + t * TRI_WORDS;
@@ -321,7 +282,7 @@ RH_DEVICE void setup_pair(const rh_draw_params& p, uint32_t cluster, int ox, int
         }
     }
     // the extended record: only for clusters whose fragments read it
-    if (bbox != BBOX_EMPTY && (!rect || persp_a || persp_b)) {
+    if (bbox != BBOX_EMPTY && (!rect || s.persp_a || s.persp_b)) {
 #pragma unroll
         for (int t = 0; t < 2; t++) {
             uint32_t* o = ext + t * EXT_TRI_WORDS;
@@ -332,12 +293,105 @@ RH_DEVICE void setup_pair(const rh_draw_params& p, uint32_t cluster, int ox, int
     }
     if (S > 1 && bbox != BBOX_EMPTY) {
         MsRecord<S>& m = *reinterpret_cast<MsRecord<S>*>(ext + EXT_WORDS);
-        if (has_a) store_ms_edges<S>(m, 0, ta, ox, oy);
-        if (has_b) store_ms_edges<S>(m, 1, tb, ox, oy);
+        if (has_a) store_ms_edges<S>(m, 0, s.ta, ox, oy);
+        if (has_b) store_ms_edges<S>(m, 1, s.tb, ox, oy);
     }
 }
 
+// Sub-record `piece` (0..3) of triangle (i0, i1, i2) of a clipped cluster: triangles 2*piece and 2*piece + 1 of the fan
+// of the triangle's part inside the clip volume; a triangle that lies inside as it is (`whole`) is piece 0 by itself.
+// The rare path: out of line, and it writes the records where they go (`w`: the pair's place in the staging area).
 template <int S>
+__device__ __noinline__ void setup_clipped(const rh_draw_params& p, uint32_t instance, uint32_t i0, uint32_t i1, uint32_t i2, bool whole,
+                                           uint32_t piece, int ox, int oy, uint32_t* w, uint32_t* ext) {
+    PairSetup s;
+    if (whole) {
+        if (piece == 0u) {
+            const SnappedVertex v0 = run_vertex(p, i0, instance), v1 = run_vertex(p, i1, instance), v2 = run_vertex(p, i2, instance);
+            s.has_a = setup_triangle(p, v0, v1, v2, ox, oy, s.ta, s.persp_a, s.big, s.bx0, s.by0, s.bx1, s.by1);
+        }
+    } else {
+        ClipPolygon poly;
+        clip_triangle(p, instance, i0, i1, i2, poly);
+        const int f = 2 * (int)piece;
+        if (f + 2 < poly.n) s.has_a = setup_triangle(p, poly.v[0], poly.v[f + 1], poly.v[f + 2], ox, oy, s.ta, s.persp_a, s.big, s.bx0, s.by0, s.bx1, s.by1);
+        if (f + 3 < poly.n) s.has_b = setup_triangle(p, poly.v[0], poly.v[f + 2], poly.v[f + 3], ox, oy, s.tb, s.persp_b, s.big, s.bx0, s.by0, s.bx1, s.by1);
+    }
+    if (s.has_a || s.has_b) s.bbox = (uint32_t)s.bx0 | ((uint32_t)s.by0 << 8) | ((uint32_t)s.bx1 << 16) | ((uint32_t)s.by1 << 24);
+    write_records<S>(s, ox, oy, w, ext);
+}
+
+// Sets up the triangles of pair value `value` (cluster | sub-record << CLIP_SUB_SHIFT) for the tile at (ox, oy) and
+// writes the pair's records (`stage`: the pair's REC_WORDS dwords of the staging area).  S > 1 (multisampled pass) also
+// writes the per-sample constants and never takes the exact-box shortcut.  CLIP: the clipping kernels (see
+// rh_geometry.h); the others leave out what is not inside the clip volume as it is.
+template <int S, bool CLIP>
+RH_DEVICE void setup_pair(const rh_draw_params& p, uint32_t value, int ox, int oy, uint4* stage, uint32_t* ext) {
+    const uint32_t cluster = value & CLIP_CLUSTER_MASK, sub = value >> CLIP_SUB_SHIFT;
+    const uint32_t instance = cluster / p.cpi, local = cluster - instance * p.cpi;
+    const uint32_t tri0 = local * 2;
+    const bool has_second = tri0 + 1 < p.tpi;
+    // Strip: triangle A = (v0, v1, v2), triangle B = (v1, v3, v2) with v_i = vertex tri0 + i (4 vertex runs).
+    // List:  triangle A = (v0, v1, v2), triangle B = (v3, v4, v5) with v_i = vertex 3*tri0 + i.
+    const bool strip = p.topology == 1u;
+    const uint32_t first = strip ? tri0 : 3 * tri0;
+    const SnappedVertex v0 = run_vertex(p, first, instance);
+    const SnappedVertex v1 = run_vertex(p, first + 1, instance);
+    const SnappedVertex v2 = run_vertex(p, first + 2, instance);
+    // triangle B's vertices (b0, b1, b2)
+    SnappedVertex b0 = v1, b1 = v1, b2 = v2;
+    if (has_second) {
+        b1 = run_vertex(p, first + 3, instance);
+        if (!strip) { b0 = b1; b1 = run_vertex(p, first + 4, instance); b2 = run_vertex(p, first + 5, instance); }
+    }
+    if (CLIP) {
+        const int kind_a = classify(v0, v1, v2), kind_b = has_second ? classify(b0, b1, b2) : TRI_DROPPED;
+        if (kind_a == TRI_CLIPPED || kind_b == TRI_CLIPPED) {
+            // a clipped cluster: sub-records 0..3 belong to triangle A, 4..7 to triangle B
+            uint32_t* const w = reinterpret_cast<uint32_t*>(stage);
+            const int kind = sub < 4u ? kind_a : kind_b;
+            if (kind == TRI_DROPPED) { PairSetup none; write_records<S>(none, ox, oy, w, ext); }
+            else if (sub < 4u) setup_clipped<S>(p, instance, first, first + 1, first + 2, kind == TRI_WHOLE, sub, ox, oy, w, ext);
+            else setup_clipped<S>(p, instance, strip ? first + 1 : first + 3, strip ? first + 3 : first + 4, strip ? first + 2 : first + 5, kind == TRI_WHOLE, sub - 4u, ox, oy, w, ext);
+            return;
+        }
+    }
+    PairSetup s;
+    int32_t rminX = 0, rmaxX = 0, rminY = 0, rmaxY = 0;
+    if (has_second && strip) {
+        const SnappedVertex& v3 = b1;
+        // a strip quad whose snapped corners form an axis-aligned rectangle split along v1-v2: with affine varyings and
+        // sides short enough for the f32 coverage path it is drawn from the shared diagonal alone (edge 1 of triangle A)
+        const bool columns = v0.X == v1.X && v2.X == v3.X && v0.Y == v2.Y && v1.Y == v3.Y;
+        const bool rows = v0.Y == v1.Y && v2.Y == v3.Y && v0.X == v2.X && v1.X == v3.X;
+        rminX = min(v0.X, v3.X); rmaxX = max(v0.X, v3.X); rminY = min(v0.Y, v3.Y); rmaxY = max(v0.Y, v3.Y);
+        const bool shape = S == 1 && (columns || rows) && v0.X != v3.X && v0.Y != v3.Y;
+        const bool lean = shape && rmaxX - rminX < F32_EDGE_LIMIT && rmaxY - rminY < F32_EDGE_LIMIT &&
+                          v0.rw == 1.0f && v1.rw == 1.0f && v2.rw == 1.0f && v3.rw == 1.0f;
+        s.has_a = setup_triangle(p, v0, v1, v2, ox, oy, s.ta, s.persp_a, s.big, s.bx0, s.by0, s.bx1, s.by1, lean ? 2u : 7u);
+        s.has_b = setup_triangle(p, v1, v3, v2, ox, oy, s.tb, s.persp_b, s.big, s.bx0, s.by0, s.bx1, s.by1, lean ? 0u : 7u);
+        s.rect = shape && s.has_a && s.has_b && !s.big;
+    } else {
+        s.has_a = setup_triangle(p, v0, v1, v2, ox, oy, s.ta, s.persp_a, s.big, s.bx0, s.by0, s.bx1, s.by1);
+        if (has_second) s.has_b = setup_triangle(p, b0, b1, b2, ox, oy, s.tb, s.persp_b, s.big, s.bx0, s.by0, s.bx1, s.by1);
+    }
+    if (s.has_a || s.has_b) {
+        if (s.rect) {
+            // Exact pixel set of the rectangle under the top-left rule: left and top edges take pixel centres on them,
+            // right and bottom edges do not.  Inside it every pixel belongs to exactly one of the two triangles, decided
+            // by the shared diagonal alone (edge 1 of triangle A).
+            const int ex0 = max(max(p.sc_x0, ox), (rminX + 255) >> 8), ex1 = min(min(p.sc_x1 - 1, ox + TILE - 1), (rmaxX - 1) >> 8);
+            const int ey0 = max(max(p.sc_y0, oy), (rminY + 255) >> 8), ey1 = min(min(p.sc_y1 - 1, oy + TILE - 1), (rmaxY - 1) >> 8);
+            if (ex0 <= ex1 && ey0 <= ey1) s.bbox = (uint32_t)(ex0 - ox) | ((uint32_t)(ey0 - oy) << 8) | ((uint32_t)(ex1 - ox) << 16) | ((uint32_t)(ey1 - oy) << 24);
+        } else s.bbox = (uint32_t)s.bx0 | ((uint32_t)s.by0 << 8) | ((uint32_t)s.bx1 << 16) | ((uint32_t)s.by1 << 24);
+    }
+    uint32_t w[REC_WORDS];
+    write_records<S>(s, ox, oy, w, ext);
+#pragma unroll
+    for (int q = 0; q < REC_WORDS / 4; q++) stage[q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+}
+
+template <int S, bool CLIP = false>
 RH_DEVICE void setup_kernel(const rh_setup_args& a) {
     uint32_t n = a.n_pairs;
     if (a.pair_total) { if (*a.pair_total > n) return; n = (uint32_t)*a.pair_total; }   // (n arrives as the room for the pairs)
@@ -352,10 +406,7 @@ RH_DEVICE void setup_kernel(const rh_setup_args& a) {
         if (i == 0u || a.tiles[i - 1u] != tile) a.tile_start[tile] = i;
         if (i == n - 1u || a.tiles[i + 1u] != tile) a.tile_end[tile] = i + 1u;
         const int ox = (int)(tile % a.p.tiles_x) * TILE, oy = (int)(tile / a.p.tiles_x) * TILE;
-        uint32_t w[REC_WORDS];
-        setup_pair<S>(a.p, a.clusters[i], ox, oy, w, reinterpret_cast<uint32_t*>(a.ext + (size_t)i * a.ext_bytes));
-#pragma unroll
-        for (int q = 0; q < REC_WORDS / 4; q++) stage[threadIdx.x * (REC_WORDS / 4) + q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+        setup_pair<S, CLIP>(a.p, a.clusters[i], ox, oy, &stage[threadIdx.x * (REC_WORDS / 4)], reinterpret_cast<uint32_t*>(a.ext + (size_t)i * a.ext_bytes));
     }
     __syncthreads();
     const uint32_t pieces = min(256u, n - first) * (REC_WORDS / 4);
@@ -914,6 +965,10 @@ extern "C" __global__ __launch_bounds__(256) void rh_setup(rh_setup_args a) { rh
 extern "C" __global__ __launch_bounds__(256) void rh_setup_ms2(rh_setup_args a) { rh::setup_kernel<2>(a); }
 extern "C" __global__ __launch_bounds__(256) void rh_setup_ms4(rh_setup_args a) { rh::setup_kernel<4>(a); }
 extern "C" __global__ __launch_bounds__(256) void rh_setup_ms8(rh_setup_args a) { rh::setup_kernel<8>(a); }
+extern "C" __global__ __launch_bounds__(256) void rh_setup_clip(rh_setup_args a) { rh::setup_kernel<1, true>(a); }
+extern "C" __global__ __launch_bounds__(256) void rh_setup_clip_ms2(rh_setup_args a) { rh::setup_kernel<2, true>(a); }
+extern "C" __global__ __launch_bounds__(256) void rh_setup_clip_ms4(rh_setup_args a) { rh::setup_kernel<4, true>(a); }
+extern "C" __global__ __launch_bounds__(256) void rh_setup_clip_ms8(rh_setup_args a) { rh::setup_kernel<8, true>(a); }
 extern "C" __global__ __launch_bounds__(RH_TILE_THREADS, RH_TILE_MIN_WAVES) void rh_tile_1(rh_tile_args a) { rh::tile_dispatch<1>(a); }
 extern "C" __global__ __launch_bounds__(RH_TILE_THREADS, RH_TILE_MIN_WAVES) void rh_tile_2(rh_tile_args a) { rh::tile_dispatch<2>(a); }
 extern "C" __global__ __launch_bounds__(RH_TILE_THREADS, RH_TILE_MIN_WAVES) void rh_tile_3(rh_tile_args a) { rh::tile_dispatch<3>(a); }

@@ -14,33 +14,61 @@ extern "C" __device__ const rh_module_info_t rh_module_info = {
 
 namespace {
 
-// The inclusive rectangle of tiles the bounding box of `cluster` touches; returns the number of tiles (0: none).
-__device__ __forceinline__ uint32_t cluster_tiles(const rh_draw_params& p, uint32_t cluster, uint32_t& tx0, uint32_t& ty0, uint32_t& tx1, uint32_t& ty1) {
+// Bounding box of the part of triangle (i0, i1, i2) of `instance` inside the clip volume, grown into (bx0 .. by1).
+__device__ __noinline__ void clipped_bbox(const rh_draw_params& p, uint32_t instance, uint32_t i0, uint32_t i1, uint32_t i2,
+                                          int& bx0, int& by0, int& bx1, int& by1) {
+    rh::ClipPolygon poly;
+    rh::clip_triangle(p, instance, i0, i1, i2, poly);
+    for (int i = 2; i < poly.n; i++) {
+        int x0, y0, x1, y1;
+        if (rh::tri_pixel_bbox(p, poly.v[0], poly.v[i - 1], poly.v[i], x0, y0, x1, y1)) { bx0 = min(bx0, x0); by0 = min(by0, y0); bx1 = max(bx1, x1); by1 = max(by1, y1); }
+    }
+}
+
+// The inclusive rectangle of tiles the bounding box of `cluster` touches; returns the number of (tile, cluster) pairs
+// the cluster makes (0: none).  CLIP (the clipping kernels): a cluster with a triangle that needs clipping makes
+// rh::CLIP_SUBS pairs per tile and has RH_RANGE_CLIPPED set in tx0.  Otherwise such a triangle is left out and
+// `wants_clip` is set: the pass has to run again with the clipping kernels.
+template <bool CLIP>
+__device__ __forceinline__ uint32_t cluster_tiles(const rh_draw_params& p, uint32_t cluster, uint32_t& tx0, uint32_t& ty0, uint32_t& tx1, uint32_t& ty1, bool& wants_clip) {
     const uint32_t instance = cluster / p.cpi, local = cluster - instance * p.cpi;
     int bx0 = 0x7fffffff, by0 = 0x7fffffff, bx1 = -1, by1 = -1;
-    int x0, y0, x1, y1;
     const uint32_t tri0 = local * 2u;
     const bool second = tri0 + 1u < p.tpi;
+    bool clipped = false;
+    auto triangle = [&](const rh::SnappedVertex& a, const rh::SnappedVertex& b, const rh::SnappedVertex& c, uint32_t i0, uint32_t i1, uint32_t i2) {
+        int x0, y0, x1, y1;
+        const int kind = rh::classify(a, b, c);
+        if (kind == rh::TRI_WHOLE) {
+            if (rh::tri_pixel_bbox(p, a, b, c, x0, y0, x1, y1)) { bx0 = min(bx0, x0); by0 = min(by0, y0); bx1 = max(bx1, x1); by1 = max(by1, y1); }
+        } else if (kind == rh::TRI_CLIPPED) {
+            clipped = true;
+            if (CLIP) clipped_bbox(p, instance, i0, i1, i2, bx0, by0, bx1, by1);
+        }
+    };
     if (p.topology == 1u) {
-        // strip: the two triangles share two of their four vertices (the order of a triangle's vertices does not matter here)
+        // strip: the two triangles share two of their four vertices
         const rh::SnappedVertex v0 = rh::run_vertex(p, tri0, instance), v1 = rh::run_vertex(p, tri0 + 1u, instance), v2 = rh::run_vertex(p, tri0 + 2u, instance);
-        if (rh::tri_pixel_bbox(p, v0, v1, v2, x0, y0, x1, y1)) { bx0 = x0; by0 = y0; bx1 = x1; by1 = y1; }
+        triangle(v0, v1, v2, tri0, tri0 + 1u, tri0 + 2u);
         if (second) {
             const rh::SnappedVertex v3 = rh::run_vertex(p, tri0 + 3u, instance);
-            if (rh::tri_pixel_bbox(p, v1, v2, v3, x0, y0, x1, y1)) { bx0 = min(bx0, x0); by0 = min(by0, y0); bx1 = max(bx1, x1); by1 = max(by1, y1); }
+            triangle(v1, v3, v2, tri0 + 1u, tri0 + 3u, tri0 + 2u);
         }
     } else {
         for (uint32_t k = 0; k < (second ? 2u : 1u); k++) {
             const uint32_t first = 3u * (tri0 + k);
             const rh::SnappedVertex v0 = rh::run_vertex(p, first, instance), v1 = rh::run_vertex(p, first + 1u, instance), v2 = rh::run_vertex(p, first + 2u, instance);
-            if (rh::tri_pixel_bbox(p, v0, v1, v2, x0, y0, x1, y1)) { bx0 = min(bx0, x0); by0 = min(by0, y0); bx1 = max(bx1, x1); by1 = max(by1, y1); }
+            triangle(v0, v1, v2, first, first + 1u, first + 2u);
         }
     }
+    if (!CLIP && clipped) { wants_clip = true; clipped = false; }
     tx0 = 1u; ty0 = 0u; tx1 = 0u; ty1 = 0u;             // x0 = 1 > x1 = 0: empty
     if (bx1 < bx0 || by1 < by0) return 0u;
     tx0 = (uint32_t)bx0 / RH_TILE_W; ty0 = (uint32_t)by0 / RH_TILE_H;
     tx1 = (uint32_t)bx1 / RH_TILE_W; ty1 = (uint32_t)by1 / RH_TILE_H;
-    return (tx1 - tx0 + 1) * (ty1 - ty0 + 1);
+    const uint32_t tiles = (tx1 - tx0 + 1) * (ty1 - ty0 + 1);
+    if (clipped) tx0 |= RH_RANGE_CLIPPED;
+    return clipped ? tiles * rh::CLIP_SUBS : tiles;
 }
 
 __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane) {
@@ -58,15 +86,18 @@ constexpr unsigned long long STATUS_VALUE = (1ull << 62) - 1ull;
 
 // One thread per cluster.  Writes the cluster's inclusive tile rectangle and the per-workgroup sum of tile counts
 // (the scan of those sums gives every workgroup its base offset in the (tile, cluster) pair array).
-extern "C" __global__ __launch_bounds__(256) void rh_bin_count(rh_bin_count_args a) {
+template <bool CLIP>
+__device__ __forceinline__ void bin_count(const rh_bin_count_args& a) {
     const rh_draw_params& p = a.p;
     const uint32_t cluster = blockIdx.x * 256u + threadIdx.x;
     uint32_t count = 0;
     if (cluster < p.n_clusters) {
         rh_tile_range r; uint32_t tx0, ty0, tx1, ty1;
-        count = cluster_tiles(p, cluster, tx0, ty0, tx1, ty1);
+        bool wants_clip = false;
+        count = cluster_tiles<CLIP>(p, cluster, tx0, ty0, tx1, ty1, wants_clip);
         r.lo = tx0 | (ty0 << 16); r.hi = tx1 | (ty1 << 16);
         a.ranges[cluster] = r;
+        if (wants_clip) *a.wants_clip = 1u;
     }
     // workgroup sum: wave reduce, then 4 partials through LDS
     __shared__ uint32_t partial[4];
@@ -76,33 +107,39 @@ extern "C" __global__ __launch_bounds__(256) void rh_bin_count(rh_bin_count_args
     __syncthreads();
     if (threadIdx.x == 0) a.block_sums[blockIdx.x] = partial[0] + partial[1] + partial[2] + partial[3];
 }
+extern "C" __global__ __launch_bounds__(256) void rh_bin_count(rh_bin_count_args a) { bin_count<false>(a); }
+extern "C" __global__ __launch_bounds__(256) void rh_bin_count_clip(rh_bin_count_args a) { bin_count<true>(a); }
 
 // The pair array in one launch (see rh_bin_pairs_args).  Workgroup `part` (its ticket) owns clusters
 // [RH_PAIR_PART * part, RH_PAIR_PART * (part + 1)), every thread RH_PAIR_PER_THREAD consecutive ones; the pairs of a
 // cluster are its tiles in row-major order, clusters in order.  (Large parts: every workgroup costs a ticket, a slot in
 // the look-back chain and an add per digit value, and adds to one word go one at a time.)
-extern "C" __global__ __launch_bounds__(RH_PAIR_THREADS) void rh_bin_pairs(rh_bin_pairs_args a) {
+template <bool CLIP>
+__device__ __forceinline__ void bin_pairs(const rh_bin_pairs_args& a) {
     const rh_draw_params& p = a.p;
     constexpr uint32_t PART = RH_PAIR_PART, THREADS = RH_PAIR_THREADS, PER = RH_PAIR_PER_THREAD, WAVES = THREADS / 64u;
     static_assert(PART == THREADS * PER, "part size");
-    __shared__ uint32_t s_part;
+    __shared__ uint32_t s_part, s_wants_clip;
     __shared__ uint32_t wave_sum[WAVES];
     __shared__ unsigned long long s_base;
     __shared__ uint32_t digits[RH_SORT_MAX_PASSES][256];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     if (a.ticketed && threadIdx.x == 0) s_part = atomicAdd(&a.state->ticket[0], 1u);
+    if (threadIdx.x == 0) s_wants_clip = 0u;
     if (threadIdx.x < 256u) for (uint32_t k = 0; k < a.sort_passes; k++) digits[k][threadIdx.x] = 0u;
     __syncthreads();
     const uint32_t part = a.ticketed ? s_part : blockIdx.x, n_parts = (p.n_clusters + PART - 1u) / PART;
     if (part >= n_parts) return;
     const uint32_t cluster0 = part * PART + threadIdx.x * PER;
     uint32_t tx0[PER], ty0[PER], tx1[PER], ty1[PER], cnt[PER], count = 0u;
+    bool wants_clip = false;
 #pragma unroll
     for (uint32_t j = 0; j < PER; j++) {
         tx0[j] = 1u; ty0[j] = 0u; tx1[j] = 0u; ty1[j] = 0u; cnt[j] = 0u;
-        if (cluster0 + j < p.n_clusters) cnt[j] = cluster_tiles(p, cluster0 + j, tx0[j], ty0[j], tx1[j], ty1[j]);
+        if (cluster0 + j < p.n_clusters) cnt[j] = cluster_tiles<CLIP>(p, cluster0 + j, tx0[j], ty0[j], tx1[j], ty1[j], wants_clip);
         count += cnt[j];
     }
+    if (wants_clip) s_wants_clip = 1u;
     const uint32_t inc = wave_inclusive_scan(count, (int)lane);
     if (lane == 63u) wave_sum[wave] = inc;
     __syncthreads();
@@ -110,6 +147,9 @@ extern "C" __global__ __launch_bounds__(RH_PAIR_THREADS) void rh_bin_pairs(rh_bi
     unsigned long long part_total = 0ull;
 #pragma unroll
     for (uint32_t w = 0; w < WAVES; w++) { const uint32_t ws = wave_sum[w]; part_total += ws; if (w < wave) before += ws; }
+    // A triangle that needs clipping (these kernels leave it out): the part's count is pushed beyond any capacity, so the
+    // total of the pass is, nobody after this kernel writes anything, and the host runs the pass with the clipping kernels.
+    if (!CLIP && s_wants_clip) part_total += RH_WANTS_CLIP;
     if (wave == 0u) {
         // the look-back: lane i polls the i-th predecessor of the current window of 64
         unsigned long long* const status = a.cluster_status;
@@ -151,26 +191,32 @@ extern "C" __global__ __launch_bounds__(RH_PAIR_THREADS) void rh_bin_pairs(rh_bi
     for (uint32_t j = 0; j < PER; j++) {
         const bool big = cnt[j] > 32u;
         const unsigned long long first = off;
+        // a clipped cluster: CLIP_SUBS pairs per tile, the sub-record number above the cluster in the pair's value
+        const uint32_t sub_shift = (tx0[j] & RH_RANGE_CLIPPED) ? 3u : 0u, cx0 = tx0[j] & ~RH_RANGE_CLIPPED;
+        static_assert(rh::CLIP_SUBS == 8u, "sub_shift");
         if (!big)
             for (uint32_t ty = ty0[j]; ty <= ty1[j]; ty++)
-                for (uint32_t tx = tx0[j]; tx <= tx1[j]; tx++, off++) {
-                    if (off >= a.capacity) continue;
-                    const uint32_t tile = ty * p.tiles_x + tx;
-                    a.keys[off] = tile; a.vals[off] = cluster0 + j;
-                    for (uint32_t k = 0; k < passes; k++) atomicAdd(&digits[k][(tile >> (8u * k)) & 0xffu], 1u);
-                }
+                for (uint32_t tx = cx0; tx <= tx1[j]; tx++)
+                    for (uint32_t sub = 0; sub < (1u << sub_shift); sub++, off++) {
+                        if (off >= a.capacity) continue;
+                        const uint32_t tile = ty * p.tiles_x + tx;
+                        a.keys[off] = tile; a.vals[off] = (cluster0 + j) | (sub << rh::CLIP_SUB_SHIFT);
+                        for (uint32_t k = 0; k < passes; k++) atomicAdd(&digits[k][(tile >> (8u * k)) & 0xffu], 1u);
+                    }
         else off += cnt[j];
-        // clusters that touch more than 32 tiles are written by the whole wave, one after the other
+        // clusters with more than 32 pairs are written by the whole wave, one after the other
         for (unsigned long long todo = __ballot(big); todo; todo &= todo - 1ull) {
             const int src = __builtin_ctzll(todo);
             const uint32_t lo = __shfl(tx0[j] | (ty0[j] << 16), src), hi = __shfl(tx1[j] | (ty1[j] << 16), src), cc = __shfl(cluster0 + j, src);
             const unsigned long long o = __shfl(first, src);
-            const uint32_t x0 = lo & 0xffffu, y0 = lo >> 16, x1 = hi & 0xffffu, y1 = hi >> 16;
-            const uint32_t w = x1 - x0 + 1u, n = w * (y1 - y0 + 1u);
+            const uint32_t sh = (lo & RH_RANGE_CLIPPED) ? 3u : 0u;
+            const uint32_t x0 = lo & 0x7fffu, y0 = lo >> 16, x1 = hi & 0xffffu, y1 = hi >> 16;
+            const uint32_t w = x1 - x0 + 1u, n = (w * (y1 - y0 + 1u)) << sh;
             for (uint32_t i = lane; i < n; i += 64u) {
                 if (o + i >= a.capacity) break;
-                const uint32_t tile = (y0 + i / w) * p.tiles_x + (x0 + i % w);
-                a.keys[o + i] = tile; a.vals[o + i] = cc;
+                const uint32_t t = i >> sh, sub = i & ((1u << sh) - 1u);
+                const uint32_t tile = (y0 + t / w) * p.tiles_x + (x0 + t % w);
+                a.keys[o + i] = tile; a.vals[o + i] = cc | (sub << rh::CLIP_SUB_SHIFT);
                 for (uint32_t k = 0; k < passes; k++) atomicAdd(&digits[k][(tile >> (8u * k)) & 0xffu], 1u);
             }
         }
@@ -183,3 +229,5 @@ extern "C" __global__ __launch_bounds__(RH_PAIR_THREADS) void rh_bin_pairs(rh_bi
             if (c) atomicAdd(&a.state->digit_count[k][part % RH_DIGIT_COPIES][threadIdx.x], c);
         }
 }
+extern "C" __global__ __launch_bounds__(RH_PAIR_THREADS) void rh_bin_pairs(rh_bin_pairs_args a) { bin_pairs<false>(a); }
+extern "C" __global__ __launch_bounds__(RH_PAIR_THREADS) void rh_bin_pairs_clip(rh_bin_pairs_args a) { bin_pairs<true>(a); }

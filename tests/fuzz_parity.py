@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity sweep: HIP renderer against the CPU oracle, bit for bit, over scenes with random sizes, quad
-shapes (sub-pixel, tiny, tile-spanning, partly or wholly off-screen, degenerate, non-rectangular), topologies, blend
+shapes (sub-pixel, tiny, tile-spanning, partly or wholly off-screen, degenerate, non-rectangular, crossing the clip
+planes), topologies, blend
 modes, filters, viewports, clip switch, target formats, sample counts and LoadOp::Load.  Stops at the first mismatch
 and prints the seed that reproduces it.
 
@@ -26,13 +27,20 @@ f32 = np.float32
 def random_scene(rng):
     import scenes
     W = int(rng.integers(1, 700)); H = int(rng.integers(1, 400))
-    shader = rng.choice(["hello", "hello", "sized", "tilted"])
+    shader = rng.choice(["hello", "hello", "sized", "tilted", "space"])
     n = int(rng.choice([0, 1, 2, 7, 64, 65, 300, 2000, 6000]))
     blend = str(rng.choice(["premultiplied", "additive"]))
     flt = str(rng.choice(["linear", "nearest"]))
     if shader == "tilted":
         scene = scenes.tilted_quads_scene(max(n, 1), W, H, seed=int(rng.integers(1 << 30)), blend=blend, filter=flt)
         scene["instances"][:, 2] *= f32(rng.choice([0.2, 1.0, 3.0]))
+        scene["instances"][:, 3] *= f32(rng.choice([1.0, 1.0, 2.5]))      # |tilt| > 1: corners behind the eye (clipped)
+    elif shader == "space":
+        # quads in space: triangles crossing the near / far planes, the eye plane and the guard band
+        scene = scenes.space_quads_scene(max(min(n, 600), 1), W, H, seed=int(rng.integers(1 << 30)), blend=blend, filter=flt,
+                                         near=float(rng.choice([0.05, 0.5, 1.5])), far=float(rng.choice([3.0, 6.0, 50.0])),
+                                         tilt_deg=float(rng.uniform(0.0, 89.0)), half_range=(0.02, float(rng.choice([0.3, 1.5, 6.0]))),
+                                         topology=str(rng.choice(["strip", "list"])), spread=float(rng.choice([1.0, 3.0, 30.0])))
     elif shader == "sized":
         lo = int(rng.integers(1, 6)); hi = lo + int(rng.integers(0, 40))
         scene = scenes.tiny_quads_scene(max(n, 1), W, H, seed=int(rng.integers(1 << 30)), lo=lo, hi=hi)

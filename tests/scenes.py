@@ -3,6 +3,7 @@ both by the HIP renderer (through renderer_amd, i.e. the C ABI) and by the CPU o
 
 Scene keys
   shader        'hello' | 'sized' | 'tilted' (projective quads; needs 'uniform': float32 [6]) |
+                'space' (quads in space; 'uniform': float32 [20] = tint + column-major 4x4 matrix) |
                 'layered' (hello sampling layer uniform[0] of a 2D-array texture; needs 'uniform' and 'texture_layers')
   width,height  window / target size
   target        'screen' (BGRA8 offscreen screen) | 'texture' (RGBA8 texture target)
@@ -122,7 +123,7 @@ def draw_oracle(scene, threads=0, clip_to_viewport=True, initial=None, msaa=None
     samples = scene.get("samples", 1)
     if samples > 1:
         msaa = np.zeros((H, W, samples, 4), dtype=np.uint8) if msaa is None else msaa.copy()
-    n = O.render(shader={"hello": O.SHADER_HELLO, "sized": O.SHADER_SIZED, "tilted": O.SHADER_TILTED,
+    n = O.render(shader={"hello": O.SHADER_HELLO, "sized": O.SHADER_SIZED, "tilted": O.SHADER_TILTED, "space": O.SHADER_SPACE,
                          "layered": O.SHADER_HELLO_LAYER}[scene["shader"]],
                  uniforms=[scene["uniform"]] if "uniform" in scene else (),
                  topology=O.TOPO_TRIANGLE_STRIP if scene["topology"] == "strip" else O.TOPO_TRIANGLE_LIST,
@@ -264,4 +265,39 @@ def tilted_quads_scene(n, width, height, seed, blend="premultiplied", filter="li
                  texture_format="rgba_u8", filter=filter, blend=blend, topology="strip", clear=(0.1, 0.1, 0.1, 1.0),
                  viewport=None, record=False)
     scene["uniform"] = np.array([1.0, 0.8, 0.6, 0.9, 1.0, 0.75], dtype=f32)
+    return scene
+
+
+def perspective_matrix(fov_y_deg, aspect, near, far):
+    """Column-major projection with the 0..1 depth range (the camera looks down -z), as float32 [16]."""
+    f = 1.0 / np.tan(np.radians(fov_y_deg) / 2.0)
+    m = np.zeros((4, 4), dtype=np.float64)
+    m[0, 0] = f / aspect; m[1, 1] = f
+    m[2, 2] = far / (near - far); m[2, 3] = near * far / (near - far)
+    m[3, 2] = -1.0
+    return m
+
+
+def space_quads_scene(n, width, height, seed, blend="premultiplied", filter="linear", near=0.5, far=6.0, tilt_deg=70.0,
+                      depth_range=(-7.0, 1.0), half_range=(0.05, 1.5), topology="strip", spread=3.0):
+    """Quads in space: a ground-plane-like set of quads tilted away from the camera, many of them crossing the near and
+    far planes, some reaching behind the eye (w <= 0) and some far outside the guard band."""
+    rng = np.random.default_rng(seed)
+    a = np.radians(tilt_deg)
+    rot = np.array([[1, 0, 0, 0], [0, np.cos(a), -np.sin(a), 0], [0, np.sin(a), np.cos(a), 0], [0, 0, 0, 1]], dtype=np.float64)
+    trans = np.eye(4); trans[2, 3] = -2.0; trans[1, 3] = -0.3
+    m = perspective_matrix(60.0, width / height, near, far) @ trans @ rot
+    cx = rng.uniform(-spread, spread, n).astype(f32); cy = rng.uniform(-spread, spread, n).astype(f32)
+    half = rng.uniform(*half_range, n).astype(f32)
+    depth = rng.uniform(*depth_range, n).astype(f32)
+    if topology == "strip":
+        position, uv = UNIT_POSITION, QUAD_UV
+    else:
+        position = np.array([[-1., -1.], [-1., 1.], [1., -1.], [1., -1.], [-1., 1.], [1., 1.]], dtype=f32)
+        uv = np.array([[0., 1.], [0., 0.], [1., 1.], [1., 1.], [0., 0.], [1., 0.]], dtype=f32)
+    scene = dict(shader="space", width=width, height=height, target="texture", position=position, uv=uv,
+                 instances=np.stack([cx, cy, half, depth], axis=1).astype(f32), texture=load_letter_f(),
+                 texture_format="rgba_u8", filter=filter, blend=blend, topology=topology, clear=(0.1, 0.1, 0.1, 1.0),
+                 viewport=None, record=False)
+    scene["uniform"] = np.concatenate([np.array([1.0, 0.9, 0.8, 0.9]), m.T.reshape(-1)]).astype(f32)
     return scene

@@ -240,6 +240,41 @@ def test_huge_and_far_away_quads(oracle):
     assert orc["fragments"] > 700 * 500
 
 
+@pytest.mark.parametrize("topology,blend", [("strip", "premultiplied"), ("list", "additive")])
+def test_quads_in_space_are_clipped_like_the_oracle(oracle, topology, blend):
+    """Triangles that cross the near and far planes, reach behind the eye (w <= 0) or far beyond the guard band are
+    clipped (reference src/pipeline.rs:197-207: depth clipping on), not dropped: bit-exact against the oracle's clipper,
+    on the first pass of a device and on one queued before its pair count is known."""
+    scene = scenes.space_quads_scene(400, 640, 400, seed=41, blend=blend, topology=topology)
+    orc = scenes.draw_oracle(scene)
+    for twice in (False, True):
+        hip = scenes.draw_hip(scene, twice=twice)
+        assert_same(hip["color"], orc["color"], f"space/{topology}/{blend}/twice={twice}")
+    # the scene does exercise the clipper: with every crossing triangle dropped it looks different
+    inside = scenes.space_quads_scene(400, 640, 400, seed=41, blend=blend, topology=topology, half_range=(0.01, 0.02))
+    assert orc["fragments"] > 50_000 and scenes.draw_oracle(inside)["fragments"] < orc["fragments"] // 10
+
+
+def test_clipped_quads_many_tiles_and_recording(oracle):
+    """A few very large clipped quads over a 1920x1080 target (two sorting passes, hundreds of pairs per cluster, eight
+    sub-records per tile) with the recording attachment."""
+    scene = scenes.space_quads_scene(30, 1920, 1080, seed=42, half_range=(1.0, 4.0))
+    scene["record"] = True
+    orc = scenes.draw_oracle(scene)
+    hip = scenes.draw_hip(scene, twice=True)
+    assert_same(hip["color"], orc["color"], "space large")
+    assert_same(hip["recording"], orc["recording"], "space large recording")
+
+
+def test_clipped_quads_multisampled(oracle):
+    scene = scenes.space_quads_scene(120, 320, 200, seed=43)
+    scene["samples"] = 4
+    orc = scenes.draw_oracle(scene)
+    hip = scenes.draw_hip(scene)
+    assert_same(hip["color"], orc["color"], "space 4x")
+    assert_same(hip["msaa"].reshape(200, 320 * 4, 4), orc["msaa"].reshape(200, 320 * 4, 4), "space 4x samples")
+
+
 def test_no_instances_only_clears(oracle):
     scene = scenes.random_quads_scene(4, 16, 200, 100, seed=24, clear=(0.2, 0.4, 0.6, 1.0))
     scene["instances"] = np.zeros((0, 2), dtype=np.float32)

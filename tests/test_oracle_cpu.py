@@ -295,6 +295,52 @@ def test_perspective_correct_interpolation_against_float64(oracle):
     assert checked > 1500
 
 
+# ---- clipping ---------------------------------------------------------------------------------------------------------------
+def test_quad_reaching_behind_the_eye_is_cut_at_w_zero(oracle):
+    """The unit quad under the homography (x, y, 0, 1 + 2x): its left part lies behind the eye (w < 0 for x < -1/2).
+    What is in front projects to x_ndc = x / (1 + 2x) < 1/3 with |y_ndc| <= 1 - 2 x_ndc; the texel sampled at a covered
+    pixel is the perspective-correct one, u = (x + 1) / 2 with x = x_ndc / (1 - 2 x_ndc) (closed form, float64)."""
+    W, H = 240, 120
+    ramp = np.zeros((1, 256, 4), dtype=np.uint8)
+    ramp[0, :, 0] = np.arange(256); ramp[0, :, 3] = 255
+    scene = scenes.space_quads_scene(1, W, H, seed=0, blend="additive", filter="nearest")
+    m = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 0, 0], [2, 0, 0, 1]], dtype=np.float64)
+    scene["uniform"] = np.concatenate([np.ones(4), m.T.reshape(-1)]).astype(f32)
+    scene["instances"] = np.array([[0.0, 0.0, 1.0, 0.0]], dtype=f32)
+    scene["texture"] = ramp
+    scene["clear"] = (0., 0., 0., 0.)
+    out = scenes.draw_oracle(scene)["color"]
+    covered = out[..., 3] > 0
+    ii, jj = np.meshgrid(np.arange(W) + 0.5, np.arange(H) + 0.5)
+    x_ndc = (ii / W - 0.5) * 2.0; y_ndc = (0.5 - jj / H) * 2.0
+    slack = 2.5 / H                                      # a pixel either way
+    sure_in = (x_ndc < 1.0 / 3.0 - 2.0 / W) & (np.abs(y_ndc) < 1.0 - 2.0 * x_ndc - 2.0 * slack)
+    sure_out = (x_ndc > 1.0 / 3.0 + 2.0 / W) | (np.abs(y_ndc) > 1.0 - 2.0 * x_ndc + 2.0 * slack)
+    assert covered[sure_in].all() and not covered[sure_out].any() and sure_in.sum() > 15000
+    x = x_ndc / (1.0 - 2.0 * x_ndc)
+    u = (x + 1.0) / 2.0
+    lo = np.clip(np.floor((u - 0.004) * 256.0), 0, 255); hi = np.clip(np.floor((u + 0.004) * 256.0), 0, 255)
+    got = out[..., 0].astype(np.float64)
+    assert ((got >= lo - 1) & (got <= hi + 1))[sure_in].all()
+
+
+def test_depth_clipping_keeps_zero_to_w(oracle):
+    """Quads in space under a matrix that maps z := x and leaves w = 1: only the part with 0 <= x_ndc <= 1 survives."""
+    W, H = 128, 64
+    scene = scenes.space_quads_scene(1, W, H, seed=0, blend="additive", filter="nearest")
+    m = np.eye(4); m[2, :] = [1, 0, 0, 0]                       # z = x
+    scene["uniform"] = np.concatenate([np.ones(4), m.T.reshape(-1)]).astype(f32)
+    scene["instances"] = np.array([[-0.031, 0.0, 0.9, 0.0]], dtype=f32)     # x_ndc in [-0.931, 0.869]
+    scene["clear"] = (0., 0., 0., 0.)
+    covered = scenes.draw_oracle(scene)["color"][..., 3] > 0
+    cols = np.nonzero(covered.any(axis=0))[0]
+    assert cols.min() == W // 2 and cols.max() == int(np.floor((0.869 * 0.5 + 0.5) * W - 0.5))
+    # the same quad pushed beyond z = w disappears, a NaN coordinate drops the triangle
+    m2 = m.copy(); m2[2, 3] = 2.0
+    scene["uniform"] = np.concatenate([np.ones(4), m2.T.reshape(-1)]).astype(f32)
+    assert not (scenes.draw_oracle(scene)["color"][..., 3] > 0).any()
+
+
 # ---- multisampling ----------------------------------------------------------------------------------------------------------
 # Standard sample locations inside a pixel (Vulkan 1.3, "Multisampling"), x right, y down.
 STANDARD_SAMPLES = {

@@ -82,7 +82,7 @@ def render(shader, topology, vertex_count, instance_count, attrs, storage, textu
     textures: list of (np.uint8 array [layers*H*W*C], width, height, layers, format, filter)
     targets:  list of dicts {data: np.uint8 [H, W, bytes per texel] (modified in place), format, clear: None | (r, g, b, a)}
     blend:    (src_factor, dst_factor)
-    samples:  1, or 2/4/8 with msaa = np.uint8 [H, W, samples, 4] (the pipeline's multisampled texture, modified in
+    samples:  1, or 2/4/8 with msaa = np.uint8 [H, W, samples, bytes per texel of the target] (the pipeline's multisampled texture, modified in
               place and resolved into the single target)
     Returns the number of fragments blended per attachment.
     """
@@ -124,7 +124,7 @@ def render(shader, topology, vertex_count, instance_count, attrs, storage, textu
     d.threads = threads
     if samples > 1:
         assert msaa is not None and msaa.dtype == np.uint8 and msaa.flags["C_CONTIGUOUS"]
-        assert msaa.shape == (targets[0]["data"].shape[0], targets[0]["data"].shape[1], samples, 4)
+        assert msaa.shape == (targets[0]["data"].shape[0], targets[0]["data"].shape[1], samples, targets[0]["data"].shape[2])
         d.samples, d.msaa = samples, msaa.ctypes.data
     rc = raster_lib().orc_render(C.byref(d))
     if rc != 0:

@@ -80,8 +80,8 @@ struct orc_draw {
     uint64_t fragments_out;          // out: number of blended fragments per attachment
     uint32_t samples;                // 0 or 1: single-sampled.  2, 4, 8: the pass renders into `msaa` and resolves into
                                      // targets[0] (reference src/render_pass.rs:76-81, src/pipeline.rs:164-176, 209-211)
-    uint8_t* msaa;                   // width*height*samples*4 bytes, the samples of a pixel adjacent, bytes in the order
-                                     // of targets[0].format; persists between passes (LoadOp::Load reads it back)
+    uint8_t* msaa;                   // width*height*samples texels of targets[0].format (reference src/pipeline.rs:164-176), the
+                                     // samples of a pixel adjacent; persists between passes (LoadOp::Load reads it back)
 };
 
 int orc_render(orc_draw* d);
@@ -486,42 +486,65 @@ inline void blend_store(const orc_draw& d, const orc_target& tg, size_t pix, con
     else { p[0] = q[0]; p[1] = q[1]; p[2] = q[2]; p[3] = q[3]; }
 }
 
-void clear_rows(const orc_target& tg, int y0, int y1, uint8_t* msaa = nullptr, uint32_t samples = 1) {
-    if (!tg.clear) return;
-    if (tg.format == ORC_FMT_RGBA_F32 || tg.format == ORC_FMT_RGBA_F16 || tg.format == ORC_FMT_R_U8) {
-        for (size_t pix = (size_t)y0 * tg.width; pix < (size_t)y1 * tg.width; pix++) {
-            if (tg.format == ORC_FMT_R_U8) { tg.data[pix] = to_unorm8((float)tg.clear_rgba[0]); continue; }
-            for (int k = 0; k < 4; k++) {
-                const float c = (float)tg.clear_rgba[k];
-                if (tg.format == ORC_FMT_RGBA_F32) std::memcpy(tg.data + (pix * 4 + k) * 4, &c, 4);
-                else { const uint16_t h = float_to_half(c); std::memcpy(tg.data + (pix * 4 + k) * 2, &h, 2); }
-            }
+inline uint32_t texel_bytes(uint32_t format) {
+    return format == ORC_FMT_R_U8 ? 1u : (format == ORC_FMT_RGBA_F16 ? 8u : (format == ORC_FMT_RGBA_F32 ? 16u : 4u));
+}
+
+// The clear colour as one texel of the target's format (reference src/clear_color.rs:7-16, src/render_pass.rs:71-74).
+inline void clear_texel(const orc_target& tg, uint8_t out[16]) {
+    if (tg.format == ORC_FMT_R_U8) { out[0] = to_unorm8((float)tg.clear_rgba[0]); return; }
+    if (tg.format == ORC_FMT_RGBA_F32 || tg.format == ORC_FMT_RGBA_F16) {
+        for (int k = 0; k < 4; k++) {
+            const float c = (float)tg.clear_rgba[k];
+            if (tg.format == ORC_FMT_RGBA_F32) std::memcpy(out + k * 4, &c, 4);
+            else { const uint16_t h = float_to_half(c); std::memcpy(out + k * 2, &h, 2); }
         }
         return;
     }
     uint8_t q[4];
     for (int k = 0; k < 4; k++) q[k] = to_unorm8((float)tg.clear_rgba[k]);
-    uint8_t px[4] = { q[0], q[1], q[2], q[3] };
-    if (tg.format == ORC_FMT_BGRA_U8) { px[0] = q[2]; px[2] = q[0]; }
-    if (msaa) {
-        for (size_t k = (size_t)y0 * tg.width * samples; k < (size_t)y1 * tg.width * samples; k++) std::memcpy(msaa + k * 4, px, 4);
-        return;
-    }
-    for (int y = y0; y < y1; y++) {
-        uint8_t* row = tg.data + (size_t)y * tg.width * 4;
-        for (uint32_t x = 0; x < tg.width; x++) std::memcpy(row + (size_t)x * 4, px, 4);
-    }
+    out[0] = q[0]; out[1] = q[1]; out[2] = q[2]; out[3] = q[3];
+    if (tg.format == ORC_FMT_BGRA_U8) { out[0] = q[2]; out[2] = q[0]; }
 }
 
-// Multisample resolve: per channel the mean of the samples, rounded to nearest, ties to even (the sum is exact).
+// Rows [y0, y1) of the target -- or, for a multisampled pass, of the multisampled texture (every sample).
+void clear_rows(const orc_target& tg, int y0, int y1, uint8_t* msaa = nullptr, uint32_t samples = 1) {
+    if (!tg.clear) return;
+    uint8_t px[16]; clear_texel(tg, px);
+    const uint32_t bpt = texel_bytes(tg.format);
+    uint8_t* const base = msaa ? msaa : tg.data;
+    const size_t per_row = (size_t)tg.width * (msaa ? samples : 1u);
+    for (size_t k = (size_t)y0 * per_row; k < (size_t)y1 * per_row; k++) std::memcpy(base + k * bpt, px, bpt);
+}
+
+// Multisample resolve: per channel the mean of the samples.  8-bit formats: the sum is exact, the mean rounded to
+// nearest, ties to even.  Float formats: the samples are added in f32 in sample order and multiplied by 1/S (exact);
+// an RGBA16F result is rounded to f16 (nearest even).
 void resolve_rows(const orc_target& tg, const uint8_t* msaa, uint32_t samples, int y0, int y1) {
     const float inv = 1.0f / (float)samples;
-    for (size_t pix = (size_t)y0 * tg.width; pix < (size_t)y1 * tg.width; pix++)
-        for (int k = 0; k < 4; k++) {
-            uint32_t sum = 0;
-            for (uint32_t sidx = 0; sidx < samples; sidx++) sum += msaa[(pix * samples + sidx) * 4 + k];
-            tg.data[pix * 4 + k] = (uint8_t)rintf((float)sum * inv);
+    const uint32_t bpt = texel_bytes(tg.format);
+    for (size_t pix = (size_t)y0 * tg.width; pix < (size_t)y1 * tg.width; pix++) {
+        if (tg.format == ORC_FMT_RGBA_F32 || tg.format == ORC_FMT_RGBA_F16) {
+            for (int k = 0; k < 4; k++) {
+                float sum = 0.0f;
+                for (uint32_t sidx = 0; sidx < samples; sidx++) {
+                    float v;
+                    if (tg.format == ORC_FMT_RGBA_F32) std::memcpy(&v, msaa + ((pix * samples + sidx) * 4 + k) * 4, 4);
+                    else { uint16_t h; std::memcpy(&h, msaa + ((pix * samples + sidx) * 4 + k) * 2, 2); v = half_to_float(h); }
+                    sum = sidx == 0 ? v : sum + v;
+                }
+                const float o = sum * inv;
+                if (tg.format == ORC_FMT_RGBA_F32) std::memcpy(tg.data + (pix * 4 + k) * 4, &o, 4);
+                else { const uint16_t h = float_to_half(o); std::memcpy(tg.data + (pix * 4 + k) * 2, &h, 2); }
+            }
+            continue;
         }
+        for (uint32_t k = 0; k < bpt; k++) {
+            uint32_t sum = 0;
+            for (uint32_t sidx = 0; sidx < samples; sidx++) sum += msaa[(pix * samples + sidx) * bpt + k];
+            tg.data[pix * bpt + k] = (uint8_t)rintf((float)sum * inv);
+        }
+    }
 }
 
 // Triangles of instance `inst`, in primitive order.  Strip triangle i uses vertices (i, i+1, i+2) for even i and
@@ -593,7 +616,6 @@ extern "C" int orc_render(orc_draw* d) {
     const Shader& sh = SHADERS[d->shader];
     const uint32_t S = d->samples > 1 ? d->samples : 1;
     if (S > 1 && ((S != 2 && S != 4 && S != 8) || d->n_targets != 1 || !d->msaa)) return -4;
-    if (S > 1 && d->targets[0].format != ORC_FMT_RGBA_U8 && d->targets[0].format != ORC_FMT_BGRA_U8) return -5;
     const int W = (int)d->targets[0].width, H = (int)d->targets[0].height;
     for (uint32_t a = 1; a < d->n_targets; a++)
         if ((int)d->targets[a].width != W || (int)d->targets[a].height != H) return -3;

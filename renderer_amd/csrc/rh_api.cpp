@@ -145,6 +145,7 @@ struct rh_module {
     hipFunction_t setup[4] = {nullptr, nullptr, nullptr, nullptr};   // 1, 2, 4, 8 samples
     hipFunction_t tile[RH_MAX_COLOR_TARGETS] = {nullptr, nullptr, nullptr, nullptr};
     hipFunction_t tile_ms[3] = {nullptr, nullptr, nullptr};        // 2, 4, 8 samples
+    hipFunction_t tile_ms_wide[3] = {nullptr, nullptr, nullptr};   // the same for RGBA16F / RGBA32F targets
     hipFunction_t tile_wide[RH_MAX_COLOR_TARGETS] = {nullptr, nullptr, nullptr, nullptr};   // passes with a float attachment
 };
 
@@ -482,7 +483,6 @@ int rh_texture_create(rh_device* dev, uint32_t width, uint32_t height, uint32_t 
     if (samples != 1 && samples != 2 && samples != 4 && samples != 8) return fail("rh_texture_create: %u samples requested; 1, 2, 4 and 8 are implemented", samples);
     if (samples > 1) {
         if (layers != 1) return fail("rh_texture_create: a multisampled texture has one layer");
-        if (format != RH_FORMAT_RGBA_U8 && format != RH_FORMAT_BGRA_U8) return fail("rh_texture_create: multisampled format %u is not implemented (RGBA8/BGRA8 only)", format);
     }
     if (set_device(dev)) return 1;
     rh_texture* t = new rh_texture();
@@ -603,6 +603,9 @@ int rh_module_load(rh_device* dev, const void* code_object, size_t size, rh_modu
         const char* ms_names[3] = { "rh_tile_ms2", "rh_tile_ms4", "rh_tile_ms8" };
         for (int i = 0; i < 3; i++)
             if (hipModuleGetFunction(&m->tile_ms[i], m->module, ms_names[i]) != hipSuccess) { (void)hipModuleUnload(m->module); delete m; return fail("rh_module_load: fragment code object lacks %s", ms_names[i]); }
+        const char* msw_names[3] = { "rh_tile_msw2", "rh_tile_msw4", "rh_tile_msw8" };
+        for (int i = 0; i < 3; i++)
+            if (hipModuleGetFunction(&m->tile_ms_wide[i], m->module, msw_names[i]) != hipSuccess) { (void)hipModuleUnload(m->module); delete m; return fail("rh_module_load: fragment code object lacks %s", msw_names[i]); }
     } else { (void)hipModuleUnload(m->module); delete m; return fail("rh_module_load: unknown stage"); }
     device_retain(dev);
     *out = m;
@@ -641,7 +644,6 @@ int rh_pipeline_create(rh_device* dev, const rh_pipeline_desc* d, rh_pipeline** 
     for (uint32_t i = 0; i < d->n_targets; i++) {
         const rh_color_target_desc& t = d->targets[i];
         if (t.format > RH_FORMAT_RGBA_F32) { delete p; return fail("rh_pipeline_create: unknown colour target format %u", t.format); }
-        if (d->samples > 1 && t.format != RH_FORMAT_RGBA_U8 && t.format != RH_FORMAT_BGRA_U8) { delete p; return fail("rh_pipeline_create: multisampled colour target format %u is not implemented (RGBA8/BGRA8 only)", t.format); }
         if (t.src_factor > RH_BLEND_ONE_MINUS_SRC_ALPHA || t.dst_factor > RH_BLEND_ONE_MINUS_SRC_ALPHA) { delete p; return fail("rh_pipeline_create: unknown blend factor"); }
         if (t.src_factor != d->targets[0].src_factor || t.dst_factor != d->targets[0].dst_factor) { delete p; return fail("rh_pipeline_create: all colour targets must share one blend state"); }
         p->targets.push_back(t);
@@ -1018,7 +1020,8 @@ int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer, rh_device::Pa
     if (!no_alloc && timing_mark(dev)) return 1;
     if (pl->samples > 1) {
         // every tile runs: the resolve rewrites the whole target from the multisampled texture (Load included)
-        hipFunction_t fn = pl->fs->tile_ms[ms_index - 1];
+        const uint32_t f0 = c.attachments[0].texture->format;
+        hipFunction_t fn = (f0 == RH_FORMAT_RGBA_F16 || f0 == RH_FORMAT_RGBA_F32) ? pl->fs->tile_ms_wide[ms_index - 1] : pl->fs->tile_ms[ms_index - 1];
         if (n_launch_tiles > 0 && launch_module_kernel(fn, n_launch_tiles, RH_TILE_THREADS, &ta, sizeof ta, s)) return 1;
     } else if ((total > 0 || any_clear || fused) && n_launch_tiles > 0) {
         bool any_float = false;

@@ -442,6 +442,11 @@ constexpr int PACK_MAX = 4;               // boxes that may share one shading pa
 template <bool WIDE> struct Px { using T = uint32_t; };
 template <> struct Px<true> { using T = uint4; };
 
+RH_DEVICE uint4 wide_words(uint32_t v) { return make_uint4(v, 0u, 0u, 0u); }
+RH_DEVICE uint4 wide_words(uint4 v) { return v; }
+RH_DEVICE uint32_t wide_pixel(uint4 v, uint32_t*) { return v.x; }
+RH_DEVICE uint4 wide_pixel(uint4 v, uint4*) { return v; }
+
 RH_DEVICE bool is_float_format(uint32_t f) { return f == FORMAT_RGBA_F16 || f == FORMAT_RGBA_F32; }
 RH_DEVICE float round_to_f16(float v) { return (float)(_Float16)v; }
 
@@ -792,16 +797,19 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
 // top-left rule, the fragment function runs once per pixel and triangle with its inputs interpolated at the pixel
 // centre, and its colour is blended into every covered sample.  The tile's samples go back to the multisampled texture
 // and their mean (round to nearest, ties to even; the sum is exact) to the resolve target.
-// One attachment; every state is read at run time.
-template <int S>
+// One attachment of any format (WIDE: RGBA16F / RGBA32F, 16-byte LDS pixels; the multisampled texture is shaped after
+// the target, reference src/pipeline.rs:164-176); every state is read at run time.  A float resolve adds the samples in
+// f32 in sample order and multiplies by 1/S; an RGBA16F mean is rounded to f16.
+template <int S, bool WIDE>
 struct TileLdsMs {
     alignas(16) uint32_t rec[ROUND * REC_WORDS];
-    uint32_t px[S][TILE_PX];               // one plane per sample index
+    typename Px<WIDE>::T px[S][TILE_PX];   // one plane per sample index
 };
 
-template <int S>
+template <int S, bool WIDE = false>
 RH_DEVICE void tile_kernel_ms(const rh_tile_args& a) {
-    __shared__ TileLdsMs<S> lds;
+    using PxT = typename Px<WIDE>::T;
+    __shared__ TileLdsMs<S, WIDE> lds;
     if (a.pair_total && *a.pair_total > a.pair_capacity) return;     // the pair arrays were too small: the host runs the pass again
     const rh_draw_params& p = a.p;
     const rh_attach_dev& at = a.att[0];
@@ -814,14 +822,11 @@ RH_DEVICE void tile_kernel_ms(const rh_tile_args& a) {
     for (int i = lane; i < TILE_PX; i += 64) {
         const uint32_t gx = (uint32_t)(ox + (i & (TILE - 1))), gy = (uint32_t)(oy + i / TILE);
         const bool inside = gx < p.width && gy < p.height;
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(at.ptr) + ((size_t)gy * at.pitch_px + gx) * S;
+        const size_t first = ((size_t)gy * at.pitch_px + gx) * S;
 #pragma unroll
         for (int sidx = 0; sidx < S; sidx++) {
-            uint32_t v = 0;
-            if (inside) {
-                if (at.load_op != 0u) v = at.clear_rgba8;
-                else { v = src[sidx]; if (at.format == FORMAT_BGRA_U8) v = swap_rb(v); }
-            }
+            PxT v{};
+            if (inside) v = at.load_op != 0u ? clear_pixel(at, (PxT*)nullptr) : load_pixel(at, first + (size_t)sidx, (PxT*)nullptr);
             lds.px[sidx][i] = v;
         }
     }
@@ -890,10 +895,7 @@ RH_DEVICE void tile_kernel_ms(const rh_tile_args& a) {
                         fragment_main(fctx, var, out);
 #pragma unroll
                         for (int sidx = 0; sidx < S; sidx++)
-                            if (cov & (1u << sidx)) {
-                                uint32_t* px = &lds.px[sidx][pidx];
-                                *px = blend<0>(*px, out.color[0], a.src_factor, a.dst_factor);
-                            }
+                            if (cov & (1u << sidx)) blend_pixel<0>(&lds.px[sidx][pidx], at, out.color[0], a.src_factor, a.dst_factor);
                     }
                 };
                 // triangle A's fragment first; a pixel with samples in both triangles gets a second invocation for B
@@ -907,25 +909,43 @@ RH_DEVICE void tile_kernel_ms(const rh_tile_args& a) {
 
     // 3. samples back to the multisampled texture, their mean to the resolve target
     const float inv_s = 1.0f / (float)S;
+    rh_attach_dev rt = at;                   // the resolve target seen as an attachment
+    rt.ptr = at.resolve_ptr; rt.pitch_px = at.resolve_pitch_px; rt.format = at.resolve_format;
     for (int i = lane; i < TILE_PX; i += 64) {
         const uint32_t gx = (uint32_t)(ox + (i & (TILE - 1))), gy = (uint32_t)(oy + i / TILE);
         if (!(gx < p.width && gy < p.height)) continue;
-        uint32_t* dst = reinterpret_cast<uint32_t*>(at.ptr) + ((size_t)gy * at.pitch_px + gx) * S;
-        uint32_t sum[4] = { 0u, 0u, 0u, 0u };
+        const size_t first = ((size_t)gy * at.pitch_px + gx) * S;
+        const bool write_samples = at.load_op != 0u || start != end;
+        if (WIDE) {
+            float sum[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
 #pragma unroll
-        for (int sidx = 0; sidx < S; sidx++) {
-            const uint32_t v = lds.px[sidx][i];
-            sum[0] += v & 0xffu; sum[1] += (v >> 8) & 0xffu; sum[2] += (v >> 16) & 0xffu; sum[3] += v >> 24;
-            if (at.load_op != 0u || start != end) dst[sidx] = at.format == FORMAT_BGRA_U8 ? swap_rb(v) : v;
-        }
-        if (at.resolve_ptr) {
-            uint32_t q = 0u;
-            q = __builtin_amdgcn_cvt_pk_u8_f32((float)sum[0] * inv_s, 0, q);
-            q = __builtin_amdgcn_cvt_pk_u8_f32((float)sum[1] * inv_s, 1, q);
-            q = __builtin_amdgcn_cvt_pk_u8_f32((float)sum[2] * inv_s, 2, q);
-            q = __builtin_amdgcn_cvt_pk_u8_f32((float)sum[3] * inv_s, 3, q);
-            if (at.resolve_format == FORMAT_BGRA_U8) q = swap_rb(q);
-            reinterpret_cast<uint32_t*>(at.resolve_ptr)[(size_t)gy * at.resolve_pitch_px + gx] = q;
+            for (int sidx = 0; sidx < S; sidx++) {
+                const PxT v = lds.px[sidx][i];
+                const uint4 w = wide_words(v);
+                if (sidx == 0) { sum[0] = __uint_as_float(w.x); sum[1] = __uint_as_float(w.y); sum[2] = __uint_as_float(w.z); sum[3] = __uint_as_float(w.w); }
+                else { sum[0] = sum[0] + __uint_as_float(w.x); sum[1] = sum[1] + __uint_as_float(w.y); sum[2] = sum[2] + __uint_as_float(w.z); sum[3] = sum[3] + __uint_as_float(w.w); }
+                if (write_samples) store_pixel(at, first + (size_t)sidx, v);
+            }
+            if (at.resolve_ptr)
+                store_pixel(rt, (size_t)gy * rt.pitch_px + gx, wide_pixel(make_uint4(__float_as_uint(sum[0] * inv_s), __float_as_uint(sum[1] * inv_s),
+                                                                                 __float_as_uint(sum[2] * inv_s), __float_as_uint(sum[3] * inv_s)), (PxT*)nullptr));
+        } else {
+            uint32_t sum[4] = { 0u, 0u, 0u, 0u };
+#pragma unroll
+            for (int sidx = 0; sidx < S; sidx++) {
+                const PxT pv = lds.px[sidx][i];
+                const uint32_t v = wide_words(pv).x;
+                sum[0] += v & 0xffu; sum[1] += (v >> 8) & 0xffu; sum[2] += (v >> 16) & 0xffu; sum[3] += v >> 24;
+                if (write_samples) store_pixel(at, first + (size_t)sidx, pv);
+            }
+            if (at.resolve_ptr) {
+                uint32_t q = 0u;
+                q = __builtin_amdgcn_cvt_pk_u8_f32((float)sum[0] * inv_s, 0, q);
+                q = __builtin_amdgcn_cvt_pk_u8_f32((float)sum[1] * inv_s, 1, q);
+                q = __builtin_amdgcn_cvt_pk_u8_f32((float)sum[2] * inv_s, 2, q);
+                q = __builtin_amdgcn_cvt_pk_u8_f32((float)sum[3] * inv_s, 3, q);
+                store_pixel(rt, (size_t)gy * rt.pitch_px + gx, wide_pixel(make_uint4(q, 0u, 0u, 0u), (PxT*)nullptr));
+            }
         }
     }
 }
@@ -976,6 +996,9 @@ extern "C" __global__ __launch_bounds__(RH_TILE_THREADS, RH_TILE_MIN_WAVES) void
 extern "C" __global__ __launch_bounds__(RH_TILE_THREADS) void rh_tile_ms2(rh_tile_args a) { rh::tile_kernel_ms<2>(a); }
 extern "C" __global__ __launch_bounds__(RH_TILE_THREADS) void rh_tile_ms4(rh_tile_args a) { rh::tile_kernel_ms<4>(a); }
 extern "C" __global__ __launch_bounds__(RH_TILE_THREADS) void rh_tile_ms8(rh_tile_args a) { rh::tile_kernel_ms<8>(a); }
+extern "C" __global__ __launch_bounds__(RH_TILE_THREADS) void rh_tile_msw2(rh_tile_args a) { rh::tile_kernel_ms<2, true>(a); }
+extern "C" __global__ __launch_bounds__(RH_TILE_THREADS) void rh_tile_msw4(rh_tile_args a) { rh::tile_kernel_ms<4, true>(a); }
+extern "C" __global__ __launch_bounds__(RH_TILE_THREADS) void rh_tile_msw8(rh_tile_args a) { rh::tile_kernel_ms<8, true>(a); }
 extern "C" __global__ __launch_bounds__(RH_TILE_THREADS) void rh_tile_w1(rh_tile_args a) { rh::tile_dispatch_wide<1>(a); }
 extern "C" __global__ __launch_bounds__(RH_TILE_THREADS) void rh_tile_w2(rh_tile_args a) { rh::tile_dispatch_wide<2>(a); }
 extern "C" __global__ __launch_bounds__(RH_TILE_THREADS) void rh_tile_w3(rh_tile_args a) { rh::tile_dispatch_wide<3>(a); }

@@ -75,7 +75,7 @@ def random_scene(rng):
     samples = int(rng.choice([1, 1, 1, 2, 4, 8]))
     if samples > 1:
         scene["samples"] = samples
-    elif scene["target"] == "texture":
+    if scene["target"] == "texture":
         scene["target_format"] = str(rng.choice(["rgba_u8", "rgba_u8", "bgra_u8", "r_u8", "rgba_f16", "rgba_f32"]))
     if rng.random() < 0.3 and samples == 1:
         scene["record"] = True

@@ -97,7 +97,7 @@ TARGET_FORMATS = {"r_u8": (0, 1), "bgra_u8": (1, 4), "rgba_u8": (2, 4), "rgba_f1
 # ---- drawing with the oracle -------------------------------------------------------------------------------------------------
 def draw_oracle(scene, threads=0, clip_to_viewport=True, initial=None, msaa=None, initial_recording=None):
     """Returns {'color': uint8 [H, W, 4] in the target's byte order, 'recording': ... (if record), 'fragments': n}.
-    scene['samples'] > 1: multisampled; `msaa` is the pipeline's multisampled texture [H, W, S, 4] (zeros when None),
+    scene['samples'] > 1: multisampled; `msaa` is the pipeline's multisampled texture [H, W, S, bytes per texel] (zeros when None),
     returned under 'msaa'."""
     from oracle import loader as O
     W, H = scene["width"], scene["height"]
@@ -122,7 +122,7 @@ def draw_oracle(scene, threads=0, clip_to_viewport=True, initial=None, msaa=None
     blend = {"premultiplied": (O.BF_ONE, O.BF_ONE_MINUS_SRC_ALPHA), "additive": (O.BF_ONE, O.BF_ONE)}[scene["blend"]]
     samples = scene.get("samples", 1)
     if samples > 1:
-        msaa = np.zeros((H, W, samples, 4), dtype=np.uint8) if msaa is None else msaa.copy()
+        msaa = np.zeros((H, W, samples, bpt), dtype=np.uint8) if msaa is None else msaa.copy()
     n = O.render(shader={"hello": O.SHADER_HELLO, "sized": O.SHADER_SIZED, "tilted": O.SHADER_TILTED, "space": O.SHADER_SPACE,
                          "layered": O.SHADER_HELLO_LAYER}[scene["shader"]],
                  uniforms=[scene["uniform"]] if "uniform" in scene else (),

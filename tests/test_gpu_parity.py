@@ -439,6 +439,22 @@ def test_multisampled_projective_and_screen_target(oracle):
     assert_same(hip["color"], orc["color"], "screen 4x")
 
 
+@pytest.mark.parametrize("fmt,samples", [("rgba_f32", 8), ("rgba_f32", 2), ("rgba_f16", 4), ("r_u8", 4)])
+def test_multisampled_targets_of_every_format(oracle, fmt, samples):
+    """The pipeline's multisampled texture is shaped after its target, whatever the format (reference
+    src/pipeline.rs:164-176): float samples blend unclamped, their mean (f32 sum in sample order) is the resolved texel."""
+    scene = scenes.tilted_quads_scene(300, 200, 136, seed=19, blend="additive")
+    scene["target_format"] = fmt
+    scene["samples"] = samples
+    orc = scenes.draw_oracle(scene)
+    hip = scenes.draw_hip(scene)
+    bpt = scenes.TARGET_FORMATS[fmt][1]
+    assert_same(hip["color"], orc["color"], f"{fmt} {samples}x")
+    assert_same(hip["msaa"].reshape(136, 200 * samples, bpt), orc["msaa"].reshape(136, 200 * samples, bpt), f"{fmt} {samples}x samples")
+    if fmt == "rgba_f32":
+        assert orc["color"].view(np.float32).max() > 1.5        # additive float samples are not clamped
+
+
 def test_multisampled_load_reads_the_pipelines_msaa_texture(oracle):
     """LoadOp::Load on a multisampled pipeline continues from ITS multisampled texture, not from the target: the
     target's previous contents are overwritten by the resolve."""

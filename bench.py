@@ -34,7 +34,9 @@ def pmc_traffic_bytes(tag="c1"):
     gfx950 correction for its 64-B tally of 128-B read requests; counters cannot be collected from inside this
     process, so the figure is the profiled one and is None when no profile of the default workload is present."""
     import glob
-    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "bench_%s_v*_pmc_avg_per_launch.json" % tag)))
+    import re
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "bench_%s_v*_pmc_avg_per_launch.json" % tag)),
+                   key=lambda q: int(re.search(r"_v(\d+)_", os.path.basename(q)).group(1)))
     for path in reversed(paths):               # the newest profile of this workload
         try:
             k = json.load(open(path))["rh_tile_1"]

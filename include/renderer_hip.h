@@ -220,7 +220,8 @@ int rh_submit(rh_device* dev, rh_cmdbuf* const* list, size_t n);
  * rejected with an error beyond that.  Differences from rh_submit: the command buffers are NOT consumed (release them
  * with rh_cmdbuf_release once the work has finished; they may be submitted again), map callbacks are not driven, no
  * timings are recorded, and textures are sampled through footprint copies only where an earlier rh_submit made them.
- * Calls on one GPU share that GPU's array: calls that overlap on one GPU race. */
+ * Calls on one GPU share that GPU's array: calls that overlap on one GPU race.  A pass with triangles that cross a clip
+ * plane is rejected: the kernels that clip them use private memory, which the runtime allocates. */
 int rh_submit_static(rh_device* dev, rh_cmdbuf* const* list, size_t n);
 
 /* ---- statistics of the most recent render pass executed (diagnostics for benchmarks) ------------------------------- */
@@ -229,8 +230,9 @@ typedef struct rh_pass_stats {
     uint64_t bin_entries;     /* (cluster, tile) pairs after binning */
     uint32_t tiles_x, tiles_y;
     uint32_t tile_w, tile_h;    /* pixels per tile (one workgroup) */
-    uint64_t reruns;          /* passes of this device, so far, that were queued before their pair count was known, did
-                                 not fit the room they had been given and ran again */
+    uint64_t reruns;          /* passes of this device, so far, that were queued before their pair count was known and ran
+                                 again: they did not fit the room they had been given, or met the pipeline's first triangle
+                                 that crosses a clip plane (from then on the pipeline runs the kernels that clip) */
 } rh_pass_stats;
 int rh_device_last_pass_stats(rh_device* dev, rh_pass_stats* out);
 

@@ -11,3 +11,7 @@ timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_WAIT_ANY SQ_WAIT_INST_LD
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc3 -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > $OUT/pmc3.log 2>&1
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc4 -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > $OUT/pmc4.log 2>&1
 python3 tools/prof_summary.py $OUT
+# keep the summaries, drop the raw traces (what comes back from the box is limited to 64 MiB)
+cp $OUT/trace/*/*kernel_stats.csv $OUT/kernel_stats.csv
+grep -h '^{"metric"' $OUT/trace.log > $OUT/bench_line_under_tracer.json || true
+rm -rf $OUT/trace $OUT/pmc1 $OUT/pmc2 $OUT/pmc3 $OUT/pmc4

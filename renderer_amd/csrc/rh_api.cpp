@@ -13,6 +13,7 @@
 #include <mutex>
 #include <string>
 #include <vector>
+#include <deque>
 
 #include "../../include/renderer_hip.h"
 #include "rh_abi.h"
@@ -94,6 +95,13 @@ struct rh_device {
     // allocation caches (exact-size reuse; capture buffers come and go every frame)
     std::multimap<size_t, void*> free_device, free_pinned;
     size_t free_device_bytes = 0, free_pinned_bytes = 0;
+    // Uploads in flight (rh_buffer_write, rh_texture_write): the caller's bytes are copied into pinned memory first, so the
+    // copy to the device is queued without the host waiting for the stream (a copy from pageable memory waits for
+    // everything queued before it: the host could never prepare a frame while the previous one renders).
+    struct StagedUpload { void* h; size_t size; hipEvent_t done; };
+    std::deque<StagedUpload> staged;
+    size_t staged_bytes = 0;
+    std::vector<hipEvent_t> stage_events;
     // freed device blocks kept for reuse: up to half of the device's memory (a recording run with a thousand streams has
     // two thousand capture buffers of 33 MB coming and going; hipFree waits for every kernel on the device)
     size_t device_cache_max_bytes = (size_t)48 << 30;
@@ -224,6 +232,30 @@ void pinned_free(rh_device* dev, size_t size, void* p) {
     } else (void)hipHostFree(p);
 }
 
+// Queues a copy of host bytes to device memory on the device's stream without waiting for the stream (see
+// rh_device::staged).  At most RH_STAGED_MAX_BYTES wait in pinned memory: beyond that the oldest upload is waited for.
+constexpr size_t RH_STAGED_MAX_BYTES = (size_t)512 << 20;
+int staged_upload(rh_device* dev, void* dst, const void* src, size_t len) {
+    while (!dev->staged.empty()) {
+        rh_device::StagedUpload& u = dev->staged.front();
+        const bool over = dev->staged_bytes + len > RH_STAGED_MAX_BYTES;
+        if (!over && hipEventQuery(u.done) != hipSuccess) break;
+        if (over) RH_HIP(hipEventSynchronize(u.done));
+        pinned_free(dev, u.size, u.h); dev->stage_events.push_back(u.done); dev->staged_bytes -= u.size;
+        dev->staged.pop_front();
+    }
+    if (len > RH_STAGED_MAX_BYTES) { RH_HIP(hipMemcpyAsync(dst, src, len, hipMemcpyHostToDevice, dev->stream)); return 0; }
+    rh_device::StagedUpload u; u.size = len; u.h = nullptr; u.done = nullptr;
+    if (pinned_alloc(dev, len, &u.h)) return 1;
+    memcpy(u.h, src, len);
+    if (!dev->stage_events.empty()) { u.done = dev->stage_events.back(); dev->stage_events.pop_back(); }
+    else RH_HIP(hipEventCreateWithFlags(&u.done, hipEventDisableTiming));
+    RH_HIP(hipMemcpyAsync(dst, u.h, len, hipMemcpyHostToDevice, dev->stream));
+    RH_HIP(hipEventRecord(u.done, dev->stream));
+    dev->staged.push_back(u); dev->staged_bytes += len;
+    return 0;
+}
+
 int set_device(rh_device* dev) { RH_HIP(hipSetDevice(dev->ordinal)); return 0; }
 int resolve_pending(rh_device* dev, bool blocking = true);
 // What every entry point that queues work on the device's stream, reads results or hands out device memory starts with.
@@ -318,6 +350,8 @@ void device_release(rh_device* dev) {
     for (Scratch* s : all) s->release();
     for (hipEvent_t e : dev->event_pool) (void)hipEventDestroy(e);
     for (hipEvent_t e : dev->timing_events) (void)hipEventDestroy(e);
+    for (rh_device::StagedUpload& u : dev->staged) { (void)hipHostFree(u.h); (void)hipEventDestroy(u.done); }
+    for (hipEvent_t e : dev->stage_events) (void)hipEventDestroy(e);
     for (auto& kv : dev->free_device) (void)hipFree(kv.second);
     for (auto& kv : dev->free_pinned) (void)hipHostFree(kv.second);
     if (dev->counted) (void)hipEventDestroy(dev->counted);
@@ -405,8 +439,7 @@ int rh_buffer_write(rh_buffer* buf, size_t offset, const void* data, size_t len)
     if (offset > buf->size || len > buf->size - offset) return fail("rh_buffer_write: range %zu+%zu exceeds buffer size %zu", offset, len, buf->size);
     if (len == 0) return 0;
     if (enter(buf->dev)) return 1;
-    RH_HIP(hipMemcpyAsync((uint8_t*)buf->dptr + offset, data, len, hipMemcpyHostToDevice, buf->dev->stream));
-    return 0;
+    return staged_upload(buf->dev, (uint8_t*)buf->dptr + offset, data, len);
 }
 
 size_t rh_buffer_size(rh_buffer* buf) { return buf ? buf->size : 0; }
@@ -511,6 +544,8 @@ int rh_texture_write(rh_texture* tex, uint32_t x, uint32_t y, uint32_t layer, ui
     if (enter(tex->dev)) return 1;
     uint8_t* dst = (uint8_t*)tex->dptr + (((size_t)layer * tex->height + y) * tex->width + x) * tex->bpt;
     tex->poly_valid = false;
+    // whole rows of the texture, tightly packed: one contiguous upload through pinned memory
+    if (width == tex->width && bytes_per_row == row_bytes) return staged_upload(tex->dev, dst, data, row_bytes * height);
     RH_HIP(hipMemcpy2DAsync(dst, (size_t)tex->width * tex->bpt, data, bytes_per_row, row_bytes, height, hipMemcpyHostToDevice, tex->dev->stream));
     return 0;
 }

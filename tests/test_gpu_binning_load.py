@@ -172,3 +172,34 @@ def test_unset_and_oversized_instance_buffers_read_zeros(oracle):
         assert_same(hs.read_color(), scenes.draw_oracle(padded)["color"], "instances past the buffer read zeros")
     finally:
         r.close()
+
+
+def test_first_clipped_pass_of_a_pipeline_queued_without_its_count(oracle):
+    """A pipeline's first pass with a triangle across a clip plane, queued whole (the device has seen passes before): the
+    usual binning kernel reports it through the pair count, every kernel behind it writes NOTHING (Load + additive: a
+    stray write would show), the pass runs again with the clipping kernels, and the pipeline keeps those afterwards."""
+    from renderer_amd import Renderer
+    W, H = 640, 400
+    r = Renderer(W, H)
+    try:
+        tiny_then(r, W, H)
+        before = r.last_pass_stats()["reruns"]
+        scene = scenes.space_quads_scene(300, W, H, seed=45, blend="additive")
+        scene["clear"] = None
+        scene["record"] = True
+        scene["record_clear"] = (0.0, 0.0, 0.0, 1.0)
+        init = np.random.default_rng(6).integers(0, 100, (H, W, 4), dtype=np.uint8)
+        want = scenes.draw_oracle(scene, initial=init)
+        hs = scenes.HipScene(scene, renderer=r)
+        hs.set_initial(init)
+        hs.draw()
+        assert r.last_pass_stats()["reruns"] == before + 1
+        assert_same(hs.read_color(), want["color"], "clipped scene after the re-run")
+        assert_same(hs.read_recording(), want["recording"], "recording after the re-run")
+        # the next frame of the pipeline is queued whole with the clipping kernels: no further re-run
+        hs.set_initial(init)
+        hs.draw()
+        assert r.last_pass_stats()["reruns"] == before + 1
+        assert_same(hs.read_color(), want["color"], "clipped scene, second frame")
+    finally:
+        r.close()

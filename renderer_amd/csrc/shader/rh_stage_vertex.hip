@@ -110,6 +110,32 @@ __device__ __forceinline__ void bin_count(const rh_bin_count_args& a) {
 extern "C" __global__ __launch_bounds__(256) void rh_bin_count(rh_bin_count_args a) { bin_count<false>(a); }
 extern "C" __global__ __launch_bounds__(256) void rh_bin_count_clip(rh_bin_count_args a) { bin_count<true>(a); }
 
+constexpr uint32_t HUGE_SLOTS = 8u;
+
+// The pairs of one cluster (tile rectangle lo..hi as in rh_tile_range, row-major; a clipped cluster: its sub-records of a
+// tile adjacent) written from position `o` of the pair array by `threads` threads, this one being number `t`.  The
+// digits of the tile numbers are counted on the way; the lanes of a wave mostly count the same value of the higher
+// digits, and adds to one LDS word go one at a time: one lane then adds for all.
+__device__ __forceinline__ void write_cluster_pairs(const rh_bin_pairs_args& a, uint32_t (*digits)[256], uint32_t lo, uint32_t hi, uint32_t cluster,
+                                                    unsigned long long o, uint32_t t, uint32_t threads) {
+    const uint32_t sh = (lo & RH_RANGE_CLIPPED) ? 3u : 0u;
+    const uint32_t x0 = lo & 0x7fffu, y0 = lo >> 16, x1 = hi & 0xffffu, y1 = hi >> 16;
+    const uint32_t w = x1 - x0 + 1u, n = (w * (y1 - y0 + 1u)) << sh;
+    for (uint32_t i = t; i < n; i += threads) {
+        if (o + i >= a.capacity) break;
+        const uint32_t ti = i >> sh, sub = i & ((1u << sh) - 1u);
+        const uint32_t tile = (y0 + ti / w) * a.p.tiles_x + (x0 + ti % w);
+        a.keys[o + i] = tile; a.vals[o + i] = cluster | (sub << rh::CLIP_SUB_SHIFT);
+        for (uint32_t k = 0; k < a.sort_passes; k++) {
+            const uint32_t d = (tile >> (8u * k)) & 0xffu;
+            const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
+            const unsigned long long same = __ballot(d == d0), active = __ballot(true);
+            if (same == active) { if ((uint32_t)__builtin_ctzll(active) == (threadIdx.x & 63u)) atomicAdd(&digits[k][d0], (uint32_t)__popcll(active)); }
+            else atomicAdd(&digits[k][d], 1u);
+        }
+    }
+}
+
 // The pair array in one launch (see rh_bin_pairs_args).  Workgroup `part` (its ticket) owns clusters
 // [RH_PAIR_PART * part, RH_PAIR_PART * (part + 1)), every thread RH_PAIR_PER_THREAD consecutive ones; the pairs of a
 // cluster are its tiles in row-major order, clusters in order.  (Large parts: every workgroup costs a ticket, a slot in
@@ -119,13 +145,15 @@ __device__ __forceinline__ void bin_pairs(const rh_bin_pairs_args& a) {
     const rh_draw_params& p = a.p;
     constexpr uint32_t PART = RH_PAIR_PART, THREADS = RH_PAIR_THREADS, PER = RH_PAIR_PER_THREAD, WAVES = THREADS / 64u;
     static_assert(PART == THREADS * PER, "part size");
-    __shared__ uint32_t s_part, s_wants_clip;
+    __shared__ uint32_t s_part, s_wants_clip, s_huge_n;
+    __shared__ uint4 s_huge[HUGE_SLOTS];
+    __shared__ unsigned long long s_huge_off[HUGE_SLOTS];
     __shared__ uint32_t wave_sum[WAVES];
     __shared__ unsigned long long s_base;
     __shared__ uint32_t digits[RH_SORT_MAX_PASSES][256];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     if (a.ticketed && threadIdx.x == 0) s_part = atomicAdd(&a.state->ticket[0], 1u);
-    if (threadIdx.x == 0) s_wants_clip = 0u;
+    if (threadIdx.x == 0) { s_wants_clip = 0u; s_huge_n = 0u; }
     if (threadIdx.x < 256u) for (uint32_t k = 0; k < a.sort_passes; k++) digits[k][threadIdx.x] = 0u;
     __syncthreads();
     const uint32_t part = a.ticketed ? s_part : blockIdx.x, n_parts = (p.n_clusters + PART - 1u) / PART;
@@ -187,9 +215,10 @@ __device__ __forceinline__ void bin_pairs(const rh_bin_pairs_args& a) {
     __syncthreads();
     unsigned long long off = s_base + before;
     const uint32_t passes = a.sort_passes;
+    constexpr uint32_t HUGE_PAIRS = 2048u;
 #pragma unroll
     for (uint32_t j = 0; j < PER; j++) {
-        const bool big = cnt[j] > 32u;
+        const bool big = cnt[j] > 32u, huge = cnt[j] > HUGE_PAIRS;
         const unsigned long long first = off;
         // a clipped cluster: CLIP_SUBS pairs per tile, the sub-record number above the cluster in the pair's value
         const uint32_t sub_shift = (tx0[j] & RH_RANGE_CLIPPED) ? 3u : 0u, cx0 = tx0[j] & ~RH_RANGE_CLIPPED;
@@ -204,22 +233,24 @@ __device__ __forceinline__ void bin_pairs(const rh_bin_pairs_args& a) {
                         for (uint32_t k = 0; k < passes; k++) atomicAdd(&digits[k][(tile >> (8u * k)) & 0xffu], 1u);
                     }
         else off += cnt[j];
+        // clusters with thousands of pairs (a quad over the whole target) wait for the whole workgroup, below
+        bool queued = false;
+        if (huge) {
+            const uint32_t slot = atomicAdd(&s_huge_n, 1u);
+            if (slot < HUGE_SLOTS) { s_huge[slot] = make_uint4(tx0[j] | (ty0[j] << 16), tx1[j] | (ty1[j] << 16), cluster0 + j, 0u); s_huge_off[slot] = first; queued = true; }
+        }
         // clusters with more than 32 pairs are written by the whole wave, one after the other
-        for (unsigned long long todo = __ballot(big); todo; todo &= todo - 1ull) {
+        for (unsigned long long todo = __ballot(big && !queued); todo; todo &= todo - 1ull) {
             const int src = __builtin_ctzll(todo);
             const uint32_t lo = __shfl(tx0[j] | (ty0[j] << 16), src), hi = __shfl(tx1[j] | (ty1[j] << 16), src), cc = __shfl(cluster0 + j, src);
             const unsigned long long o = __shfl(first, src);
-            const uint32_t sh = (lo & RH_RANGE_CLIPPED) ? 3u : 0u;
-            const uint32_t x0 = lo & 0x7fffu, y0 = lo >> 16, x1 = hi & 0xffffu, y1 = hi >> 16;
-            const uint32_t w = x1 - x0 + 1u, n = (w * (y1 - y0 + 1u)) << sh;
-            for (uint32_t i = lane; i < n; i += 64u) {
-                if (o + i >= a.capacity) break;
-                const uint32_t t = i >> sh, sub = i & ((1u << sh) - 1u);
-                const uint32_t tile = (y0 + t / w) * p.tiles_x + (x0 + t % w);
-                a.keys[o + i] = tile; a.vals[o + i] = cc | (sub << rh::CLIP_SUB_SHIFT);
-                for (uint32_t k = 0; k < passes; k++) atomicAdd(&digits[k][(tile >> (8u * k)) & 0xffu], 1u);
-            }
+            write_cluster_pairs(a, digits, lo, hi, cc, o, lane, 64u);
         }
+    }
+    __syncthreads();
+    for (uint32_t h = 0; h < min(s_huge_n, HUGE_SLOTS); h++) {
+        const uint4 c = s_huge[h];
+        write_cluster_pairs(a, digits, c.x, c.y, c.z, s_huge_off[h], threadIdx.x, THREADS);
     }
     __syncthreads();
     // the workgroups spread their adds over RH_DIGIT_COPIES copies of the counts

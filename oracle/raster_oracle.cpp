@@ -358,8 +358,10 @@ int clip_triangle(const Shader& sh, const ViewXf& xf, const Vert& a, const Vert&
             const ClipVert& cur = src[i]; const ClipVert& nxt = src[(i + 1) % n];
             const float dc = clip_distance(xf, cur, plane), dn = clip_distance(xf, nxt, plane);
             const bool cin = !(dc < 0.0f), nin = !(dn < 0.0f);
-            if (cin) dst[m++] = cur;
-            if (cin != nin) {
+            // (a convex polygon gains at most one vertex per plane; with infinite coordinates the distances can be NaN and the
+            // inside tests inconsistent: vertices beyond the room of the arrays are left out)
+            if (cin && m < CLIP_MAX_VERTS) dst[m++] = cur;
+            if (cin != nin && m < CLIP_MAX_VERTS) {
                 const ClipVert& vi = cin ? cur : nxt; const ClipVert& vo = cin ? nxt : cur;
                 const float di = cin ? dc : dn, dout = cin ? dn : dc;
                 const float t = di / (di - dout);

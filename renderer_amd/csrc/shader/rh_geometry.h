@@ -120,8 +120,10 @@ __device__ __noinline__ void clip_triangle(const rh_draw_params& p, uint32_t ins
             const ClipVertex& nxt = src[i + 1 == n ? 0 : i + 1];
             const float dc = clip_distance(p, cur, plane), dn = clip_distance(p, nxt, plane);
             const bool cin = !(dc < 0.0f), nin = !(dn < 0.0f);
-            if (cin) dst[m++] = cur;
-            if (cin != nin) {
+            // (a convex polygon gains at most one vertex per plane; infinite coordinates can make the distances NaN and the
+            // inside tests inconsistent: vertices beyond the room of the arrays are left out)
+            if (cin && m < CLIP_MAX_VERTS) dst[m++] = cur;
+            if (cin != nin && m < CLIP_MAX_VERTS) {
                 const ClipVertex& in = cin ? cur : nxt;
                 const ClipVertex& ou = cin ? nxt : cur;
                 const float di = cin ? dc : dn, dou = cin ? dn : dc;

@@ -255,6 +255,24 @@ def test_quads_in_space_are_clipped_like_the_oracle(oracle, topology, blend):
     assert orc["fragments"] > 50_000 and scenes.draw_oracle(inside)["fragments"] < orc["fragments"] // 10
 
 
+def test_clipped_quads_with_infinite_and_enormous_coordinates(oracle):
+    """Coordinates at the edge of f32 (products overflow to infinity, differences of infinities are NaN) go through the
+    clipper without harm and give what the oracle gives."""
+    scene = scenes.space_quads_scene(64, 320, 200, seed=46)
+    inst = scene["instances"]
+    inst[0] = [1e30, 0.0, 1.0, -2.0]
+    inst[1] = [np.inf, 0.0, 0.5, -2.0]
+    inst[2] = [0.0, -np.inf, 1.0, -1.0]
+    inst[3] = [3e38, 3e38, 3e38, -1.0]
+    inst[4] = [0.0, 0.0, 3e38, -2.0]
+    inst[5] = [0.0, 0.0, 1e20, 1e20]
+    inst[6] = [-1e38, 1e38, 1e19, -3e38]
+    scene["instances"] = inst.astype(np.float32)
+    orc = scenes.draw_oracle(scene)
+    hip = scenes.draw_hip(scene, twice=True)
+    assert_same(hip["color"], orc["color"], "space with infinities")
+
+
 def test_clipped_quads_many_tiles_and_recording(oracle):
     """A few very large clipped quads over a 1920x1080 target (two sorting passes, hundreds of pairs per cluster, eight
     sub-records per tile) with the recording attachment."""

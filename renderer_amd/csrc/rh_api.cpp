@@ -903,6 +903,7 @@ int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer, rh_device::Pa
     const bool empty_scissor = p.sc_x0 >= p.sc_x1 || p.sc_y0 >= p.sc_y1;
     const uint32_t n_clusters = empty_scissor ? 0u : p.n_clusters;
 
+    if (no_alloc && pl->clips) return fail("rh_submit_static: the pipeline has triangles that cross a clip plane; the kernels that clip them need private memory, which the runtime allocates");
     hipStream_t s = dev->stream;
     uint64_t total = 0;                          // pairs, or the room for them when the count has not come back yet
     const unsigned long long* pair_total = nullptr;

@@ -70,3 +70,24 @@ def test_static_submit_rejects_a_pass_beyond_its_limits(oracle):
         assert_same(hs.read_color(), scenes.draw_oracle(scene)["color"], "after the rejected call")
     finally:
         r.close()
+
+
+def test_static_submit_rejects_a_pass_that_needs_clipping(oracle):
+    """The kernels that clip use private memory, which the runtime allocates: rh_submit_static says so instead of running
+    them, whether it meets the crossing triangle itself or the pipeline has met one before."""
+    from renderer_amd import Renderer, RendererError
+    W, H = 320, 200
+    r = Renderer(W, H)
+    try:
+        scene = scenes.space_quads_scene(50, W, H, seed=74)
+        hs = scenes.HipScene(scene, renderer=r)
+        r.render(hs.pipeline, hs.clear, hs.viewport, hs.count)
+        with pytest.raises(RendererError, match="clip plane"):
+            r.flush_static()
+        hs.draw()                                   # rh_submit clips
+        assert_same(hs.read_color(), scenes.draw_oracle(scene)["color"], "after the rejected call")
+        r.render(hs.pipeline, hs.clear, hs.viewport, hs.count)
+        with pytest.raises(RendererError, match="clip plane"):
+            r.flush_static()
+    finally:
+        r.close()

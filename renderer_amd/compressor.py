@@ -156,7 +156,7 @@ class Compressor:
     def _writers(self):
         if self._pool is None:
             from concurrent.futures import ThreadPoolExecutor
-            self._pool = ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1))
+            self._pool = ThreadPoolExecutor(max_workers=min(int(os.environ.get("RH_WRITER_THREADS", "16")), os.cpu_count() or 1))
         return self._pool
 
     def drain_kernel_stats(self):

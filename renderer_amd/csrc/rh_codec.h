@@ -7,8 +7,8 @@
 
 // Persistent per-stream compressor state (LZ4_stream_t_internal + the 64 KiB LZ4F dictionary buffer).
 struct rh_lz4_stream_state {
-    uint32_t hash[4096];
-    uint16_t tag[4096];         // per table entry: 0 = never written, else 0x8000 | 15 bits derived from the four bytes at the entry's position
+    uint32_t hash[4096];        // per entry: the position's index (17 bits; the table is rebased before every block) and, above it,
+                                // 15 bits derived from the four bytes at the position (0: never written)
     uint8_t dict[65536];        // the last dict_size bytes are valid, ending at dict + 65536
     uint32_t current_offset;
     uint32_t dict_size;

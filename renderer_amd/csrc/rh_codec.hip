@@ -77,12 +77,14 @@ constexpr uint32_t CUR = KB64;                // virtual offset of the current b
 // the few bytes behind it that every source buffer is padded with.
 constexpr uint32_t WIN = 4096u, WIN_DWORDS = WIN / 4u, WIN_CHUNK = 1024u;
 struct Lds {
+    // A table entry is the position's index in its low IDX_BITS bits and, above them, fifteen bits derived from the four
+    // bytes at the position (0: the entry was never written).  A candidate whose bits differ from the position's own
+    // cannot match, so its bytes need not be read at all: the straight piece of the search reads the bytes of one
+    // candidate -- the first that can match -- instead of 64.  Indices fit seventeen bits because the table is rebased
+    // before every block (the stream's offset never exceeds 64 KiB at a block's start, see the kernel), which is what
+    // LZ4_renormDictT does once in 2 GiB: positions further back than 64 KiB cannot be matched anyway.
     uint32_t hash[(1 << HASHLOG) + 64];       // + one private slot per lane: lanes past the end of the walk go there,
                                               //   so every lane runs the table protocol and no step needs a lane mask
-    // Beside every table entry, fifteen bits of the four bytes at its position (0: the entry was never written).  A
-    // candidate whose bits differ from the position's own cannot match, so its bytes need not be read at all: the
-    // straight piece of the search reads the bytes of one candidate -- the first that can match -- instead of 64.
-    uint16_t tag[(1 << HASHLOG) + 64];
     // The bytes around the current position of a block whose history precedes it in the same source: the byte at
     // virtual offset v at index v mod 4 KiB.  What the search reads of the block itself (the sequences at the walk's
     // positions, literal runs, the bytes around a nearby match) comes from here at LDS latency; only candidates further
@@ -106,7 +108,9 @@ struct Window {
     __device__ __forceinline__ uint32_t byte(uint32_t v) const { return reinterpret_cast<const uint8_t*>(w)[v & (WIN - 1u)]; }
 };
 
-__device__ __forceinline__ uint32_t tag_of(uint32_t seq) { return 0x8000u | ((seq * 2654435761u) >> 17); }
+constexpr uint32_t IDX_BITS = 17u, IDX_MASK = (1u << IDX_BITS) - 1u;
+__device__ __forceinline__ uint32_t tag_of(uint32_t seq) { return 0x4000u | ((seq * 2654435761u) >> 18); }      // 15 bits, never 0
+__device__ __forceinline__ uint32_t entry_of(uint32_t index, uint32_t seq) { return index | (tag_of(seq) << IDX_BITS); }
 
 constexpr uint32_t READ_SLACK = 16;           // bytes behind the end of a source that may be read (and are ignored)
 
@@ -266,7 +270,8 @@ __device__ uint32_t compress_block(Lds& L, const Ring& R, Stream& st, uint32_t n
                 // store must not be forwarded to its later load, other lanes write the same slot: the compiler
                 // barriers make every access a real LDS operation; a volatile pointer would lose the LDS address space.)
                 uint32_t* const table = L.hash;
-                const uint32_t old = table[h];
+                const uint32_t old_entry = table[h];
+                const uint32_t old = old_entry & IDX_MASK;
                 table[h] = 0xffffffffu;
                 asm volatile("" ::: "memory");
                 atomicMin(&table[h], (uint32_t)lane);
@@ -276,7 +281,7 @@ __device__ uint32_t compress_block(Lds& L, const Ring& R, Stream& st, uint32_t n
                 const uint32_t old4 = R.rd32(old + bias);
                 const uint32_t leader = table[h];
                 asm volatile("" ::: "memory");
-                if (leader == (uint32_t)lane) table[h] = old;               // the table is as it was
+                if (leader == (uint32_t)lane) table[h] = old_entry;         // the table is as it was
                 const unsigned long long repeats = __ballot(leader != (uint32_t)lane);   // lanes with an earlier lane of the same hash (never a lane past the end)
                 const int first_invalid = (~vm) ? __builtin_ctzll(~vm) : 64;
                 uint32_t mi = old;
@@ -324,12 +329,12 @@ __device__ uint32_t compress_block(Lds& L, const Ring& R, Stream& st, uint32_t n
                 // the inserts of the lanes up to the stop, in order: per hash value the last of them stays
                 if (general) {
                     const unsigned long long inserting = last_insert < 0 ? 0ull : (last_insert >= 63 ? ~0ull : (2ull << last_insert) - 1ull);
-                    if (valid && lane <= last_insert && (same & above & inserting) == 0ull) { table[h] = mine; L.tag[h] = (uint16_t)tag_of(seq); }
+                    if (valid && lane <= last_insert && (same & above & inserting) == 0ull) table[h] = entry_of(mine, seq);
                 } else {
                     // hashes are distinct among the lanes up to f, except f and its group's first lane
                     const uint32_t leader_of_f = (uint32_t)__builtin_amdgcn_readlane((int)leader, f < 64 ? f : 0);
                     const bool shadowed = f <= last_insert && (uint32_t)lane == leader_of_f;
-                    if (valid && lane <= last_insert && !shadowed) { table[h] = mine; L.tag[h] = (uint16_t)tag_of(seq); }
+                    if (valid && lane <= last_insert && !shadowed) table[h] = entry_of(mine, seq);
                 }
                 if (hits) {
                     const int e = __builtin_ctzll(hits);
@@ -549,15 +554,15 @@ __device__ uint32_t compress_block_w(Lds& L, const Ring& R, Stream& st, uint32_t
             const uint32_t h = Ring::hash5_of(s8);
             const uint32_t my_tag = tag_of(seq);
             const uint32_t mine = p - bias;
-            const uint32_t old = table[h];
-            const uint32_t old_tag = L.tag[h];
+            const uint32_t old_entry = table[h];
+            const uint32_t old = old_entry & IDX_MASK, old_tag = old_entry >> IDX_BITS;
             table[h] = 0xffffffffu;
             asm volatile("" ::: "memory");
             atomicMin(&table[h], (uint32_t)lane);
             asm volatile("" ::: "memory");
             const uint32_t leader = table[h];
             asm volatile("" ::: "memory");
-            if (leader == (uint32_t)lane) table[h] = old;
+            if (leader == (uint32_t)lane) table[h] = old_entry;
             const unsigned long long repeats = __ballot(leader != (uint32_t)lane);
             const int f = repeats ? __builtin_ctzll(repeats) : 64;
             const uint32_t from_leader = (uint32_t)__shfl((int)mine, (int)leader);
@@ -613,7 +618,7 @@ __device__ uint32_t compress_block_w(Lds& L, const Ring& R, Stream& st, uint32_t
                 // ---- decided: the inserts of the lanes up to the hit (per hash value the last of them stays) ...
                 const uint32_t leader_of_f = (uint32_t)__builtin_amdgcn_readlane((int)leader, f < 64 ? f : 0);
                 const bool shadowed = f <= e && (uint32_t)lane == leader_of_f;
-                if (lane <= e && !shadowed) { table[h] = mine; L.tag[h] = (uint16_t)my_tag; }
+                if (lane <= e && !shadowed) table[h] = mine | (my_tag << IDX_BITS);
                 // ... and the sequence: token, one length byte for a run of 15 or more, the run, the offset
                 const uint32_t lit = ip_hit - back - ip;
                 const uint32_t long_run = lit >= RUN_MASK ? 1u : 0u;
@@ -640,7 +645,7 @@ __device__ uint32_t compress_block_w(Lds& L, const Ring& R, Stream& st, uint32_t
             if (!cands && !repeats) {
                 // nothing in this round can match and its hashes are all different: every lane inserts, and the general
                 // code goes on with the walk's second round
-                table[h] = mine; L.tag[h] = (uint16_t)my_tag;
+                table[h] = mine | (my_tag << IDX_BITS);
                 first_round = 64u;
             }
             RH_STAMP(9, ip);
@@ -675,7 +680,8 @@ __device__ uint32_t compress_block_w(Lds& L, const Ring& R, Stream& st, uint32_t
                 const uint32_t h = valid ? hashed : (uint32_t)(1 << HASHLOG) + (uint32_t)lane;
                 const uint32_t mine = p - bias;
                 RH_STAMP(0, h);
-                const uint32_t old = table[h];
+                const uint32_t old_entry = table[h];
+                const uint32_t old = old_entry & IDX_MASK;
                 table[h] = 0xffffffffu;
                 asm volatile("" ::: "memory");
                 atomicMin(&table[h], (uint32_t)lane);
@@ -687,7 +693,7 @@ __device__ uint32_t compress_block_w(Lds& L, const Ring& R, Stream& st, uint32_t
                 const u32x4 cand16 = R.rd128(cand_edge ? cv : cv - 4u);
                 const uint32_t leader = table[h];
                 asm volatile("" ::: "memory");
-                if (leader == (uint32_t)lane) table[h] = old;
+                if (leader == (uint32_t)lane) table[h] = old_entry;
                 const unsigned long long repeats = __ballot(leader != (uint32_t)lane);
                 const int first_invalid = (~vm) ? __builtin_ctzll(~vm) : 64;
                 uint32_t mi = old;
@@ -728,11 +734,11 @@ __device__ uint32_t compress_block_w(Lds& L, const Ring& R, Stream& st, uint32_t
                 const int last_insert = hits ? __builtin_ctzll(hits) : first_invalid - 1;
                 if (general) {
                     const unsigned long long inserting = last_insert < 0 ? 0ull : (last_insert >= 63 ? ~0ull : (2ull << last_insert) - 1ull);
-                    if (valid && lane <= last_insert && (same & above & inserting) == 0ull) { table[h] = mine; L.tag[h] = (uint16_t)tag_of(seq); }
+                    if (valid && lane <= last_insert && (same & above & inserting) == 0ull) table[h] = entry_of(mine, seq);
                 } else {
                     const uint32_t leader_of_f = (uint32_t)__builtin_amdgcn_readlane((int)leader, f < 64 ? f : 0);
                     const bool shadowed = f <= last_insert && (uint32_t)lane == leader_of_f;
-                    if (valid && lane <= last_insert && !shadowed) { table[h] = mine; L.tag[h] = (uint16_t)tag_of(seq); }
+                    if (valid && lane <= last_insert && !shadowed) table[h] = entry_of(mine, seq);
                 }
                 RH_STAMP(2, last_insert);
                 if (hits) {
@@ -867,7 +873,7 @@ extern "C" __global__ __launch_bounds__(64) void rh_lz4f_compress(const rh_lz4_j
     g_u8* const dict = (g_u8*)S.dict;
 
     // bring the hash table into LDS
-    for (int i = lane; i < (1 << HASHLOG); i += 64) { L.hash[i] = S.hash[i]; L.tag[i] = S.tag[i]; }
+    for (int i = lane; i < (1 << HASHLOG); i += 64) L.hash[i] = S.hash[i];
     Stream st; st.current_offset = __builtin_amdgcn_readfirstlane(S.current_offset); st.dict_size = __builtin_amdgcn_readfirstlane(S.dict_size);
     __syncthreads();
 
@@ -883,10 +889,14 @@ extern "C" __global__ __launch_bounds__(64) void rh_lz4f_compress(const rh_lz4_j
         bool first_block = true;
         for (uint64_t done = 0; done < size; ) {
             const uint32_t n = __builtin_amdgcn_readfirstlane((uint32_t)((size - done) < KB64 ? (size - done) : KB64));
-            // LZ4_renormDictT
-            if (st.current_offset + n > 0x80000000u) {
+            // LZ4_renormDictT, before every block instead of once in 2 GiB: the stream's offset goes back to 64 KiB and the
+            // table's indices with it (an index that falls below zero is further back than any match can reach: its entry
+            // is cleared), so that an index of the block fits IDX_BITS bits.  The decisions of the search only compare
+            // indices with one another, so they do not change.
+            if (st.current_offset > KB64) {
                 const uint32_t delta = st.current_offset - KB64;
-                for (int i = lane; i < (1 << HASHLOG); i += 64) { const uint32_t h = L.hash[i]; L.hash[i] = h < delta ? 0u : h - delta; }
+                __syncthreads();
+                for (int i = lane; i < (1 << HASHLOG); i += 64) { const uint32_t e = L.hash[i]; L.hash[i] = (e & IDX_MASK) < delta ? 0u : e - delta; }
                 st.current_offset = KB64;
                 if (st.dict_size > KB64) st.dict_size = KB64;
             }
@@ -938,7 +948,7 @@ extern "C" __global__ __launch_bounds__(64) void rh_lz4f_compress(const rh_lz4_j
 #endif
     // persist the stream state (the dictionary is already in place)
     __syncthreads();
-    for (int i = lane; i < (1 << HASHLOG); i += 64) { S.hash[i] = L.hash[i]; S.tag[i] = L.tag[i]; }
+    for (int i = lane; i < (1 << HASHLOG); i += 64) S.hash[i] = L.hash[i];
     if (lane == 0) { S.current_offset = st.current_offset; S.dict_size = st.dict_size; *job.out_len = op; }
 }
 

@@ -82,7 +82,7 @@ struct rh_bin_count_args {
     rh_draw_params p;
     rh_tile_range* ranges;      // [n_clusters]
     uint32_t* block_sums;       // [ceil(n_clusters / 256)]
-    uint32_t* wants_clip;       // set to 1 by rh_bin_count when it left out a triangle that needs clipping (rh_bin_count_clip clips it)
+    uint32_t* wants_clip;       // set to 1 when a triangle crosses a clip plane (rh_bin_count leaves it out, rh_bin_count_clip clips it)
 };
 // Added to the pair count of a pass by rh_bin_pairs when it left out a triangle that needs clipping: the count then exceeds
 // every capacity (the kernels behind it write nothing) and tells the host to run the pass with the clipping kernels.
@@ -105,7 +105,7 @@ struct rh_bin_state {
     unsigned long long total;           // pairs of the pass (all of them, also when they do not fit the arrays)
     uint32_t ticket[1 + RH_SORT_MAX_PASSES];    // [0] pair kernel, [1 + i] sorting pass i
     uint32_t fault;                     // set when a look-back gave up (the results of the pass are then undefined)
-    uint32_t wants_clip;                // set by rh_bin_count (see rh_bin_count_args)
+    uint32_t wants_clip;                // a triangle of the pass crosses a clip plane (rh_bin_count, rh_bin_count_clip, rh_bin_pairs_clip)
     uint32_t reserved[7];
     uint32_t digit_count[RH_SORT_MAX_PASSES][RH_DIGIT_COPIES][256];    // pairs per value of every 8-bit digit of the tile number (sum of the copies)
 };
@@ -126,7 +126,8 @@ struct rh_bin_pairs_args {
     uint32_t capacity;
     uint32_t sort_passes;
     uint32_t ticketed;                      // 0: all the workgroups fit the device at once and take their index as their place in the chain
-    unsigned long long* host_total;         // pinned host memory: [0] receives the total as well, [1] is set on a fault
+    unsigned long long* host_total;         // pinned host memory: [0] receives the total as well, [1] is set on a fault,
+                                            // [2] (rh_bin_pairs_clip) receives rh_bin_state::wants_clip
 };
 
 // Triangle set-up (its own launch, one thread per (tile, cluster) pair of the sorted pair array): runs the vertex

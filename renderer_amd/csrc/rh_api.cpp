@@ -87,6 +87,7 @@ struct rh_device {
     // before the next command runs (resolve_pending) and the pass runs again, waiting for the count, if it did not fit.
     uint32_t compute_units = 0, resident_sort_parts = 0;   // (workgroups of a chained sorting pass the device holds at once)
     uint64_t pair_guess = 0;                    // room given to the pair arrays of a queued pass; 0: no pass seen yet
+    bool pending_clip_kernels = false;          // the pass awaiting its count ran the clipping kernels
     hipEvent_t counted = nullptr;               // recorded once the count is in h_total and the pairs are sorted
     const void* pending_pass = nullptr;         // (a PassCmd of the command buffer being submitted, or of `pending_cb`)
     const void* pending_fused = nullptr;        // (the CopyCmd performed by that pass, or null)
@@ -170,6 +171,7 @@ struct rh_pipeline {
     // Set when a pass of the pipeline met a triangle that crosses a clip plane: from then on its passes run the kernels
     // that clip (their polygons live in private memory, which makes them several times slower than the usual ones).
     bool clips = false;
+    uint32_t passes_without_clipping = 0;       // consecutive passes run with the clipping kernels that clipped nothing
 };
 
 namespace {
@@ -841,6 +843,13 @@ bool fusable_copy(const rh_device* dev, const PassCmd& c, const CopyCmd& cp) {
     return found;
 }
 
+// A pipeline that clips goes back to the usual kernels after RH_CLIP_IDLE_PASSES passes in a row that clipped nothing.
+constexpr uint32_t RH_CLIP_IDLE_PASSES = 16;
+void note_clipping(rh_pipeline* pl, bool clipped) {
+    if (clipped) { pl->passes_without_clipping = 0; return; }
+    if (++pl->passes_without_clipping >= RH_CLIP_IDLE_PASSES) { pl->clips = false; pl->passes_without_clipping = 0; }
+}
+
 // `ss`: the scratch areas the pass works in; `no_alloc`: called from rh_submit_static, which must not allocate -- timing
 // marks (they create events) and footprint copies that do not exist yet are left out.
 // `fused`: a texture-to-buffer copy that follows the pass in its command buffer and that the tile kernel performs as it
@@ -965,6 +974,7 @@ int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer, rh_device::Pa
             if (dev->timing && !dev->timing_events.empty()) { dev->event_pool.push_back(dev->timing_events.back()); dev->timing_events.pop_back(); }
             return execute_pass(dev, c, false, ss, no_alloc, fused);
         }
+        if (pl->clips) note_clipping(pl, (uint32_t)dev->h_total[2] != 0u);
         total = dev->h_total[0];
         if (total >= 0x7fffffffull) return fail("render pass: %llu (tile, cluster) pairs exceed the 31-bit pair index", (unsigned long long)total);
         dev->pair_guess = std::max<uint64_t>(dev->pair_guess, std::min<uint64_t>(total + total / 4 + 4096, 0x7ffffffeull));
@@ -1067,7 +1077,7 @@ int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer, rh_device::Pa
     }
     if (!no_alloc && timing_mark(dev)) return 1;
 
-    if (deferred) { dev->pending_pass = &c; dev->pending_capacity = (uint32_t)total; dev->pending_fused = fused; }
+    if (deferred) { dev->pending_clip_kernels = pl->clips; dev->pending_pass = &c; dev->pending_capacity = (uint32_t)total; dev->pending_fused = fused; }
     dev->stats.clusters = n_clusters; dev->stats.bin_entries = deferred ? 0 : total;
     dev->stats.tiles_x = p.tiles_x; dev->stats.tiles_y = p.tiles_y; dev->stats.tile_w = RH_TILE_W; dev->stats.tile_h = RH_TILE_H;
     return 0;
@@ -1099,6 +1109,7 @@ int resolve_pending(rh_device* dev, bool blocking) {
     else if (total >= 0x7fffffffull) rc = fail("render pass: %llu (tile, cluster) pairs exceed the 31-bit pair index", (unsigned long long)total);
     else {
         dev->stats.bin_entries = total;
+        if (c.pipeline->clips && dev->pending_clip_kernels) note_clipping(c.pipeline, (uint32_t)dev->h_total[2] != 0u);
         if (total <= capacity) dev->pair_guess = std::max<uint64_t>(dev->pair_guess, std::min<uint64_t>(total + total / 4 + 4096, 0x7ffffffeull));
         else {
             // the attempt that wrote nothing is not a pass of its own: its timing marks go back to the pool

@@ -27,8 +27,9 @@ __device__ __noinline__ void clipped_bbox(const rh_draw_params& p, uint32_t inst
 
 // The inclusive rectangle of tiles the bounding box of `cluster` touches; returns the number of (tile, cluster) pairs
 // the cluster makes (0: none).  CLIP (the clipping kernels): a cluster with a triangle that needs clipping makes
-// rh::CLIP_SUBS pairs per tile and has RH_RANGE_CLIPPED set in tx0.  Otherwise such a triangle is left out and
-// `wants_clip` is set: the pass has to run again with the clipping kernels.
+// rh::CLIP_SUBS pairs per tile and has RH_RANGE_CLIPPED set in tx0.  Otherwise such a triangle is left out: the pass has
+// to run again with the clipping kernels.  Either way `wants_clip` is set when a triangle of the cluster crosses a clip
+// plane (the host goes back to the usual kernels when a pipeline's passes have not met one for a while).
 template <bool CLIP>
 __device__ __forceinline__ uint32_t cluster_tiles(const rh_draw_params& p, uint32_t cluster, uint32_t& tx0, uint32_t& ty0, uint32_t& tx1, uint32_t& ty1, bool& wants_clip) {
     const uint32_t instance = cluster / p.cpi, local = cluster - instance * p.cpi;
@@ -61,7 +62,8 @@ __device__ __forceinline__ uint32_t cluster_tiles(const rh_draw_params& p, uint3
             triangle(v0, v1, v2, first, first + 1u, first + 2u);
         }
     }
-    if (!CLIP && clipped) { wants_clip = true; clipped = false; }
+    if (clipped) wants_clip = true;
+    if (!CLIP) clipped = false;
     tx0 = 1u; ty0 = 0u; tx1 = 0u; ty1 = 0u;             // x0 = 1 > x1 = 0: empty
     if (bx1 < bx0 || by1 < by0) return 0u;
     tx0 = (uint32_t)bx0 / RH_TILE_W; ty0 = (uint32_t)by0 / RH_TILE_H;
@@ -178,6 +180,9 @@ __device__ __forceinline__ void bin_pairs(const rh_bin_pairs_args& a) {
     // A triangle that needs clipping (these kernels leave it out): the part's count is pushed beyond any capacity, so the
     // total of the pass is, nobody after this kernel writes anything, and the host runs the pass with the clipping kernels.
     if (!CLIP && s_wants_clip) part_total += RH_WANTS_CLIP;
+    // (the clipping kernels say whether the pass needed them: the flag is in place before the part's count is published,
+    // and whoever reads counts reads it after them)
+    if (CLIP && s_wants_clip && threadIdx.x == 0) { atomicOr(&a.state->wants_clip, 1u); __threadfence(); }
     if (wave == 0u) {
         // the look-back: lane i polls the i-th predecessor of the current window of 64
         unsigned long long* const status = a.cluster_status;
@@ -209,7 +214,11 @@ __device__ __forceinline__ void bin_pairs(const rh_bin_pairs_args& a) {
         if (lane == 0u) {
             s_base = base;
             if (part != 0u) __hip_atomic_store(&status[part], ((unsigned long long)RH_STATUS_PREFIX << 62) | (base + part_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (part == n_parts - 1u) { a.state->total = base + part_total; a.host_total[0] = base + part_total; }
+            if (CLIP) __threadfence();
+            if (part == n_parts - 1u) {
+                if (CLIP) a.host_total[2] = __hip_atomic_load(&a.state->wants_clip, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                a.state->total = base + part_total; a.host_total[0] = base + part_total;
+            }
         }
     }
     __syncthreads();

@@ -203,3 +203,36 @@ def test_first_clipped_pass_of_a_pipeline_queued_without_its_count(oracle):
         assert_same(hs.read_color(), want["color"], "clipped scene, second frame")
     finally:
         r.close()
+
+
+def test_pipeline_goes_back_to_the_usual_kernels_when_nothing_is_clipped(oracle):
+    """A pipeline that met a crossing triangle runs the clipping kernels; after a run of passes that clipped nothing it
+    returns to the usual ones (seen from outside: the next crossing triangle costs a re-run again), with the same
+    pixels all along."""
+    from renderer_amd import Renderer
+    W, H = 320, 200
+    r = Renderer(W, H)
+    try:
+        tiny_then(r, W, H)
+        scene = scenes.space_quads_scene(80, W, H, seed=47)
+        want_clipped = scenes.draw_oracle(scene)["color"]
+        flat = dict(scene)
+        m = np.eye(4); m[2, :] = [0, 0, 0, 0.5]                     # z = 0.5, w = 1: nothing crosses a plane
+        flat["uniform"] = np.concatenate([np.ones(4), m.T.reshape(-1)]).astype(np.float32)
+        want_flat = scenes.draw_oracle(flat)["color"]
+        hs = scenes.HipScene(scene, renderer=r)
+        before = r.last_pass_stats()["reruns"]
+        hs.draw()
+        assert r.last_pass_stats()["reruns"] == before + 1
+        assert_same(hs.read_color(), want_clipped, "clipped")
+        r.set_uniform(hs.pipeline, (0, 1), flat["uniform"])
+        for _ in range(20):
+            hs.draw()
+        assert r.last_pass_stats()["reruns"] == before + 1
+        assert_same(hs.read_color(), want_flat, "flat, after twenty passes")
+        r.set_uniform(hs.pipeline, (0, 1), scene["uniform"])
+        hs.draw()
+        assert r.last_pass_stats()["reruns"] == before + 2             # the usual kernels met the crossing triangle again
+        assert_same(hs.read_color(), want_clipped, "clipped again")
+    finally:
+        r.close()

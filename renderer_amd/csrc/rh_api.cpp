@@ -929,13 +929,14 @@ int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer, rh_device::Pa
     // one area, cleared by one fill: [binning state | start of every tile | end of every tile | look-back status words]
     const size_t cluster_status_at = STATE_HEADER_BYTES + (size_t)n_tiles * 8;
     const size_t sort_status_at = cluster_status_at + (deferred ? (size_t)n_pair_parts * 8 : 0);
-    const size_t state_bytes = sort_status_at + (deferred ? (size_t)sort_passes * rhk::sort_status_words((uint32_t)dev->pair_guess) * 4 : 0);
+    const size_t state_bytes = (sort_status_at + (deferred ? (size_t)sort_passes * rhk::sort_status_words((uint32_t)dev->pair_guess) * 4 : 0) + 15) & ~(size_t)15;
     if (ss.tile_start.ensure(state_bytes)) return 1;
     uint8_t* const state_base = ss.tile_start.as<uint8_t>();
     rh_bin_state* const state = reinterpret_cast<rh_bin_state*>(state_base);
     uint32_t* const tile_start = reinterpret_cast<uint32_t*>(state_base + STATE_HEADER_BYTES); uint32_t* const tile_end = tile_start + n_tiles;
     if (!no_alloc && timing_mark(dev)) return 1;
-    RH_HIP(hipMemsetAsync(state_base, 0, state_bytes, s));
+    rhk::clear(state_base, state_bytes, s);
+    RH_HIP(hipGetLastError());
     uint32_t* sorted_keys = nullptr; uint32_t* sorted_vals = nullptr;
     if (deferred) {
         const uint32_t n = (uint32_t)dev->pair_guess;

@@ -23,6 +23,7 @@ uint32_t sort_blocks_for(uint32_t n);
 // `general` forces the three-launch form that serves any n (short scans otherwise take one or two launches).
 void exclusive_scan(uint32_t* data, uint32_t n, uint32_t* chunk_tmp, unsigned long long* total_out, hipStream_t s, bool general = false);
 
+void clear(void* p, size_t bytes, hipStream_t s);
 void bin_emit(const rh_tile_range* ranges, uint32_t n_clusters, uint32_t tiles_x, const uint32_t* block_bases,
               uint32_t* keys, uint32_t* vals, hipStream_t s);
 

@@ -458,6 +458,13 @@ extern "C" __global__ __launch_bounds__(256) void rh_polyphase_build(const uint3
     }
 }
 
+// ---- clearing the state area of a pass ------------------------------------------------------------------------------------
+// (one launch of a few microseconds; the runtime's fill is two launches for a size that is not a multiple of its unit)
+extern "C" __global__ __launch_bounds__(256) void rh_clear(uint4* p, uint32_t n16) {
+    const uint32_t i = blockIdx.x * WG + threadIdx.x;
+    if (i < n16) p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
 // ---- host-callable launchers ----------------------------------------------------------------------------------------------
 namespace rhk {
 
@@ -537,6 +544,11 @@ int sort_passes_chained(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, ui
         cur ^= 1;
     }
     return cur;
+}
+
+void clear(void* p, size_t bytes, hipStream_t s) {          // bytes: a multiple of 16
+    const uint32_t n16 = (uint32_t)(bytes / 16);
+    if (n16) hipLaunchKernelGGL(rh_clear, dim3(div_up(n16, WG)), dim3(WG), 0, s, (uint4*)p, n16);
 }
 
 void polyphase_build(const void* src, void* dst, uint32_t width, uint32_t height, uint32_t layers, hipStream_t s) {

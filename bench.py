@@ -94,7 +94,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--quads", type=int, default=1_000_000)
+    ap.add_argument("--quads", type=int, default=0, help="default: 1,000,000 (c1), 10,000,000 (c2)")
     ap.add_argument("--side", type=int, default=16, help="quad edge in pixels (headline: 16)")
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
@@ -112,6 +112,8 @@ def main():
                     help="stream files per GPU; default 1024 (one wavefront per stream: four per compute unit; a round of up "
                          "to 1024 streams takes about as long as a round of one)")
     args = ap.parse_args()
+    if args.quads <= 0:
+        args.quads = 1_000_000 if args.workload == "c1" else 10_000_000
 
     capture_auto = args.capture_frames < 0 and args.capture_streams < 0      # sized below, once the ranks can agree
     capture_warm_rounds = 1

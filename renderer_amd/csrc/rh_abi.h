@@ -4,7 +4,7 @@
 #pragma once
 #include <stdint.h>
 
-#define RH_DEVICE_ABI_VERSION 13u
+#define RH_DEVICE_ABI_VERSION 14u
 #define RH_MODULE_MAGIC 0x52484d4fu   // "RHMO"
 
 #define RH_DEV_MAX_ATTRIBUTES 8
@@ -72,11 +72,17 @@ struct rh_draw_params {
                                                      // samples away from the pixel centre can be covered
 };
 
-// Packed tile rectangle of a cluster: x0 | y0 << 16, x1 | y1 << 16 (inclusive); x0 > x1 marks "touches nothing".
-// RH_RANGE_CLIPPED in `lo`: a triangle of the cluster is clipped and the cluster makes 8 pairs per tile, the pair's value
-// carrying the number of the sub-record (0..7) in its top three bits (cluster indices stay below 2^29).
+// Packed tile rectangle of a cluster: lo = x0 | y0 << 16, hi = x1 | y1 << 16 (inclusive); x0 > x1 marks "touches nothing".
+// Tile columns take ten bits.  Above x0, `lo` carries how many sub-records the cluster's first (bits 10-12) and second
+// triangle (bits 13-15) need when a triangle of the cluster is clipped, 0..4 each: the cluster then makes that many
+// (tile, cluster) pairs per tile instead of one, the pair's value carrying the number of the sub-record in its top three
+// bits (0..3: first triangle, 4..7: second; cluster indices stay below 2^29).  Both zero: the usual cluster, one pair.
 struct rh_tile_range { uint32_t lo, hi; };
-#define RH_RANGE_CLIPPED 0x8000u
+#define RH_RANGE_X0(lo) ((lo) & 0x3ffu)
+#define RH_RANGE_SUBS_A(lo) (((lo) >> 10) & 7u)
+#define RH_RANGE_SUBS_B(lo) (((lo) >> 13) & 7u)
+#define RH_RANGE_SUBS(sa, sb) (((sa) << 10) | ((sb) << 13))
+#define RH_RANGE_MAX_TILES_X 1024u
 
 struct rh_bin_count_args {
     rh_draw_params p;

@@ -889,6 +889,7 @@ int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer, rh_device::Pa
     }
     p.width = W; p.height = H;
     p.tiles_x = (W + RH_TILE_W - 1) / RH_TILE_W; p.tiles_y = (H + RH_TILE_H - 1) / RH_TILE_H;
+    if (p.tiles_x > RH_RANGE_MAX_TILES_X) return fail("render pass: a target %u pixels wide exceeds %u tile columns", W, RH_RANGE_MAX_TILES_X);
     const uint32_t n_tiles = p.tiles_x * p.tiles_y;
     // sort-first strip: only tile rows [row0, row1) are rendered (and cleared) by this device
     uint32_t tile_row0 = 0, tile_row1 = p.tiles_y;

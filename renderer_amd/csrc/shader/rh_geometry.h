@@ -149,10 +149,11 @@ __device__ __noinline__ void clip_triangle(const rh_draw_params& p, uint32_t ins
     out.n = n;
 }
 
-// A cluster some of whose triangles are clipped makes CLIP_SUBS (tile, cluster) pairs per tile instead of one: pair
-// value = cluster | sub << CLIP_SUB_SHIFT; sub s covers triangles 2*(s mod 4) and 2*(s mod 4) + 1 of the fan of the
-// cluster's first (s < 4) or second triangle (a triangle that needs no clipping is a fan of one).
-constexpr uint32_t CLIP_SUB_SHIFT = 29u, CLIP_SUBS = 8u, CLIP_CLUSTER_MASK = (1u << CLIP_SUB_SHIFT) - 1u;
+// A cluster some of whose triangles are clipped makes one (tile, cluster) pair per tile and *sub-record*: pair value =
+// cluster | sub << CLIP_SUB_SHIFT; sub s covers triangles 2*(s mod 4) and 2*(s mod 4) + 1 of the fan of the cluster's
+// first (s < 4) or second triangle (a triangle that needs no clipping is a fan of one).  Only the sub-records whose fan
+// triangles exist get pairs (rh_tile_range carries their numbers).
+constexpr uint32_t CLIP_SUB_SHIFT = 29u, CLIP_CLUSTER_MASK = (1u << CLIP_SUB_SHIFT) - 1u;
 static_assert((CLIP_MAX_VERTS - 2 + 1) / 2 == 4, "four records of two fan triangles per clipped triangle");
 
 // Vertex indices of triangle `i` of an instance.  Strip: (i, i+1, i+2) for even i, (i, i+2, i+1) for odd i

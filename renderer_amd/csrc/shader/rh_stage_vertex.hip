@@ -15,19 +15,21 @@ extern "C" __device__ const rh_module_info_t rh_module_info = {
 namespace {
 
 // Bounding box of the part of triangle (i0, i1, i2) of `instance` inside the clip volume, grown into (bx0 .. by1).
-__device__ __noinline__ void clipped_bbox(const rh_draw_params& p, uint32_t instance, uint32_t i0, uint32_t i1, uint32_t i2,
-                                          int& bx0, int& by0, int& bx1, int& by1) {
+// Returns the number of the polygon's vertices.
+__device__ __noinline__ int clipped_bbox(const rh_draw_params& p, uint32_t instance, uint32_t i0, uint32_t i1, uint32_t i2,
+                                         int& bx0, int& by0, int& bx1, int& by1) {
     rh::ClipPolygon poly;
     rh::clip_triangle(p, instance, i0, i1, i2, poly);
     for (int i = 2; i < poly.n; i++) {
         int x0, y0, x1, y1;
         if (rh::tri_pixel_bbox(p, poly.v[0], poly.v[i - 1], poly.v[i], x0, y0, x1, y1)) { bx0 = min(bx0, x0); by0 = min(by0, y0); bx1 = max(bx1, x1); by1 = max(by1, y1); }
     }
+    return poly.n;
 }
 
 // The inclusive rectangle of tiles the bounding box of `cluster` touches; returns the number of (tile, cluster) pairs
 // the cluster makes (0: none).  CLIP (the clipping kernels): a cluster with a triangle that needs clipping makes
-// rh::CLIP_SUBS pairs per tile and has RH_RANGE_CLIPPED set in tx0.  Otherwise such a triangle is left out: the pass has
+// one pair per tile and sub-record, the numbers of sub-records packed above tx0 (see rh_tile_range).  Otherwise such a triangle is left out: the pass has
 // to run again with the clipping kernels.  Either way `wants_clip` is set when a triangle of the cluster crosses a clip
 // plane (the host goes back to the usual kernels when a pipeline's passes have not met one for a while).
 template <bool CLIP>
@@ -37,29 +39,34 @@ __device__ __forceinline__ uint32_t cluster_tiles(const rh_draw_params& p, uint3
     const uint32_t tri0 = local * 2u;
     const bool second = tri0 + 1u < p.tpi;
     bool clipped = false;
-    auto triangle = [&](const rh::SnappedVertex& a, const rh::SnappedVertex& b, const rh::SnappedVertex& c, uint32_t i0, uint32_t i1, uint32_t i2) {
+    uint32_t subs[2] = { 0u, 0u };              // sub-records of the two triangles, should the cluster turn out clipped
+    auto triangle = [&](int which, const rh::SnappedVertex& a, const rh::SnappedVertex& b, const rh::SnappedVertex& c, uint32_t i0, uint32_t i1, uint32_t i2) {
         int x0, y0, x1, y1;
         const int kind = rh::classify(a, b, c);
         if (kind == rh::TRI_WHOLE) {
+            subs[which] = 1u;
             if (rh::tri_pixel_bbox(p, a, b, c, x0, y0, x1, y1)) { bx0 = min(bx0, x0); by0 = min(by0, y0); bx1 = max(bx1, x1); by1 = max(by1, y1); }
         } else if (kind == rh::TRI_CLIPPED) {
             clipped = true;
-            if (CLIP) clipped_bbox(p, instance, i0, i1, i2, bx0, by0, bx1, by1);
+            if (CLIP) {
+                const int n = clipped_bbox(p, instance, i0, i1, i2, bx0, by0, bx1, by1);
+                subs[which] = n >= 3 ? (uint32_t)(n - 1) / 2u : 0u;         // two triangles of the fan of n - 2 per sub-record
+            }
         }
     };
     if (p.topology == 1u) {
         // strip: the two triangles share two of their four vertices
         const rh::SnappedVertex v0 = rh::run_vertex(p, tri0, instance), v1 = rh::run_vertex(p, tri0 + 1u, instance), v2 = rh::run_vertex(p, tri0 + 2u, instance);
-        triangle(v0, v1, v2, tri0, tri0 + 1u, tri0 + 2u);
+        triangle(0, v0, v1, v2, tri0, tri0 + 1u, tri0 + 2u);
         if (second) {
             const rh::SnappedVertex v3 = rh::run_vertex(p, tri0 + 3u, instance);
-            triangle(v1, v3, v2, tri0 + 1u, tri0 + 3u, tri0 + 2u);
+            triangle(1, v1, v3, v2, tri0 + 1u, tri0 + 3u, tri0 + 2u);
         }
     } else {
         for (uint32_t k = 0; k < (second ? 2u : 1u); k++) {
             const uint32_t first = 3u * (tri0 + k);
             const rh::SnappedVertex v0 = rh::run_vertex(p, first, instance), v1 = rh::run_vertex(p, first + 1u, instance), v2 = rh::run_vertex(p, first + 2u, instance);
-            triangle(v0, v1, v2, first, first + 1u, first + 2u);
+            triangle((int)k, v0, v1, v2, first, first + 1u, first + 2u);
         }
     }
     if (clipped) wants_clip = true;
@@ -69,8 +76,9 @@ __device__ __forceinline__ uint32_t cluster_tiles(const rh_draw_params& p, uint3
     tx0 = (uint32_t)bx0 / RH_TILE_W; ty0 = (uint32_t)by0 / RH_TILE_H;
     tx1 = (uint32_t)bx1 / RH_TILE_W; ty1 = (uint32_t)by1 / RH_TILE_H;
     const uint32_t tiles = (tx1 - tx0 + 1) * (ty1 - ty0 + 1);
-    if (clipped) tx0 |= RH_RANGE_CLIPPED;
-    return clipped ? tiles * rh::CLIP_SUBS : tiles;
+    if (!clipped) return tiles;
+    tx0 |= RH_RANGE_SUBS(subs[0], subs[1]);
+    return tiles * (subs[0] + subs[1]);
 }
 
 __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane) {
@@ -120,12 +128,12 @@ constexpr uint32_t HUGE_SLOTS = 8u;
 // digits, and adds to one LDS word go one at a time: one lane then adds for all.
 __device__ __forceinline__ void write_cluster_pairs(const rh_bin_pairs_args& a, uint32_t (*digits)[256], uint32_t lo, uint32_t hi, uint32_t cluster,
                                                     unsigned long long o, uint32_t t, uint32_t threads) {
-    const uint32_t sh = (lo & RH_RANGE_CLIPPED) ? 3u : 0u;
-    const uint32_t x0 = lo & 0x7fffu, y0 = lo >> 16, x1 = hi & 0xffffu, y1 = hi >> 16;
-    const uint32_t w = x1 - x0 + 1u, n = (w * (y1 - y0 + 1u)) << sh;
+    const uint32_t sa = RH_RANGE_SUBS_A(lo), sb = RH_RANGE_SUBS_B(lo), per_tile = sa + sb ? sa + sb : 1u;
+    const uint32_t x0 = RH_RANGE_X0(lo), y0 = lo >> 16, x1 = hi & 0xffffu, y1 = hi >> 16;
+    const uint32_t w = x1 - x0 + 1u, n = w * (y1 - y0 + 1u) * per_tile;
     for (uint32_t i = t; i < n; i += threads) {
         if (o + i >= a.capacity) break;
-        const uint32_t ti = i >> sh, sub = i & ((1u << sh) - 1u);
+        const uint32_t ti = i / per_tile, k = i - ti * per_tile, sub = k < sa ? k : (sa + sb ? 4u + (k - sa) : 0u);
         const uint32_t tile = (y0 + ti / w) * a.p.tiles_x + (x0 + ti % w);
         a.keys[o + i] = tile; a.vals[o + i] = cluster | (sub << rh::CLIP_SUB_SHIFT);
         for (uint32_t k = 0; k < a.sort_passes; k++) {
@@ -229,15 +237,15 @@ __device__ __forceinline__ void bin_pairs(const rh_bin_pairs_args& a) {
     for (uint32_t j = 0; j < PER; j++) {
         const bool big = cnt[j] > 32u, huge = cnt[j] > HUGE_PAIRS;
         const unsigned long long first = off;
-        // a clipped cluster: CLIP_SUBS pairs per tile, the sub-record number above the cluster in the pair's value
-        const uint32_t sub_shift = (tx0[j] & RH_RANGE_CLIPPED) ? 3u : 0u, cx0 = tx0[j] & ~RH_RANGE_CLIPPED;
-        static_assert(rh::CLIP_SUBS == 8u, "sub_shift");
+        // a clipped cluster: one pair per tile and sub-record, the sub-record's number above the cluster in the pair's value
+        const uint32_t sa = RH_RANGE_SUBS_A(tx0[j]), sb = RH_RANGE_SUBS_B(tx0[j]), per_tile = sa + sb ? sa + sb : 1u, cx0 = RH_RANGE_X0(tx0[j]);
         if (!big)
             for (uint32_t ty = ty0[j]; ty <= ty1[j]; ty++)
                 for (uint32_t tx = cx0; tx <= tx1[j]; tx++)
-                    for (uint32_t sub = 0; sub < (1u << sub_shift); sub++, off++) {
+                    for (uint32_t k = 0; k < per_tile; k++, off++) {
                         if (off >= a.capacity) continue;
                         const uint32_t tile = ty * p.tiles_x + tx;
+                        const uint32_t sub = k < sa ? k : (sa + sb ? 4u + (k - sa) : 0u);
                         a.keys[off] = tile; a.vals[off] = (cluster0 + j) | (sub << rh::CLIP_SUB_SHIFT);
                         for (uint32_t k = 0; k < passes; k++) atomicAdd(&digits[k][(tile >> (8u * k)) & 0xffu], 1u);
                     }

@@ -67,6 +67,10 @@ enum {
     RH_OPTION_BINNING_TICKETS = 5,    /* 1: the workgroups of the binning chain always take their place in the chain from
                                          a ticket counter, as launches too large to fit the device at once do (identical
                                          results; for testing); default 0 */
+    RH_OPTION_EARLY_BINNING = 6,      /* 1 (default): binning and set-up of a pass that is queued whole run on a stream of
+                                         their own, beside the tile kernel of the pass before (they read only what the
+                                         vertex stage reads, and wait for everything queued before the pass that could
+                                         change it); 0: everything on one stream (identical results) */
 };
 
 #define RH_MAX_ATTRIBUTES 8

@@ -78,7 +78,23 @@ struct rh_device {
     // scratch of a render pass: binning arrays and the set-up records of the sorted (tile, cluster) pairs.  `grown` is
     // allocated on demand; `held` is carved out of the library's static device array (rh_submit_static)
     struct PassScratch { Scratch ranges, block_sums, chunk_tmp, keys_a, vals_a, keys_b, vals_b, hist, tile_start, rec, ext; };
-    PassScratch grown, held;
+    PassScratch grown, grown2, held;
+    // Binning and set-up of a pass run on a stream of their own (RH_OPTION_EARLY_BINNING): they only read what the vertex
+    // stage reads, so they may run while the tile kernel of the pass before is still at work -- that kernel's last
+    // workgroups leave most of the device idle.  The two streams meet again before the tile kernel, which waits for the
+    // set-up; consecutive passes alternate between two sets of scratch areas.  A pass takes the binning stream only when
+    // nothing but the previous pass's tile kernel has been queued on the main stream since that kernel's start (the
+    // binning then waits for everything before that kernel); otherwise it runs on the main stream like everything else.
+    hipStream_t bin_stream = nullptr;           // created when the first pass takes it (a process has few hardware queues)
+    int bin_priority = 0;
+    int early_binning = 1;
+    int scratch_flip = 0;                       // which of grown / grown2 the next pass takes
+    hipEvent_t tile_done[2] = { nullptr, nullptr };   // recorded behind the tile kernel that read the set
+    bool tile_done_valid[2] = { false, false };
+    hipEvent_t before_tile = nullptr;           // recorded on the main stream just before the last tile kernel
+    bool before_tile_valid = false;
+    hipEvent_t setup_done = nullptr;
+    bool main_dirty = true;                     // something other than a tile kernel was queued on the main stream since `before_tile`
     Scratch png_slots, png_rows, png_out;          // GPU PNG encoder scratch
     void* png_host = nullptr; size_t png_host_cap = 0;   // pinned
     unsigned long long* d_total = nullptr;
@@ -111,7 +127,7 @@ struct rh_device {
     // optional per-pass HIP-event timing
     int timing = 0;
     std::vector<hipEvent_t> event_pool;            // unused events
-    std::vector<hipEvent_t> timing_events;         // 4 per recorded pass: start, before set-up, before tile kernel, end
+    std::vector<hipEvent_t> timing_events;         // 5 per recorded pass: start, before set-up, after set-up, before tile kernel, end
 };
 
 struct rh_buffer {
@@ -246,9 +262,10 @@ int staged_upload(rh_device* dev, void* dst, const void* src, size_t len) {
         pinned_free(dev, u.size, u.h); dev->stage_events.push_back(u.done); dev->staged_bytes -= u.size;
         dev->staged.pop_front();
     }
-    if (len > RH_STAGED_MAX_BYTES) { RH_HIP(hipMemcpyAsync(dst, src, len, hipMemcpyHostToDevice, dev->stream)); return 0; }
+    if (len > RH_STAGED_MAX_BYTES) { dev->main_dirty = true; RH_HIP(hipMemcpyAsync(dst, src, len, hipMemcpyHostToDevice, dev->stream)); return 0; }
     rh_device::StagedUpload u; u.size = len; u.h = nullptr; u.done = nullptr;
     if (pinned_alloc(dev, len, &u.h)) return 1;
+    dev->main_dirty = true;
     memcpy(u.h, src, len);
     if (!dev->stage_events.empty()) { u.done = dev->stage_events.back(); dev->stage_events.pop_back(); }
     else RH_HIP(hipEventCreateWithFlags(&u.done, hipEventDisableTiming));
@@ -291,6 +308,8 @@ int rh_device_create(int hip_ordinal, uint32_t width, uint32_t height, rh_device
     rh_device* dev = new rh_device();
     dev->ordinal = hip_ordinal; dev->width = width; dev->height = height;
     dev->name = std::string(prop.name) + " (" + prop.gcnArchName + ")";
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     hipError_t e = hipStreamCreateWithFlags(&dev->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete dev; return fail("hipStreamCreate failed: %s", hipGetErrorString(e)); }
     if (hipMalloc((void**)&dev->d_total, 8) != hipSuccess || hipHostMalloc((void**)&dev->h_total, 32, hipHostMallocDefault) != hipSuccess ||
@@ -298,6 +317,15 @@ int rh_device_create(int hip_ordinal, uint32_t width, uint32_t height, rh_device
         delete dev; return fail("rh_device_create: allocation failed");
     }
     dev->h_total[0] = 0; dev->h_total[1] = 0; dev->h_total[2] = 0; dev->h_total[3] = 0;
+    // (the lowest priority: the binning of the next pass takes the places the tile kernel's last workgroups leave free, not
+    // the places of workgroups it has yet to start)
+    dev->bin_priority = prio_least;
+    if (hipEventCreateWithFlags(&dev->tile_done[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&dev->tile_done[1], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&dev->before_tile, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&dev->setup_done, hipEventDisableTiming) != hipSuccess) {
+        rh_device_destroy(dev); return fail("rh_device_create: creating the binning stream failed");
+    }
+    if (const char* v = getenv("RH_EARLY_BINNING")) dev->early_binning = atoi(v) ? 1 : 0;
     dev->compute_units = (uint32_t)prop.multiProcessorCount;
     dev->device_cache_max_bytes = (size_t)prop.totalGlobalMem / 2;
     dev->resident_sort_parts = rhk::sort_pass_resident_parts(dev->compute_units);
@@ -346,10 +374,16 @@ void device_release(rh_device* dev) {
     if (dev->refs.fetch_sub(1) != 1) return;
     (void)hipSetDevice(dev->ordinal);
     (void)hipStreamSynchronize(dev->stream);
-    rh_device::PassScratch& g = dev->grown;
-    Scratch* all[] = { &g.ranges, &g.block_sums, &g.chunk_tmp, &g.keys_a, &g.vals_a, &g.keys_b, &g.vals_b,
-                       &g.hist, &g.tile_start, &g.rec, &g.ext, &dev->png_slots, &dev->png_rows, &dev->png_out };
-    for (Scratch* s : all) s->release();
+    if (dev->bin_stream) (void)hipStreamSynchronize(dev->bin_stream);
+    for (rh_device::PassScratch* gp : { &dev->grown, &dev->grown2 }) {
+        rh_device::PassScratch& g = *gp;
+        Scratch* all[] = { &g.ranges, &g.block_sums, &g.chunk_tmp, &g.keys_a, &g.vals_a, &g.keys_b, &g.vals_b, &g.hist, &g.tile_start, &g.rec, &g.ext };
+        for (Scratch* s : all) s->release();
+    }
+    Scratch* png[] = { &dev->png_slots, &dev->png_rows, &dev->png_out };
+    for (Scratch* s : png) s->release();
+    for (hipEvent_t e : { dev->tile_done[0], dev->tile_done[1], dev->before_tile, dev->setup_done }) if (e) (void)hipEventDestroy(e);
+    if (dev->bin_stream) (void)hipStreamDestroy(dev->bin_stream);
     for (hipEvent_t e : dev->event_pool) (void)hipEventDestroy(e);
     for (hipEvent_t e : dev->timing_events) (void)hipEventDestroy(e);
     for (rh_device::StagedUpload& u : dev->staged) { (void)hipHostFree(u.h); (void)hipEventDestroy(u.done); }
@@ -380,6 +414,7 @@ int rh_device_set_option(rh_device* dev, int option, int value) {
     if (option == RH_OPTION_GENERAL_KERNELS) { dev->general_kernels = value ? 1 : 0; return 0; }
     if (option == RH_OPTION_BINNING_TICKETS) { dev->binning_tickets = value ? 1 : 0; return 0; }
     if (option == RH_OPTION_TIMING) { dev->timing = value ? 1 : 0; return 0; }
+    if (option == RH_OPTION_EARLY_BINNING) { dev->early_binning = value ? 1 : 0; return 0; }
     if (option == RH_OPTION_STRIP_ROW0 || option == RH_OPTION_STRIP_ROW1) {
         if (value < 0) return fail("rh_device_set_option: negative strip row");
         (option == RH_OPTION_STRIP_ROW0 ? dev->strip_row0 : dev->strip_row1) = (uint32_t)value;
@@ -391,6 +426,7 @@ int rh_device_set_option(rh_device* dev, int option, int value) {
 int rh_device_synchronize(rh_device* dev) {
     if (!dev) return fail("rh_device_synchronize: null device");
     if (enter(dev)) return 1;
+    if (dev->bin_stream) RH_HIP(hipStreamSynchronize(dev->bin_stream));
     RH_HIP(hipStreamSynchronize(dev->stream));
     return 0;
 }
@@ -445,7 +481,7 @@ int rh_buffer_write(rh_buffer* buf, size_t offset, const void* data, size_t len)
 }
 
 size_t rh_buffer_size(rh_buffer* buf) { return buf ? buf->size : 0; }
-void* rh_buffer_device_ptr(rh_buffer* buf) { return buf && !enter(buf->dev) ? buf->dptr : nullptr; }
+void* rh_buffer_device_ptr(rh_buffer* buf) { if (buf) buf->dev->main_dirty = true; return buf && !enter(buf->dev) ? buf->dptr : nullptr; }
 void rh_buffer_retain(rh_buffer* buf) { if (buf) buf->refs.fetch_add(1); }
 
 void rh_buffer_release(rh_buffer* buf) {
@@ -548,6 +584,7 @@ int rh_texture_write(rh_texture* tex, uint32_t x, uint32_t y, uint32_t layer, ui
     tex->poly_valid = false;
     // whole rows of the texture, tightly packed: one contiguous upload through pinned memory
     if (width == tex->width && bytes_per_row == row_bytes) return staged_upload(tex->dev, dst, data, row_bytes * height);
+    tex->dev->main_dirty = true;
     RH_HIP(hipMemcpy2DAsync(dst, (size_t)tex->width * tex->bpt, data, bytes_per_row, row_bytes, height, hipMemcpyHostToDevice, tex->dev->stream));
     return 0;
 }
@@ -573,7 +610,7 @@ int rh_texture_size(rh_texture* tex, uint32_t* width, uint32_t* height, uint32_t
     return 0;
 }
 
-void* rh_texture_device_ptr(rh_texture* tex) { if (tex) tex->poly_always = true; return tex && !enter(tex->dev) ? tex->dptr : nullptr; }
+void* rh_texture_device_ptr(rh_texture* tex) { if (tex) { tex->poly_always = true; tex->dev->main_dirty = true; } return tex && !enter(tex->dev) ? tex->dptr : nullptr; }
 void rh_texture_retain(rh_texture* tex) { if (tex) tex->refs.fetch_add(1); }
 void rh_texture_release(rh_texture* tex) {
     if (!tex) return;
@@ -812,12 +849,12 @@ void rh_cmdbuf_release(rh_cmdbuf* cb) { if (!cb) return; release_cmds(cb->cmds);
 // ---- execution ---------------------------------------------------------------------------------------------------------------
 namespace {
 
-int timing_mark(rh_device* dev) {
+int timing_mark(rh_device* dev, hipStream_t on = nullptr) {
     if (!dev->timing) return 0;
     hipEvent_t e = nullptr;
     if (!dev->event_pool.empty()) { e = dev->event_pool.back(); dev->event_pool.pop_back(); }
     else RH_HIP(hipEventCreate(&e));
-    RH_HIP(hipEventRecord(e, dev->stream));
+    RH_HIP(hipEventRecord(e, on ? on : dev->stream));
     dev->timing_events.push_back(e);
     return 0;
 }
@@ -854,7 +891,7 @@ void note_clipping(rh_pipeline* pl, bool clipped) {
 // marks (they create events) and footprint copies that do not exist yet are left out.
 // `fused`: a texture-to-buffer copy that follows the pass in its command buffer and that the tile kernel performs as it
 // writes its tiles back (see fusable_copy), or null.
-int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer, rh_device::PassScratch& ss, bool no_alloc, const CopyCmd* fused) {
+int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer, rh_device::PassScratch& ss_in, bool no_alloc, const CopyCmd* fused) {
     rh_pipeline* pl = c.pipeline;
     const rh_texture* t0 = c.attachments[0].texture;
     const uint32_t W = t0->width, H = t0->height;
@@ -914,7 +951,7 @@ int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer, rh_device::Pa
     const uint32_t n_clusters = empty_scissor ? 0u : p.n_clusters;
 
     if (no_alloc && pl->clips) return fail("rh_submit_static: the pipeline has triangles that cross a clip plane; the kernels that clip them need private memory, which the runtime allocates");
-    hipStream_t s = dev->stream;
+    hipStream_t const sm = dev->stream;         // the main stream: the tile kernel and everything else
     uint64_t total = 0;                          // pairs, or the room for them when the count has not come back yet
     const unsigned long long* pair_total = nullptr;
     const int ms_index = pl->samples == 1 ? 0 : (pl->samples == 2 ? 1 : (pl->samples == 4 ? 2 : 3));
@@ -926,6 +963,24 @@ int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer, rh_device::Pa
     const uint32_t key_bits = bits_for(n_tiles), sort_passes = (key_bits + 7) / 8;
     const bool deferred = may_defer && n_clusters > 0 && dev->pair_guess > 0 && dev->pair_guess < (1ull << 30) && !dev->general_kernels &&
                           sort_passes <= RH_SORT_MAX_PASSES;
+    // The growing scratch areas come in two sets that consecutive passes alternate between; binning and set-up of a pass
+    // queued whole run on the binning stream (see rh_device::bin_stream) unless the vertex stage reads a texture, which a
+    // pass still at work could be rendering.
+    const bool alternating = &ss_in == &dev->grown;
+    const int set = alternating ? dev->scratch_flip : 0;
+    rh_device::PassScratch& ss = (alternating && set) ? dev->grown2 : ss_in;
+    bool vertex_reads_texture = false;
+    for (const SlotRef& sl : pl->slots) if (sl.tex && (sl.visibility & RH_STAGE_VERTEX)) vertex_reads_texture = true;
+    // (only when nothing but the tile kernel of the pass before has been queued on the main stream since that kernel's
+    // start: anything else -- an upload, a copy -- may be what this pass's vertex stage reads, the binning would have to
+    // wait for it and there would be nothing left to run beside)
+    const bool early = deferred && alternating && dev->early_binning && !vertex_reads_texture && !dev->main_dirty && dev->before_tile_valid;
+    if (early && !dev->bin_stream) RH_HIP(hipStreamCreateWithPriority(&dev->bin_stream, hipStreamNonBlocking, dev->bin_priority));
+    hipStream_t const s = early ? dev->bin_stream : sm;     // binning and set-up
+    if (early) {
+        RH_HIP(hipStreamWaitEvent(s, dev->before_tile, 0));
+        if (dev->tile_done_valid[set]) RH_HIP(hipStreamWaitEvent(s, dev->tile_done[set], 0));
+    }
     const uint32_t n_parts = (n_clusters + 255) / 256, n_pair_parts = (n_clusters + RH_PAIR_PART - 1) / RH_PAIR_PART;
     // one area, cleared by one fill: [binning state | start of every tile | end of every tile | look-back status words]
     const size_t cluster_status_at = STATE_HEADER_BYTES + (size_t)n_tiles * 8;
@@ -935,7 +990,7 @@ int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer, rh_device::Pa
     uint8_t* const state_base = ss.tile_start.as<uint8_t>();
     rh_bin_state* const state = reinterpret_cast<rh_bin_state*>(state_base);
     uint32_t* const tile_start = reinterpret_cast<uint32_t*>(state_base + STATE_HEADER_BYTES); uint32_t* const tile_end = tile_start + n_tiles;
-    if (!no_alloc && timing_mark(dev)) return 1;
+    if (!no_alloc && timing_mark(dev, s)) return 1;
     rhk::clear(state_base, state_bytes, s);
     RH_HIP(hipGetLastError());
     uint32_t* sorted_keys = nullptr; uint32_t* sorted_vals = nullptr;
@@ -948,10 +1003,11 @@ int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer, rh_device::Pa
         ba.state = state; ba.cluster_status = reinterpret_cast<unsigned long long*>(state_base + cluster_status_at);
         ba.keys = ss.keys_a.as<uint32_t>(); ba.vals = ss.vals_a.as<uint32_t>();
         ba.capacity = n; ba.sort_passes = sort_passes; ba.host_total = dev->h_total;
-        ba.ticketed = (dev->binning_tickets || n_pair_parts > pl->vs->resident_pair_parts) ? 1u : 0u;
+        // (beside another kernel not every workgroup of the chain may be on the device at once: tickets)
+        ba.ticketed = (early || dev->binning_tickets || n_pair_parts > pl->vs->resident_pair_parts) ? 1u : 0u;
         if (launch_module_kernel(pl->clips ? pl->vs->bin_pairs_clip : pl->vs->bin_pairs, n_pair_parts, RH_PAIR_THREADS, &ba, sizeof ba, s)) return 1;
         const int where = rhk::sort_passes_chained(ss.keys_a.as<uint32_t>(), ss.vals_a.as<uint32_t>(), ss.keys_b.as<uint32_t>(), ss.vals_b.as<uint32_t>(),
-                                                   n, key_bits, state, reinterpret_cast<uint32_t*>(state_base + sort_status_at), dev->h_total, dev->binning_tickets ? 0u : dev->resident_sort_parts, s);
+                                                   n, key_bits, state, reinterpret_cast<uint32_t*>(state_base + sort_status_at), dev->h_total, (early || dev->binning_tickets) ? 0u : dev->resident_sort_parts, s);
         RH_HIP(hipGetLastError());
         RH_HIP(hipEventRecord(dev->counted, s));
         sorted_keys = where ? ss.keys_b.as<uint32_t>() : ss.keys_a.as<uint32_t>();
@@ -974,7 +1030,7 @@ int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer, rh_device::Pa
             if (no_alloc) return fail("rh_submit_static: the pass has triangles that cross a clip plane; the kernels that clip them need private memory, which the runtime allocates");
             pl->clips = true;
             if (dev->timing && !dev->timing_events.empty()) { dev->event_pool.push_back(dev->timing_events.back()); dev->timing_events.pop_back(); }
-            return execute_pass(dev, c, false, ss, no_alloc, fused);
+            return execute_pass(dev, c, false, ss_in, no_alloc, fused);
         }
         if (pl->clips) note_clipping(pl, (uint32_t)dev->h_total[2] != 0u);
         total = dev->h_total[0];
@@ -1004,9 +1060,12 @@ int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer, rh_device::Pa
         sa.rec = ss.rec.as<uint8_t>(); sa.ext = ss.ext.as<uint8_t>(); sa.ext_bytes = ext_bytes;
         sa.n_pairs = n; sa.pair_total = pair_total;
         sa.tile_start = tile_start; sa.tile_end = tile_end;
-        if (!no_alloc && timing_mark(dev)) return 1;
+        if (!no_alloc && timing_mark(dev, s)) return 1;
         if (launch_module_kernel(pl->clips ? pl->fs->setup_clip[ms_index] : pl->fs->setup[ms_index], (n + 255) / 256, 256, &sa, sizeof sa, s)) return 1;
-    } else if (!no_alloc && timing_mark(dev)) return 1;
+    } else if (!no_alloc && timing_mark(dev, s)) return 1;
+    if (!no_alloc && timing_mark(dev, s)) return 1;          // the end of the set-up
+    // the streams meet: the tile kernel waits for the set-up
+    if (early) { RH_HIP(hipEventRecord(dev->setup_done, s)); RH_HIP(hipStreamWaitEvent(sm, dev->setup_done, 0)); }
 
     rh_tile_args ta;
     memset(&ta, 0, sizeof ta);
@@ -1054,7 +1113,7 @@ int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer, rh_device::Pa
                 if (!t || pl->slots[i].kind != RH_SLOT_TEXTURE) continue;
                 if (!t->poly) { if (device_alloc(dev, t->bytes * 4 * RH_POLY_COPIES, &t->poly)) return 1; t->poly_valid = false; }     // (no_alloc: every copy exists, see all_poly)
                 if (!t->poly_valid || t->poly_always) {
-                    rhk::polyphase_build(t->dptr, t->poly, t->width, t->height, t->layers, s);
+                    rhk::polyphase_build(t->dptr, t->poly, t->width, t->height, t->layers, sm);
                     RH_HIP(hipGetLastError());
                     t->poly_valid = true;
                 }
@@ -1066,18 +1125,27 @@ int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer, rh_device::Pa
         ta.variant = (blend_class && tex_class && !dev->general_kernels) ? 1 + (blend_class - 1) * 3 + (tex_class - 1) : 0;
     }
     if (!no_alloc && timing_mark(dev)) return 1;
+    // (what the binning of the next pass may run beside: everything from here to the next thing queued on the main stream)
+    RH_HIP(hipEventRecord(dev->before_tile, sm));
+    dev->before_tile_valid = true;
     if (pl->samples > 1) {
         // every tile runs: the resolve rewrites the whole target from the multisampled texture (Load included)
         const uint32_t f0 = c.attachments[0].texture->format;
         hipFunction_t fn = (f0 == RH_FORMAT_RGBA_F16 || f0 == RH_FORMAT_RGBA_F32) ? pl->fs->tile_ms_wide[ms_index - 1] : pl->fs->tile_ms[ms_index - 1];
-        if (n_launch_tiles > 0 && launch_module_kernel(fn, n_launch_tiles, RH_TILE_THREADS, &ta, sizeof ta, s)) return 1;
+        if (n_launch_tiles > 0 && launch_module_kernel(fn, n_launch_tiles, RH_TILE_THREADS, &ta, sizeof ta, sm)) return 1;
     } else if ((total > 0 || any_clear || fused) && n_launch_tiles > 0) {
         bool any_float = false;
         for (const rh_attachment_desc& a : c.attachments) any_float = any_float || a.texture->format == RH_FORMAT_RGBA_F16 || a.texture->format == RH_FORMAT_RGBA_F32;
         hipFunction_t fn = any_float ? pl->fs->tile_wide[c.attachments.size() - 1] : pl->fs->tile[c.attachments.size() - 1];
-        if (launch_module_kernel(fn, n_launch_tiles, RH_TILE_THREADS, &ta, sizeof ta, s)) return 1;
+        if (launch_module_kernel(fn, n_launch_tiles, RH_TILE_THREADS, &ta, sizeof ta, sm)) return 1;
     }
     if (!no_alloc && timing_mark(dev)) return 1;
+    dev->main_dirty = false;
+    if (alternating) {
+        RH_HIP(hipEventRecord(dev->tile_done[set], sm));
+        dev->tile_done_valid[set] = true;
+        dev->scratch_flip = set ^ 1;
+    }
 
     if (deferred) { dev->pending_clip_kernels = pl->clips; dev->pending_pass = &c; dev->pending_capacity = (uint32_t)total; dev->pending_fused = fused; }
     dev->stats.clusters = n_clusters; dev->stats.bin_entries = deferred ? 0 : total;
@@ -1104,7 +1172,7 @@ int resolve_pending(rh_device* dev, bool blocking) {
     else if (total >= RH_WANTS_CLIP && !c.pipeline->clips) {
         // a triangle crosses a clip plane (nothing was written): the pass runs again, now and from now on with the kernels that clip
         c.pipeline->clips = true;
-        for (int k = 0; k < 4 && dev->timing && !dev->timing_events.empty(); k++) { dev->event_pool.push_back(dev->timing_events.back()); dev->timing_events.pop_back(); }
+        for (int k = 0; k < 5 && dev->timing && !dev->timing_events.empty(); k++) { dev->event_pool.push_back(dev->timing_events.back()); dev->timing_events.pop_back(); }
         dev->stats.reruns++;
         rc = execute_pass(dev, c, false, dev->grown, false, fused);
     }
@@ -1115,7 +1183,7 @@ int resolve_pending(rh_device* dev, bool blocking) {
         if (total <= capacity) dev->pair_guess = std::max<uint64_t>(dev->pair_guess, std::min<uint64_t>(total + total / 4 + 4096, 0x7ffffffeull));
         else {
             // the attempt that wrote nothing is not a pass of its own: its timing marks go back to the pool
-            for (int k = 0; k < 4 && dev->timing && !dev->timing_events.empty(); k++) { dev->event_pool.push_back(dev->timing_events.back()); dev->timing_events.pop_back(); }
+            for (int k = 0; k < 5 && dev->timing && !dev->timing_events.empty(); k++) { dev->event_pool.push_back(dev->timing_events.back()); dev->timing_events.pop_back(); }
             dev->stats.reruns++;
             rc = execute_pass(dev, c, false, dev->grown, false, fused);
         }
@@ -1125,6 +1193,7 @@ int resolve_pending(rh_device* dev, bool blocking) {
 }
 
 int execute_copy(rh_device* dev, const CopyCmd& c) {
+    dev->main_dirty = true;
     rhk::copy_texture_to_buffer((const uint8_t*)c.tex->dptr, c.tex->width * c.tex->bpt, c.ox, c.oy, c.tex->bpt, c.width, c.height,
                                 (uint8_t*)c.buf->dptr, c.bytes_per_row, dev->stream);
     RH_HIP(hipGetLastError());
@@ -1188,14 +1257,15 @@ int rh_device_drain_timings(rh_device* dev, rh_timings* out) {
     if (!dev || !out) return fail("rh_device_drain_timings: bad argument");
     if (enter(dev)) return 1;
     out->passes = 0; out->bin_ms = 0.0; out->setup_ms = 0.0; out->tile_ms = 0.0;
-    const size_t n = dev->timing_events.size() / 4;
+    const size_t n = dev->timing_events.size() / 5;
     for (size_t i = 0; i < n; i++) {
-        hipEvent_t e0 = dev->timing_events[4 * i], e1 = dev->timing_events[4 * i + 1], e2 = dev->timing_events[4 * i + 2], e3 = dev->timing_events[4 * i + 3];
-        RH_HIP(hipEventSynchronize(e3));
+        // start, before set-up, after set-up (the three on the stream that did the binning), before and after the tile kernel
+        hipEvent_t e0 = dev->timing_events[5 * i], e1 = dev->timing_events[5 * i + 1], e2 = dev->timing_events[5 * i + 2], e3 = dev->timing_events[5 * i + 3], e4 = dev->timing_events[5 * i + 4];
+        RH_HIP(hipEventSynchronize(e4));
         float a = 0.0f, b = 0.0f, c = 0.0f;
         RH_HIP(hipEventElapsedTime(&a, e0, e1));
         RH_HIP(hipEventElapsedTime(&b, e1, e2));
-        RH_HIP(hipEventElapsedTime(&c, e2, e3));
+        RH_HIP(hipEventElapsedTime(&c, e3, e4));
         out->passes++; out->bin_ms += a; out->setup_ms += b; out->tile_ms += c;
     }
     for (hipEvent_t e : dev->timing_events) dev->event_pool.push_back(e);

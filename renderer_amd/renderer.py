@@ -182,6 +182,11 @@ class Renderer:
         """Forces the form of the binning chain that launches too large for the device use (identical results; for testing)."""
         _ffi.check(_ffi.lib().rh_device_set_option(self.device, _ffi.OPTION_BINNING_TICKETS, 1 if enabled else 0))
 
+    def set_early_binning(self, enabled):
+        """Binning and set-up of a pass on a stream of their own, beside the tile kernel of the pass before (default on;
+        identical results either way)."""
+        _ffi.check(_ffi.lib().rh_device_set_option(self.device, _ffi.OPTION_EARLY_BINNING, 1 if enabled else 0))
+
     def set_timing(self, enabled):
         _ffi.check(_ffi.lib().rh_device_set_option(self.device, _ffi.OPTION_TIMING, 1 if enabled else 0))
 

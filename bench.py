@@ -282,6 +282,10 @@ def main():
                          "algorithmic_bytes_per_launch": b_alg, "compulsory_bytes_per_launch": b_min,
                          "kernel_ms": tile_ms, "binning_ms": bin_ms, "setup_ms": setup_ms,
                          "fragments_per_s": n_frag / (tile_ms * 1e-3) if tile_ms > 0 else 0.0,
+                         # binning and set-up of frame n+1 run on a stream of their own beside the tile kernel of frame n
+                         # (unless RH_EARLY_BINNING=0): binning_ms is then their wall time spread under that kernel, not
+                         # time added to the frame, and kernel_ms is the tile kernel with that work sharing the GPU
+                         "overlapped": os.environ.get("RH_EARLY_BINNING", "1") != "0",
                          # "hbm" is how the path is priced (bytes the reference's semantics move per fragment); the tile
                          # lives in LDS, so what the kernel actually runs into is the SIMDs' instruction issue rate
                          "limited_by": "VALU instruction issue (LDS-resident tile: HBM traffic is a tenth of the algorithmic bytes)"},

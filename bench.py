@@ -189,6 +189,29 @@ def main():
     # the timed region)
     hip_frame = hs.read_color() if (rank == 0 and n_gpus == 1 and not args.no_cpu_baseline) else None
 
+    # Outside the timed region: the same frames with every launch on the one stream, so that the tile kernel's duration
+    # is also known with nothing beside it (in the timed region the binning of the next frame shares the GPU with it).
+    alone = None
+    overlapped = os.environ.get("RH_EARLY_BINNING", "1") != "0"
+    if rank == 0 and overlapped:
+        renderer.set_early_binning(False)
+        for _ in range(max(2, args.warmup)):
+            step()
+        renderer.synchronize()
+        renderer.set_timing(True)
+        renderer.drain_timings()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        renderer.synchronize()
+        alone_s = time.perf_counter() - t1
+        alone_t = renderer.drain_timings()
+        renderer.set_timing(False)
+        renderer.set_early_binning(True)
+        np_ = max(1, alone_t["passes"])
+        alone = {"ms_per_step": alone_s / args.steps * 1e3, "kernel_ms": alone_t["tile_ms"] / np_,
+                 "binning_ms": alone_t["bin_ms"] / np_, "setup_ms": alone_t["setup_ms"] / np_}
+
     # release the quads scene before the recording leg
     hs.close()
     renderer.close()
@@ -285,11 +308,16 @@ def main():
                          # binning and set-up of frame n+1 run on a stream of their own beside the tile kernel of frame n
                          # (unless RH_EARLY_BINNING=0): binning_ms is then their wall time spread under that kernel, not
                          # time added to the frame, and kernel_ms is the tile kernel with that work sharing the GPU
-                         "overlapped": os.environ.get("RH_EARLY_BINNING", "1") != "0",
+                         "overlapped": overlapped,
                          # "hbm" is how the path is priced (bytes the reference's semantics move per fragment); the tile
                          # lives in LDS, so what the kernel actually runs into is the SIMDs' instruction issue rate
                          "limited_by": "VALU instruction issue (LDS-resident tile: HBM traffic is a tenth of the algorithmic bytes)"},
         }
+        if alone is not None and alone["kernel_ms"] > 0:
+            # the same kernel over the same frames with nothing beside it (untimed leg above): the kernel's own figure
+            a = b_alg / (alone["kernel_ms"] * 1e-3) / 1e9
+            out["roofline"]["alone"] = dict(alone, achieved=a, frac=a / HBM_PEAK_GBS,
+                                            note="early binning off: every launch on one stream; not the timed region")
         if n_gpus == 1 and not args.no_cpu_baseline:
             # CPU restatement (the parity oracle) timed on the host cores, same scene, one full frame.
             cores = min(16, os.cpu_count() or 1)

@@ -12,6 +12,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 #include <deque>
 
@@ -88,6 +89,13 @@ struct rh_device {
     hipStream_t bin_stream = nullptr;           // created when the first pass takes it (a process has few hardware queues)
     int bin_priority = 0;
     int early_binning = 1;
+    // The tiles of a pass's last, partly filled round of workgroups are cut into bands of rows (rh_tile_args::split2_first):
+    // 0 = never, 1 = halves or quarters (one kind per pass), 2 = quarters for as many of them as there is room, halves for the rest.
+    int tail_split = 2;
+    struct Room { hipFunction_t fn; uint32_t groups; };            // per tile kernel: workgroups the whole GPU holds at once
+    Room room[32] = {};
+    int n_room = 0;
+    uint32_t room_override = 0;      // tests: the number of workgroups the GPU is taken to hold (RH_TILE_ROOM)
     int scratch_flip = 0;                       // which of grown / grown2 the next pass takes
     hipEvent_t tile_done[2] = { nullptr, nullptr };   // recorded behind the tile kernel that read the set
     bool tile_done_valid[2] = { false, false };
@@ -326,6 +334,8 @@ int rh_device_create(int hip_ordinal, uint32_t width, uint32_t height, rh_device
         rh_device_destroy(dev); return fail("rh_device_create: creating the binning stream failed");
     }
     if (const char* v = getenv("RH_EARLY_BINNING")) dev->early_binning = atoi(v) ? 1 : 0;
+    if (const char* v = getenv("RH_TAIL_SPLIT")) dev->tail_split = std::max(0, std::min(2, atoi(v)));
+    if (const char* v = getenv("RH_TILE_ROOM")) dev->room_override = (uint32_t)std::max(0, atoi(v));
     dev->compute_units = (uint32_t)prop.multiProcessorCount;
     dev->device_cache_max_bytes = (size_t)prop.totalGlobalMem / 2;
     dev->resident_sort_parts = rhk::sort_pass_resident_parts(dev->compute_units);
@@ -415,6 +425,7 @@ int rh_device_set_option(rh_device* dev, int option, int value) {
     if (option == RH_OPTION_BINNING_TICKETS) { dev->binning_tickets = value ? 1 : 0; return 0; }
     if (option == RH_OPTION_TIMING) { dev->timing = value ? 1 : 0; return 0; }
     if (option == RH_OPTION_EARLY_BINNING) { dev->early_binning = value ? 1 : 0; return 0; }
+    if (option == RH_OPTION_TAIL_SPLIT) { if (value > 2) return fail("rh_device_set_option: RH_OPTION_TAIL_SPLIT takes 0, 1 or 2"); dev->tail_split = (int)value; return 0; }
     if (option == RH_OPTION_STRIP_ROW0 || option == RH_OPTION_STRIP_ROW1) {
         if (value < 0) return fail("rh_device_set_option: negative strip row");
         (option == RH_OPTION_STRIP_ROW0 ? dev->strip_row0 : dev->strip_row1) = (uint32_t)value;
@@ -1137,7 +1148,29 @@ int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer, rh_device::Pa
         bool any_float = false;
         for (const rh_attachment_desc& a : c.attachments) any_float = any_float || a.texture->format == RH_FORMAT_RGBA_F16 || a.texture->format == RH_FORMAT_RGBA_F32;
         hipFunction_t fn = any_float ? pl->fs->tile_wide[c.attachments.size() - 1] : pl->fs->tile[c.attachments.size() - 1];
-        if (launch_module_kernel(fn, n_launch_tiles, RH_TILE_THREADS, &ta, sizeof ta, sm)) return 1;
+        uint32_t n_groups = n_launch_tiles;
+        ta.split2_first = ta.split4_first = n_launch_tiles;
+        if (dev->tail_split) {
+            // The GPU holds `room` workgroups of this kernel at once.  The tiles beyond the last full round of them would
+            // run a few to a SIMD, each no faster than one wave's dependent chain: cut into bands they fill the SIMDs
+            // and end sooner (identical results: a pixel belongs to one band, which walks the same records in order).
+            uint32_t room = dev->room_override;
+            for (int i = 0; i < dev->n_room && !room; i++) if (dev->room[i].fn == fn) room = dev->room[i].groups;
+            if (!room) {
+                int per_cu = 0;
+                if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, RH_TILE_THREADS, 0) != hipSuccess || per_cu <= 0) { (void)hipGetLastError(); per_cu = 16; }
+                room = (uint32_t)per_cu * std::max(1u, dev->compute_units);
+                if (dev->n_room < 32) dev->room[dev->n_room++] = {fn, room};
+            }
+            const uint32_t tail = n_launch_tiles % room, whole = n_launch_tiles - tail;
+            if (tail * 4u <= room) { ta.split2_first = ta.split4_first = whole; n_groups = whole + tail * 4u; }
+            else if (tail * 2u <= room) {
+                const uint32_t quartered = dev->tail_split >= 2 ? (room - tail * 2u) / 2u : 0u;
+                ta.split2_first = whole; ta.split4_first = n_launch_tiles - quartered;
+                n_groups = whole + (tail - quartered) * 2u + quartered * 4u;
+            }
+        }
+        if (launch_module_kernel(fn, n_groups, RH_TILE_THREADS, &ta, sizeof ta, sm)) return 1;
     }
     if (!no_alloc && timing_mark(dev)) return 1;
     dev->main_dirty = false;

@@ -505,8 +505,8 @@ RH_DEVICE void blend_pixel(uint4* px, const rh_attach_dev& at, float4 s, uint32_
 
 // The tile's part of a captured region (rh_attach_dev::cap_ptr): the texels as the attachment's memory holds them, and,
 // from the tile that holds the region's last column, the zeroed bytes behind each row.
-RH_DEVICE void capture_tile(const rh_attach_dev& at, const uint32_t* px, int ox, int oy, int lane) {
-    for (int i = lane; i < TILE_PX; i += 64) {
+RH_DEVICE void capture_tile(const rh_attach_dev& at, const uint32_t* px, int ox, int oy, int lane, int r0 = 0, int rows = TILE) {
+    for (int i = r0 * TILE + lane; i < (r0 + rows) * TILE; i += 64) {
         const uint32_t cx = (uint32_t)(ox + (i & (TILE - 1))) - at.cap_x0, cy = (uint32_t)(oy + i / TILE) - at.cap_y0;
         if (cx < at.cap_w && cy < at.cap_h) {
             const uint32_t v = px[i];
@@ -515,13 +515,13 @@ RH_DEVICE void capture_tile(const rh_attach_dev& at, const uint32_t* px, int ox,
     }
     const uint32_t last = at.cap_x0 + at.cap_w - 1u, pad = (at.cap_pitch - at.cap_w * 4u) / 4u;
     if (last - (uint32_t)ox < (uint32_t)TILE && pad != 0u)
-        for (int r = 0; r < TILE; r++) {
+        for (int r = r0; r < r0 + rows; r++) {
             const uint32_t cy = (uint32_t)(oy + r) - at.cap_y0;
             if (cy < at.cap_h)
                 for (uint32_t k = (uint32_t)lane; k < pad; k += 64u) *reinterpret_cast<uint32_t*>(at.cap_ptr + (size_t)cy * at.cap_pitch + (size_t)(at.cap_w + k) * 4u) = 0u;
         }
 }
-RH_DEVICE void capture_tile(const rh_attach_dev&, const uint4*, int, int, int) {}        // (wide kernels: never asked to)
+RH_DEVICE void capture_tile(const rh_attach_dev&, const uint4*, int, int, int, int, int) {}        // (wide kernels: never asked to)
 
 // The LDS of a tile wave.
 template <int NA, bool WIDE = false>
@@ -546,16 +546,27 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
     const rh_draw_params& p = a.p;
     const int lane = (int)threadIdx.x;
     RH_PHASE_BEGIN
-    const uint32_t tile = blockIdx.x + p.tile_first;
+    // which tile, and which band of its rows (rh_tile_args::split2_first): wave-uniform
+    uint32_t job = blockIdx.x, tile_rel;
+    int r0 = 0, rows = TILE;
+    if (job < a.split2_first) tile_rel = job;
+    else {
+        job -= a.split2_first;
+        const uint32_t halves = (a.split4_first - a.split2_first) * 2u;
+        if (job < halves) { tile_rel = a.split2_first + (job >> 1); rows = TILE / 2; r0 = (int)(job & 1u) * rows; }
+        else { job -= halves; tile_rel = a.split4_first + (job >> 2); rows = TILE / 4; r0 = (int)(job & 3u) * rows; }
+    }
+    const uint32_t tile = tile_rel + p.tile_first;
     const int ox = (int)(tile % p.tiles_x) * TILE, oy = (int)(tile / p.tiles_x) * TILE;
     const uint32_t start = a.tile_start[tile], end = a.tile_end[tile];
+    const int px_first = r0 * TILE, px_end = (r0 + rows) * TILE;
 
     // 1. bring the tile into LDS
 #pragma unroll
     for (int t = 0; t < NA; t++) {
         const rh_attach_dev& at = a.att[t];
         if (at.load_op == 0u && start == end && !at.cap_ptr) continue;          // untouched tile of a Load attachment
-        for (int i = lane; i < TILE_PX; i += 64) {
+        for (int i = px_first + lane; i < px_end; i += 64) {
             const uint32_t gx = (uint32_t)(ox + (i & (TILE - 1))), gy = (uint32_t)(oy + i / TILE);
             PxT v{};
             if (gx < p.width && gy < p.height)
@@ -580,9 +591,11 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
         RH_PHASE_MARK(1)
         // lane = record of this round (all wave-parallel)
         const uint32_t hdr = lane < n ? lds.rec[lane * REC_WORDS] : HDR_EMPTY;
-        const uint32_t bb = hdr_box(hdr), fl = hdr_flags(hdr);
-        const int hx0 = (int)(bb & 0xffu), hy0 = (int)((bb >> 8) & 0xffu), hx1 = (int)((bb >> 16) & 0xffu), hy1 = (int)(bb >> 24);
-        const bool hit = hx0 <= hx1;
+        const uint32_t bb0 = hdr_box(hdr), fl = hdr_flags(hdr);
+        // the box, cut to the rows of this workgroup's band
+        const int hx0 = (int)(bb0 & 0xffu), hy0 = max((int)((bb0 >> 8) & 0xffu), r0), hx1 = (int)((bb0 >> 16) & 0xffu), hy1 = min((int)(bb0 >> 24), r0 + rows - 1);
+        const uint32_t bb = (bb0 & 0x00ff00ffu) | ((uint32_t)hy0 << 8) | ((uint32_t)hy1 << 24);
+        const bool hit = hx0 <= hx1 && hy0 <= hy1;
         const int npx = (hx1 - hx0 + 1) * (hy1 - hy0 + 1);
         const unsigned long long mask = __ballot(hit);
         const int nh = __popcll(mask);
@@ -781,11 +794,11 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
         const bool untouched = at.load_op == 0u && start == end;
         if (untouched && !at.cap_ptr) continue;
         if (!untouched)
-            for (int i = lane; i < TILE_PX; i += 64) {
+            for (int i = px_first + lane; i < px_end; i += 64) {
                 const uint32_t gx = (uint32_t)(ox + (i & (TILE - 1))), gy = (uint32_t)(oy + i / TILE);
                 if (gx < p.width && gy < p.height) store_pixel(at, (size_t)gy * at.pitch_px + gx, lds.px[t][i]);
             }
-        if (!WIDE && at.cap_ptr) capture_tile(at, &lds.px[t][0], ox, oy, lane);
+        if (!WIDE && at.cap_ptr) capture_tile(at, &lds.px[t][0], ox, oy, lane, r0, rows);
     }
     RH_PHASE_MARK(3)
     RH_PHASE_END

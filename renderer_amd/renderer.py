@@ -187,6 +187,11 @@ class Renderer:
         identical results either way)."""
         _ffi.check(_ffi.lib().rh_device_set_option(self.device, _ffi.OPTION_EARLY_BINNING, 1 if enabled else 0))
 
+    def set_tail_split(self, mode):
+        """How the tiles of a pass's last, partly filled round of workgroups are cut into bands of rows: 0 never, 1 one
+        kind of band per pass, 2 (default) quarters where there is room and halves elsewhere (identical results)."""
+        _ffi.check(_ffi.lib().rh_device_set_option(self.device, _ffi.OPTION_TAIL_SPLIT, int(mode)))
+
     def set_timing(self, enabled):
         _ffi.check(_ffi.lib().rh_device_set_option(self.device, _ffi.OPTION_TIMING, 1 if enabled else 0))
 

@@ -142,6 +142,34 @@ def test_axis_aligned_edges_on_pixel_centres(oracle, topology):
     assert orc["fragments"] > 0
 
 
+@pytest.mark.parametrize("size,room", [((512, 288), 0), ((2048, 1152), 0), ((1024, 512), 150), ((1024, 512), 200)])
+def test_last_tiles_cut_into_bands_of_rows(oracle, size, room, monkeypatch):
+    """The tiles beyond the last full round of workgroups run as 2 or 4 bands of rows (RH_OPTION_TAIL_SPLIT): whole tiles
+    only, one kind of band, and the mix give the oracle's bytes (144 tiles: all quartered; 2304: halves, or 768 of them
+    quartered; 512 tiles with the GPU taken to hold 150 or 200 workgroups: whole tiles, then halves and quarters)."""
+    if room:
+        monkeypatch.setenv("RH_TILE_ROOM", str(room))
+    W, H = size
+    scene = scenes.random_quads_scene(20000 if W > 1024 else 6000, 24, W, H, seed=17)
+    scene["record"] = True                       # two attachments and the captured frame
+    want = scenes.draw_oracle(scene)
+    for mode in (0, 1, 2):
+        hs = scenes.HipScene(scene)
+        hs.renderer.set_tail_split(mode)
+        hs.draw()
+        got = {"color": hs.read_color(), "recording": hs.read_recording()}
+        hs.renderer.synchronize()
+        hs.renderer.recorder.process_mapped_buffers()
+        frame, rows = hs.frames[0], []
+        frame.image_data.bytes_fn(lambda b: rows.append(np.array(b).reshape(frame.height, frame.padded_bytes_per_row)))
+        hs.close()
+        for key in got:
+            assert_same(got[key], want[key], f"mode={mode} {key}")
+        # (the tile kernel writes the captured frame as its bands go back to memory)
+        assert_same(rows[0][:, :W * 4].reshape(H, W, 4), want["recording"], f"mode={mode} captured frame")
+        assert not rows[0][:, W * 4:].any()
+
+
 def test_general_and_specialised_kernel_bodies_agree(oracle):
     """The state-specialised kernel bodies and the general body give identical bytes."""
     scene = scenes.random_quads_scene(5000, 24, 512, 288, seed=5)

@@ -101,6 +101,7 @@ def main():
     ap.add_argument("--workload", choices=["c1", "c2"], default="c1",
                     help="c1 (headline): --quads quads of --side px, alpha blend; c2: --quads quads of 2..8 px, additive")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alone", action="store_true", help="skip the untimed leg that runs the same frames with every launch on one stream (profiling runs: the kernel statistics then hold the timed region only)")
     ap.add_argument("--texture-size", type=int, default=0,
                     help="experiment: sample an NxN subsampling of the texture instead of the 256x256 original")
     ap.add_argument("--filter", choices=["linear", "nearest"], default="linear", help="experiment: sampler filter (headline: linear)")
@@ -193,7 +194,7 @@ def main():
     # is also known with nothing beside it (in the timed region the binning of the next frame shares the GPU with it).
     alone = None
     overlapped = os.environ.get("RH_EARLY_BINNING", "1") != "0"
-    if rank == 0 and overlapped:
+    if rank == 0 and overlapped and not args.no_alone:
         renderer.set_early_binning(False)
         for _ in range(max(2, args.warmup)):
             step()

@@ -194,7 +194,7 @@ def main():
     # is also known with nothing beside it (in the timed region the binning of the next frame shares the GPU with it).
     alone = None
     overlapped = os.environ.get("RH_EARLY_BINNING", "1") != "0"
-    if rank == 0 and overlapped and not args.no_alone:
+    if rank == 0 and n_gpus == 1 and overlapped and not args.no_alone:
         renderer.set_early_binning(False)
         for _ in range(max(2, args.warmup)):
             step()

@@ -17,6 +17,9 @@
 //       3. the tile is written back with coalesced row stores (RGBA or BGRA).
 //     Nothing in a tile waits for another wave: there is no workgroup barrier in the kernel, every lane of the set-up
 //     launch has a pair of its own, and a quad is cut into pieces only where it crosses a tile border.
+//     The last workgroups of a single-sampled launch may each take a band of a tile's rows (a half or a quarter of
+//     the tile) instead of a whole tile (rh_tile_args::split2_first): the same records in the same order, every box cut
+//     to the band, only the band's rows brought in and written back -- a pixel still belongs to exactly one wave.
 //
 // The kernel body exists in several specialisations (template parameters BLEND and TEX, selected per launch by
 // rh_tile_args::variant): with the blend factors and the texture format / filter known at compile time the per-fragment

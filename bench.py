@@ -90,6 +90,10 @@ def main():
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
+    if os.environ.get("RH_BENCH_WATCHDOG"):
+        # debugging aid: after that many seconds every thread's Python stack goes to stderr and the process exits
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["RH_BENCH_WATCHDOG"]), exit=True)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
@@ -132,6 +136,9 @@ def main():
         import torch.distributed as dist
         if os.environ.get("RH_REHEARSE_ON_ONE_GPU") == "1":
             # every rank on GPU 0 with gloo between them: a rehearsal of the multi-rank control flow on a one-GPU box
+            # (one stream per process: processes that share a GPU take turns on it, and a pass whose binning runs on
+            # a second queue then waits through the other process's turns -- seconds per pass)
+            os.environ.setdefault("RH_EARLY_BINNING", "0")
             local_rank = 0
             torch.cuda.set_device(0)
             dist.init_process_group(backend="gloo")

@@ -13,7 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def launch(world, script, args, port):
-    env = dict(os.environ, RH_REHEARSE_ON_ONE_GPU="1")
+    # (one stream per process: two processes on one GPU take turns on it, see bench.py)
+    env = dict(os.environ, RH_REHEARSE_ON_ONE_GPU="1", RH_EARLY_BINNING="0")
     if world == 1:
         cmd = [sys.executable, os.path.join(ROOT, "tools", script)] + args
     else:

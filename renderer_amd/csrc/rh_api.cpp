@@ -12,7 +12,6 @@
 #include <map>
 #include <mutex>
 #include <string>
-#include <unordered_map>
 #include <vector>
 #include <deque>
 
@@ -425,7 +424,7 @@ int rh_device_set_option(rh_device* dev, int option, int value) {
     if (option == RH_OPTION_BINNING_TICKETS) { dev->binning_tickets = value ? 1 : 0; return 0; }
     if (option == RH_OPTION_TIMING) { dev->timing = value ? 1 : 0; return 0; }
     if (option == RH_OPTION_EARLY_BINNING) { dev->early_binning = value ? 1 : 0; return 0; }
-    if (option == RH_OPTION_TAIL_SPLIT) { if (value > 2) return fail("rh_device_set_option: RH_OPTION_TAIL_SPLIT takes 0, 1 or 2"); dev->tail_split = (int)value; return 0; }
+    if (option == RH_OPTION_TAIL_SPLIT) { if (value < 0 || value > 2) return fail("rh_device_set_option: RH_OPTION_TAIL_SPLIT takes 0, 1 or 2"); dev->tail_split = (int)value; return 0; }
     if (option == RH_OPTION_STRIP_ROW0 || option == RH_OPTION_STRIP_ROW1) {
         if (value < 0) return fail("rh_device_set_option: negative strip row");
         (option == RH_OPTION_STRIP_ROW0 ? dev->strip_row0 : dev->strip_row1) = (uint32_t)value;

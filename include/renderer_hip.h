@@ -71,7 +71,7 @@ enum {
                                          their own, beside the tile kernel of the pass before (they read only what the
                                          vertex stage reads, and wait for everything queued before the pass that could
                                          change it); 0: everything on one stream (identical results) */
-    RH_OPTION_TAIL_SPLIT = 7,         /* single-sampled passes: the tiles beyond the last full round of workgroups the GPU
+    RH_OPTION_TAIL_SPLIT = 7,         /* the tiles beyond the last full round of workgroups the GPU
                                          holds at once are cut into bands of rows with a workgroup each, so that the end
                                          of the pass fills the SIMDs instead of running a few long waves on each.
                                          0: never; 1: halves or quarters, one kind per pass; 2 (default): quarters for as

@@ -196,7 +196,7 @@ struct rh_tile_args {
     // anything -- the host notices and runs the pass again with enough room.  Null: the lists are known to fit.
     uint32_t pair_capacity;
     const unsigned long long* pair_total;
-    // Workgroups against tiles (single-sampled kernels; the multisampled ones run one workgroup per tile).  A pass ends
+    // Workgroups against tiles.  A pass ends
     // with the machine draining: the last tiles run a few to a SIMD, each at the speed of one wave's dependent chain, so
     // the tiles the last workgroups take may be cut into 2 or 4 bands of rows with a workgroup each (same records, the
     // boxes cut to the band).  Workgroup j < split2_first takes tile j whole; the next 2 * (split4_first - split2_first)

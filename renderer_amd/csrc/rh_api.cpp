@@ -1138,15 +1138,8 @@ int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer, rh_device::Pa
     // (what the binning of the next pass may run beside: everything from here to the next thing queued on the main stream)
     RH_HIP(hipEventRecord(dev->before_tile, sm));
     dev->before_tile_valid = true;
-    if (pl->samples > 1) {
-        // every tile runs: the resolve rewrites the whole target from the multisampled texture (Load included)
-        const uint32_t f0 = c.attachments[0].texture->format;
-        hipFunction_t fn = (f0 == RH_FORMAT_RGBA_F16 || f0 == RH_FORMAT_RGBA_F32) ? pl->fs->tile_ms_wide[ms_index - 1] : pl->fs->tile_ms[ms_index - 1];
-        if (n_launch_tiles > 0 && launch_module_kernel(fn, n_launch_tiles, RH_TILE_THREADS, &ta, sizeof ta, sm)) return 1;
-    } else if ((total > 0 || any_clear || fused) && n_launch_tiles > 0) {
-        bool any_float = false;
-        for (const rh_attachment_desc& a : c.attachments) any_float = any_float || a.texture->format == RH_FORMAT_RGBA_F16 || a.texture->format == RH_FORMAT_RGBA_F32;
-        hipFunction_t fn = any_float ? pl->fs->tile_wide[c.attachments.size() - 1] : pl->fs->tile[c.attachments.size() - 1];
+    // How many workgroups the tile kernel `fn` is launched with, and which tiles they take whole, in halves or in quarters.
+    auto workgroups_for = [&](hipFunction_t fn) -> uint32_t {
         uint32_t n_groups = n_launch_tiles;
         ta.split2_first = ta.split4_first = n_launch_tiles;
         if (dev->tail_split) {
@@ -1169,6 +1162,18 @@ int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer, rh_device::Pa
                 n_groups = whole + (tail - quartered) * 2u + quartered * 4u;
             }
         }
+        return n_groups;
+    };
+    if (pl->samples > 1) {
+        // every tile runs: the resolve rewrites the whole target from the multisampled texture (Load included)
+        const uint32_t f0 = c.attachments[0].texture->format;
+        hipFunction_t fn = (f0 == RH_FORMAT_RGBA_F16 || f0 == RH_FORMAT_RGBA_F32) ? pl->fs->tile_ms_wide[ms_index - 1] : pl->fs->tile_ms[ms_index - 1];
+        if (n_launch_tiles > 0 && launch_module_kernel(fn, workgroups_for(fn), RH_TILE_THREADS, &ta, sizeof ta, sm)) return 1;
+    } else if ((total > 0 || any_clear || fused) && n_launch_tiles > 0) {
+        bool any_float = false;
+        for (const rh_attachment_desc& a : c.attachments) any_float = any_float || a.texture->format == RH_FORMAT_RGBA_F16 || a.texture->format == RH_FORMAT_RGBA_F32;
+        hipFunction_t fn = any_float ? pl->fs->tile_wide[c.attachments.size() - 1] : pl->fs->tile[c.attachments.size() - 1];
+        const uint32_t n_groups = workgroups_for(fn);
         if (launch_module_kernel(fn, n_groups, RH_TILE_THREADS, &ta, sizeof ta, sm)) return 1;
     }
     if (!no_alloc && timing_mark(dev)) return 1;

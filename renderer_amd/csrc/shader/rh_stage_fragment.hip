@@ -17,7 +17,7 @@
 //       3. the tile is written back with coalesced row stores (RGBA or BGRA).
 //     Nothing in a tile waits for another wave: there is no workgroup barrier in the kernel, every lane of the set-up
 //     launch has a pair of its own, and a quad is cut into pieces only where it crosses a tile border.
-//     The last workgroups of a single-sampled launch may each take a band of a tile's rows (a half or a quarter of
+//     The last workgroups of a launch may each take a band of a tile's rows (a half or a quarter of
 //     the tile) instead of a whole tile (rh_tile_args::split2_first): the same records in the same order, every box cut
 //     to the band, only the band's rows brought in and written back -- a pixel still belongs to exactly one wave.
 //
@@ -526,6 +526,19 @@ RH_DEVICE void capture_tile(const rh_attach_dev& at, const uint32_t* px, int ox,
 }
 RH_DEVICE void capture_tile(const rh_attach_dev&, const uint4*, int, int, int, int, int) {}        // (wide kernels: never asked to)
 
+// Which tile a workgroup takes, and which band of its rows (rh_tile_args::split2_first): wave-uniform.
+RH_DEVICE uint32_t tile_of_workgroup(const rh_tile_args& a, int& r0, int& rows) {
+    uint32_t job = blockIdx.x;
+    r0 = 0; rows = TILE;
+    if (job < a.split2_first) return job;
+    job -= a.split2_first;
+    const uint32_t halves = (a.split4_first - a.split2_first) * 2u;
+    if (job < halves) { rows = TILE / 2; r0 = (int)(job & 1u) * rows; return a.split2_first + (job >> 1); }
+    job -= halves;
+    rows = TILE / 4; r0 = (int)(job & 3u) * rows;
+    return a.split4_first + (job >> 2);
+}
+
 // The LDS of a tile wave.
 template <int NA, bool WIDE = false>
 struct TileLds {
@@ -549,17 +562,8 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
     const rh_draw_params& p = a.p;
     const int lane = (int)threadIdx.x;
     RH_PHASE_BEGIN
-    // which tile, and which band of its rows (rh_tile_args::split2_first): wave-uniform
-    uint32_t job = blockIdx.x, tile_rel;
-    int r0 = 0, rows = TILE;
-    if (job < a.split2_first) tile_rel = job;
-    else {
-        job -= a.split2_first;
-        const uint32_t halves = (a.split4_first - a.split2_first) * 2u;
-        if (job < halves) { tile_rel = a.split2_first + (job >> 1); rows = TILE / 2; r0 = (int)(job & 1u) * rows; }
-        else { job -= halves; tile_rel = a.split4_first + (job >> 2); rows = TILE / 4; r0 = (int)(job & 3u) * rows; }
-    }
-    const uint32_t tile = tile_rel + p.tile_first;
+    int r0, rows;
+    const uint32_t tile = tile_of_workgroup(a, r0, rows) + p.tile_first;
     const int ox = (int)(tile % p.tiles_x) * TILE, oy = (int)(tile / p.tiles_x) * TILE;
     const uint32_t start = a.tile_start[tile], end = a.tile_end[tile];
     const int px_first = r0 * TILE, px_end = (r0 + rows) * TILE;
@@ -830,12 +834,14 @@ RH_DEVICE void tile_kernel_ms(const rh_tile_args& a) {
     const rh_draw_params& p = a.p;
     const rh_attach_dev& at = a.att[0];
     const int lane = (int)threadIdx.x;
-    const uint32_t tile = blockIdx.x + p.tile_first;
+    int r0, rows;
+    const uint32_t tile = tile_of_workgroup(a, r0, rows) + p.tile_first;
     const int ox = (int)(tile % p.tiles_x) * TILE, oy = (int)(tile / p.tiles_x) * TILE;
     const uint32_t start = a.tile_start[tile], end = a.tile_end[tile];
+    const int px_first = r0 * TILE, px_end = (r0 + rows) * TILE;
 
     // 1. the tile's samples into LDS (every tile: the resolve below rewrites the whole target)
-    for (int i = lane; i < TILE_PX; i += 64) {
+    for (int i = px_first + lane; i < px_end; i += 64) {
         const uint32_t gx = (uint32_t)(ox + (i & (TILE - 1))), gy = (uint32_t)(oy + i / TILE);
         const bool inside = gx < p.width && gy < p.height;
         const size_t first = ((size_t)gy * at.pitch_px + gx) * S;
@@ -867,7 +873,8 @@ RH_DEVICE void tile_kernel_ms(const rh_tile_args& a) {
             const MsRecord<S>& m = *reinterpret_cast<const MsRecord<S>*>(ef + EXT_WORDS);
             const bool has_a = (flags & FLAG_HAS_A) != 0u, has_b = (flags & FLAG_HAS_B) != 0u;
             const bool any_persp = (flags & (FLAG_PERSP_A | FLAG_PERSP_B)) != 0u;
-            const int hx0 = (int)(hb & 0xffu), hy0 = (int)((hb >> 8) & 0xffu), hx1 = (int)((hb >> 16) & 0xffu), hy1 = (int)(hb >> 24);
+            // (the box cut to the rows of this workgroup's band: nothing left of it = no passes)
+            const int hx0 = (int)(hb & 0xffu), hy0 = max((int)((hb >> 8) & 0xffu), r0), hx1 = (int)((hb >> 16) & 0xffu), hy1 = min((int)(hb >> 24), r0 + rows - 1);
             const int w = hx1 - hx0 + 1, npx = w * (hy1 - hy0 + 1);
             const float wf = (float)w, invw = __builtin_amdgcn_rcpf(wf);
             for (int first = 0; first < npx; first += 64) {
@@ -927,7 +934,7 @@ RH_DEVICE void tile_kernel_ms(const rh_tile_args& a) {
     const float inv_s = 1.0f / (float)S;
     rh_attach_dev rt = at;                   // the resolve target seen as an attachment
     rt.ptr = at.resolve_ptr; rt.pitch_px = at.resolve_pitch_px; rt.format = at.resolve_format;
-    for (int i = lane; i < TILE_PX; i += 64) {
+    for (int i = px_first + lane; i < px_end; i += 64) {
         const uint32_t gx = (uint32_t)(ox + (i & (TILE - 1))), gy = (uint32_t)(oy + i / TILE);
         if (!(gx < p.width && gy < p.height)) continue;
         const size_t first = ((size_t)gy * at.pitch_px + gx) * S;

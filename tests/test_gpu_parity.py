@@ -170,6 +170,26 @@ def test_last_tiles_cut_into_bands_of_rows(oracle, size, room, monkeypatch):
         assert not rows[0][:, W * 4:].any()
 
 
+@pytest.mark.parametrize("samples,fmt,room", [(4, "rgba_u8", 0), (2, "rgba_u8", 150), (8, "rgba_f16", 200)])
+def test_last_tiles_cut_into_bands_of_rows_multisampled(oracle, samples, fmt, room, monkeypatch):
+    """The multisampled tile kernels take bands of rows the same way: samples and resolved image identical to the
+    oracle's with whole tiles only, one kind of band and the mix."""
+    if room:
+        monkeypatch.setenv("RH_TILE_ROOM", str(room))
+    W, H = (512, 288) if not room else (1024, 512)
+    scene = scenes.tilted_quads_scene(1500, W, H, seed=23)
+    scene.update(samples=samples, target_format=fmt)
+    want = scenes.draw_oracle(scene)
+    for mode in (0, 1, 2):
+        hs = scenes.HipScene(scene)
+        hs.renderer.set_tail_split(mode)
+        hs.draw()
+        got = {"color": hs.read_color(), "msaa": hs.pipeline.msaa_texture.read()}
+        hs.close()
+        for key in got:
+            assert_same(got[key], want[key], f"mode={mode} {key}")
+
+
 def test_general_and_specialised_kernel_bodies_agree(oracle):
     """The state-specialised kernel bodies and the general body give identical bytes."""
     scene = scenes.random_quads_scene(5000, 24, 512, 288, seed=5)

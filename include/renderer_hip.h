@@ -71,11 +71,12 @@ enum {
                                          their own, beside the tile kernel of the pass before (they read only what the
                                          vertex stage reads, and wait for everything queued before the pass that could
                                          change it); 0: everything on one stream (identical results) */
-    RH_OPTION_TAIL_SPLIT = 7,         /* the tiles beyond the last full round of workgroups the GPU
-                                         holds at once are cut into bands of rows with a workgroup each, so that the end
-                                         of the pass fills the SIMDs instead of running a few long waves on each.
-                                         0: never; 1: halves or quarters, one kind per pass; 2 (default): quarters for as
-                                         many tiles as there is room, halves for the rest (identical results) */
+    RH_OPTION_TAIL_SPLIT = 7,         /* the tiles beyond the last full round of workgroups the GPU holds at once are cut
+                                         into bands of rows (halves, quarters or eighths of a tile) with a workgroup
+                                         each, so that the end of the pass fills the SIMDs instead of running a few long
+                                         waves on each.  0: never; 1: the finest bands of which they all fit the round;
+                                         2 (default): where those are halves, quarters for as many tiles as there is
+                                         room left (identical results) */
 };
 
 #define RH_MAX_ATTRIBUTES 8

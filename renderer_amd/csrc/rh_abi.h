@@ -4,7 +4,7 @@
 #pragma once
 #include <stdint.h>
 
-#define RH_DEVICE_ABI_VERSION 15u
+#define RH_DEVICE_ABI_VERSION 16u
 #define RH_MODULE_MAGIC 0x52484d4fu   // "RHMO"
 
 #define RH_DEV_MAX_ATTRIBUTES 8
@@ -196,11 +196,12 @@ struct rh_tile_args {
     // anything -- the host notices and runs the pass again with enough room.  Null: the lists are known to fit.
     uint32_t pair_capacity;
     const unsigned long long* pair_total;
-    // Workgroups against tiles.  A pass ends
-    // with the machine draining: the last tiles run a few to a SIMD, each at the speed of one wave's dependent chain, so
-    // the tiles the last workgroups take may be cut into 2 or 4 bands of rows with a workgroup each (same records, the
-    // boxes cut to the band).  Workgroup j < split2_first takes tile j whole; the next 2 * (split4_first - split2_first)
-    // take the halves of tiles split2_first .. split4_first - 1; the rest take the quarters of the tiles from
-    // split4_first on.  (All relative to rh_draw_params::tile_first; both = the number of tiles: nothing is cut.)
-    uint32_t split2_first, split4_first;
+    // Workgroups against tiles.  A pass ends with the machine draining: the last tiles run a few to a SIMD, each at the
+    // speed of one wave's dependent chain, so the tiles the last workgroups take may be cut into 2, 4 or 8 bands of rows
+    // with a workgroup each (same records, the boxes cut to the band).  Workgroup j < split2_first takes tile j whole;
+    // the next 2 * (split4_first - split2_first) take the halves of tiles split2_first .. split4_first - 1; the next
+    // 4 * (split8_first - split4_first) the quarters of tiles split4_first .. split8_first - 1; the rest the eighths of
+    // the tiles from split8_first on.  (All relative to rh_draw_params::tile_first; all three = the number of tiles:
+    // nothing is cut.)
+    uint32_t split2_first, split4_first, split8_first;
 };

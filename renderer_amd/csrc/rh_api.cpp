@@ -89,7 +89,7 @@ struct rh_device {
     int bin_priority = 0;
     int early_binning = 1;
     // The tiles of a pass's last, partly filled round of workgroups are cut into bands of rows (rh_tile_args::split2_first):
-    // 0 = never, 1 = halves or quarters (one kind per pass), 2 = quarters for as many of them as there is room, halves for the rest.
+    // 0 = never, 1 = halves, quarters or eighths (one kind per pass), 2 = where that kind is halves, quarters for as many of them as there is room left.
     int tail_split = 2;
     struct Room { hipFunction_t fn; uint32_t groups; };            // per tile kernel: workgroups the whole GPU holds at once
     Room room[32] = {};
@@ -1141,7 +1141,7 @@ int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer, rh_device::Pa
     // How many workgroups the tile kernel `fn` is launched with, and which tiles they take whole, in halves or in quarters.
     auto workgroups_for = [&](hipFunction_t fn) -> uint32_t {
         uint32_t n_groups = n_launch_tiles;
-        ta.split2_first = ta.split4_first = n_launch_tiles;
+        ta.split2_first = ta.split4_first = ta.split8_first = n_launch_tiles;
         if (dev->tail_split) {
             // The GPU holds `room` workgroups of this kernel at once.  The tiles beyond the last full round of them would
             // run a few to a SIMD, each no faster than one wave's dependent chain: cut into bands they fill the SIMDs
@@ -1155,11 +1155,17 @@ int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer, rh_device::Pa
                 if (dev->n_room < 32) dev->room[dev->n_room++] = {fn, room};
             }
             const uint32_t tail = n_launch_tiles % room, whole = n_launch_tiles - tail;
-            if (tail * 4u <= room) { ta.split2_first = ta.split4_first = whole; n_groups = whole + tail * 4u; }
-            else if (tail * 2u <= room) {
-                const uint32_t quartered = dev->tail_split >= 2 ? (room - tail * 2u) / 2u : 0u;
-                ta.split2_first = whole; ta.split4_first = n_launch_tiles - quartered;
-                n_groups = whole + (tail - quartered) * 2u + quartered * 4u;
+            // the finest bands of which the whole tail fits the round (a last round more than half full is left
+            // alone); in the mixed mode, where those are halves, quarters for as many of its last tiles as there is
+            // room left (measured: quarters mixed with eighths are slower than quarters alone)
+            const uint32_t cut = tail * 8u <= room ? 8u : tail * 4u <= room ? 4u : tail * 2u <= room ? 2u : 1u;
+            if (cut > 1u) {
+                const uint32_t finer = (dev->tail_split >= 2 && cut == 2u) ? (room - tail * cut) / cut : 0u;    // (< tail)
+                const uint32_t coarse_first = whole, finer_first = n_launch_tiles - finer;
+                ta.split2_first = cut == 2u ? coarse_first : whole;
+                ta.split4_first = cut == 2u ? finer_first : (cut == 4u ? coarse_first : whole);
+                ta.split8_first = cut == 2u ? n_launch_tiles : (cut == 4u ? finer_first : coarse_first);
+                n_groups = whole + (tail - finer) * cut + finer * cut * 2u;
             }
         }
         return n_groups;

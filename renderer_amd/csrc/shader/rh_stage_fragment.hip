@@ -17,8 +17,8 @@
 //       3. the tile is written back with coalesced row stores (RGBA or BGRA).
 //     Nothing in a tile waits for another wave: there is no workgroup barrier in the kernel, every lane of the set-up
 //     launch has a pair of its own, and a quad is cut into pieces only where it crosses a tile border.
-//     The last workgroups of a launch may each take a band of a tile's rows (a half or a quarter of
-//     the tile) instead of a whole tile (rh_tile_args::split2_first): the same records in the same order, every box cut
+//     The last workgroups of a launch may each take a band of a tile's rows (a half, a quarter or an
+//     eighth of the tile) instead of a whole tile (rh_tile_args::split2_first): the same records in the same order, every box cut
 //     to the band, only the band's rows brought in and written back -- a pixel still belongs to exactly one wave.
 //
 // The kernel body exists in several specialisations (template parameters BLEND and TEX, selected per launch by
@@ -535,8 +535,11 @@ RH_DEVICE uint32_t tile_of_workgroup(const rh_tile_args& a, int& r0, int& rows) 
     const uint32_t halves = (a.split4_first - a.split2_first) * 2u;
     if (job < halves) { rows = TILE / 2; r0 = (int)(job & 1u) * rows; return a.split2_first + (job >> 1); }
     job -= halves;
-    rows = TILE / 4; r0 = (int)(job & 3u) * rows;
-    return a.split4_first + (job >> 2);
+    const uint32_t quarters = (a.split8_first - a.split4_first) * 4u;
+    if (job < quarters) { rows = TILE / 4; r0 = (int)(job & 3u) * rows; return a.split4_first + (job >> 2); }
+    job -= quarters;
+    rows = TILE / 8; r0 = (int)(job & 7u) * rows;
+    return a.split8_first + (job >> 3);
 }
 
 // The LDS of a tile wave.

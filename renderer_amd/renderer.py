@@ -189,7 +189,8 @@ class Renderer:
 
     def set_tail_split(self, mode):
         """How the tiles of a pass's last, partly filled round of workgroups are cut into bands of rows: 0 never, 1 one
-        kind of band per pass, 2 (default) quarters where there is room and halves elsewhere (identical results)."""
+        kind of band per pass (halves, quarters or eighths), 2 (default) quarters beside the halves where there is room
+        left (identical results)."""
         _ffi.check(_ffi.lib().rh_device_set_option(self.device, _ffi.OPTION_TAIL_SPLIT, int(mode)))
 
     def set_timing(self, enabled):

@@ -142,11 +142,12 @@ def test_axis_aligned_edges_on_pixel_centres(oracle, topology):
     assert orc["fragments"] > 0
 
 
-@pytest.mark.parametrize("size,room", [((512, 288), 0), ((2048, 1152), 0), ((1024, 512), 150), ((1024, 512), 200)])
+@pytest.mark.parametrize("size,room", [((512, 288), 0), ((2048, 1152), 0), ((1600, 1024), 0), ((1024, 512), 150), ((1024, 512), 200), ((1024, 512), 1500)])
 def test_last_tiles_cut_into_bands_of_rows(oracle, size, room, monkeypatch):
     """The tiles beyond the last full round of workgroups run as 2 or 4 bands of rows (RH_OPTION_TAIL_SPLIT): whole tiles
-    only, one kind of band, and the mix give the oracle's bytes (144 tiles: all quartered; 2304: halves, or 768 of them
-    quartered; 512 tiles with the GPU taken to hold 150 or 200 workgroups: whole tiles, then halves and quarters)."""
+    only, one kind of band, and the mix give the oracle's bytes (144 tiles: eighths; 2304: halves, or 768 of them
+    quartered; 1600: quarters; 512 tiles with the GPU taken to hold 150, 200 or 1500 workgroups: whole
+    tiles and then halves and quarters, or halves and quarters of all of them)."""
     if room:
         monkeypatch.setenv("RH_TILE_ROOM", str(room))
     W, H = size

@@ -142,12 +142,13 @@ def test_axis_aligned_edges_on_pixel_centres(oracle, topology):
     assert orc["fragments"] > 0
 
 
-@pytest.mark.parametrize("size,room", [((512, 288), 0), ((2048, 1152), 0), ((1600, 1024), 0), ((1024, 512), 150), ((1024, 512), 200), ((1024, 512), 1500)])
+@pytest.mark.parametrize("size,room", [((512, 288), 0), ((1024, 512), 150), ((1024, 512), 460), ((1024, 512), 1500), ((1024, 512), 2500), ((1024, 512), 5000)])
 def test_last_tiles_cut_into_bands_of_rows(oracle, size, room, monkeypatch):
-    """The tiles beyond the last full round of workgroups run as 2 or 4 bands of rows (RH_OPTION_TAIL_SPLIT): whole tiles
-    only, one kind of band, and the mix give the oracle's bytes (144 tiles: eighths; 2304: halves, or 768 of them
-    quartered; 1600: quarters; 512 tiles with the GPU taken to hold 150, 200 or 1500 workgroups: whole
-    tiles and then halves and quarters, or halves and quarters of all of them)."""
+    """The tiles beyond the last full round of workgroups run as 2, 4 or 8 bands of rows (RH_OPTION_TAIL_SPLIT): whole
+    tiles only, one kind of band, and the mix give the oracle's bytes.  144 tiles on the real GPU: eighths.  512 tiles
+    with the GPU taken to hold 150 workgroups: 450 whole tiles, then halves (the last 13 quartered in the mixed mode);
+    460: 460 whole, 52 in eighths; 1500: all halved (238 quartered in the mixed mode); 2500: all quartered; 5000: all in
+    eighths."""
     if room:
         monkeypatch.setenv("RH_TILE_ROOM", str(room))
     W, H = size
@@ -171,7 +172,7 @@ def test_last_tiles_cut_into_bands_of_rows(oracle, size, room, monkeypatch):
         assert not rows[0][:, W * 4:].any()
 
 
-@pytest.mark.parametrize("samples,fmt,room", [(4, "rgba_u8", 0), (2, "rgba_u8", 150), (8, "rgba_f16", 200)])
+@pytest.mark.parametrize("samples,fmt,room", [(4, "rgba_u8", 0), (2, "rgba_u8", 150), (8, "rgba_f16", 1500), (4, "rgba_f32", 2500)])
 def test_last_tiles_cut_into_bands_of_rows_multisampled(oracle, samples, fmt, room, monkeypatch):
     """The multisampled tile kernels take bands of rows the same way: samples and resolved image identical to the
     oracle's with whole tiles only, one kind of band and the mix."""

@@ -527,19 +527,30 @@ RH_DEVICE void capture_tile(const rh_attach_dev& at, const uint32_t* px, int ox,
 RH_DEVICE void capture_tile(const rh_attach_dev&, const uint4*, int, int, int, int, int) {}        // (wide kernels: never asked to)
 
 // Which tile a workgroup takes, and which band of its rows (rh_tile_args::split2_first): wave-uniform.
+// Workgroups go to the eight XCDs in turn, each with an L2 of its own, and the bands of a tile read the same records:
+// within the tiles cut into F bands, eight consecutive tiles form a group whose 8 * F workgroups are numbered band by
+// band, so that the bands of a tile are eight workgroups apart -- on the same XCD, one after the other.
+template <uint32_t F>
+RH_DEVICE uint32_t band_of_workgroup(uint32_t job, uint32_t n_tiles, int& r0, int& rows) {
+    const uint32_t group = job / (8u * F), r = job - group * (8u * F);
+    const uint32_t left = n_tiles - group * 8u, m = left < 8u ? left : 8u;       // tiles of this group (the last may hold fewer)
+    const uint32_t band = r / m;
+    rows = TILE / (int)F; r0 = (int)band * rows;
+    return group * 8u + (r - band * m);
+}
 RH_DEVICE uint32_t tile_of_workgroup(const rh_tile_args& a, int& r0, int& rows) {
     uint32_t job = blockIdx.x;
     r0 = 0; rows = TILE;
     if (job < a.split2_first) return job;
     job -= a.split2_first;
-    const uint32_t halves = (a.split4_first - a.split2_first) * 2u;
-    if (job < halves) { rows = TILE / 2; r0 = (int)(job & 1u) * rows; return a.split2_first + (job >> 1); }
-    job -= halves;
-    const uint32_t quarters = (a.split8_first - a.split4_first) * 4u;
-    if (job < quarters) { rows = TILE / 4; r0 = (int)(job & 3u) * rows; return a.split4_first + (job >> 2); }
-    job -= quarters;
-    rows = TILE / 8; r0 = (int)(job & 7u) * rows;
-    return a.split8_first + (job >> 3);
+    const uint32_t halved = a.split4_first - a.split2_first;
+    if (job < halved * 2u) return a.split2_first + band_of_workgroup<2>(job, halved, r0, rows);
+    job -= halved * 2u;
+    const uint32_t quartered = a.split8_first - a.split4_first;
+    if (job < quartered * 4u) return a.split4_first + band_of_workgroup<4>(job, quartered, r0, rows);
+    job -= quartered * 4u;
+    const uint32_t in_eighths = (gridDim.x - (blockIdx.x - job)) >> 3;          // the rest of the grid is theirs
+    return a.split8_first + band_of_workgroup<8>(job, in_eighths, r0, rows);
 }
 
 // The LDS of a tile wave.

@@ -166,3 +166,13 @@ def test_bench_capture_plan_shrinks_with_ranks_and_room(monkeypatch):
         assert [p[:3] for p in plans] == [(4096, 1024, 1), (2048, 1024, 1), (1024, 512, 1), (512, 256, 2)]
     monkeypatch.setattr(shutil, "disk_usage", lambda path: Usage(252e9, 251e9, 1e9))
     assert bench.capture_plan(1, None, 0)[:3] == (128, 128, 1)
+
+
+def test_option_numbers_of_the_python_mirror_match_the_header():
+    """renderer_amd/_ffi.py repeats the RH_OPTION_* values of include/renderer_hip.h."""
+    from renderer_amd import _ffi
+    header = open(os.path.join(ROOT, "include", "renderer_hip.h")).read()
+    declared = {name: int(value) for name, value in re.findall(r"RH_OPTION_([A-Z_0-9]+) = (\d+)", header)}
+    assert len(declared) >= 8
+    for name, value in declared.items():
+        assert getattr(_ffi, "OPTION_" + name) == value, name

@@ -84,16 +84,30 @@ def capture_plan(n_ranks, dist, local_rank):
     return plans[choice] + (root,)
 
 
+def launch_ranks(n):
+    """`bench.py --gpus N` started as one plain process: start the N ranks here, as fresh child processes under
+    torch.distributed.run (one rank per GPU, RCCL between them), before this process has made any GPU call, relay
+    rank 0's one JSON line and leave with the launcher's exit status.  The value of a run is never scaled by the
+    argument: it is what the ranks that really ran measured."""
+    import socket
+    import subprocess
+    rehearsal = os.environ.get("RH_REHEARSE_ON_ONE_GPU") == "1"
+    if not rehearsal:
+        import torch                      # (counting devices does not initialise the GPU)
+        have = torch.cuda.device_count()
+        if have < n:
+            sys.stderr.write(f"bench.py: --gpus {n} but this host shows {have} GPU(s); set RH_REHEARSE_ON_ONE_GPU=1 to rehearse "
+                             f"the {n}-rank control flow on one GPU (gloo, not a measurement of scaling)\n")
+            return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd).returncode        # the children inherit stdout: rank 0 writes the line there itself
+
+
 def main():
-    # Libraries underneath (RCCL prints a version banner at start-up) write to stdout: keep the real stdout for the one
-    # JSON line and send everything else to stderr.
-    sys.stdout.flush()
-    json_fd = os.dup(1)
-    os.dup2(2, 1)
-    if os.environ.get("RH_BENCH_WATCHDOG"):
-        # debugging aid: after that many seconds every thread's Python stack goes to stderr and the process exits
-        import faulthandler
-        faulthandler.dump_traceback_later(float(os.environ["RH_BENCH_WATCHDOG"]), exit=True)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
@@ -117,6 +131,24 @@ def main():
                     help="stream files per GPU; default 1024 (one wavefront per stream: four per compute unit; a round of up "
                          "to 1024 streams takes about as long as a round of one)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be at least 1")
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            sys.exit(launch_ranks(args.gpus))
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} rank(s); "
+                         "the two must agree\n")
+        sys.exit(2)
+    # Libraries underneath (RCCL prints a version banner at start-up) write to stdout: keep the real stdout for the one
+    # JSON line and send everything else to stderr.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    if os.environ.get("RH_BENCH_WATCHDOG"):
+        # debugging aid: after that many seconds every thread's Python stack goes to stderr and the process exits
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["RH_BENCH_WATCHDOG"]), exit=True)
     if args.quads <= 0:
         args.quads = 1_000_000 if args.workload == "c1" else 10_000_000
 
@@ -126,7 +158,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    n_gpus = max(args.gpus, world)
+    n_gpus = world                     # the ranks that run, never the argument (checked against it above)
+    backend, devices = "none", [local_rank]
 
     dist = None
     if world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ):
@@ -145,6 +178,16 @@ def main():
         else:
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if dist.get_world_size() != args.gpus:
+            sys.stderr.write(f"bench.py: --gpus {args.gpus} but the process group has {dist.get_world_size()} rank(s)\n")
+            sys.exit(2)
+        n_gpus = dist.get_world_size()
+        backend = dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else " (rehearsal: every rank on GPU 0)")
+        # the device ordinal every rank renders on, as the ranks report them
+        t = torch.zeros(n_gpus, dtype=torch.int64, device=f"cuda:{local_rank}")
+        t[rank] = local_rank
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        devices = [int(v) for v in t.tolist()]
 
     import numpy as np
     import scenes
@@ -245,20 +288,25 @@ def main():
                 warmup=capture_warm_rounds * args.capture_streams)
         except Exception as e:                   # e.g. no room for the stream files: report it, keep the quads/s line
             cap_error = f"rank {rank}: {type(e).__name__}: {e}"
+        # a frame the recorder dropped (no room in the capture budget) is not a recorded frame
+        recorded_frames = (args.capture_frames - cap_info["frames_dropped"]) if cap_info is not None else 0
         if dist is not None:
             # ranks start the leg together (they all left the barrier of the first leg) and the slowest one counts
             import torch
             t = torch.tensor([cap_s], dtype=torch.float64, device=f"cuda:{local_rank}")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             cap_s = float(t.item())
+            t = torch.tensor([recorded_frames], dtype=torch.int64, device=f"cuda:{local_rank}")
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            recorded_frames = int(t.item())
         if cap_info is None or cap_s == float("inf"):
             capture = {"metric": "recorded frames/s", "value": None, "error": cap_error or "failed on another rank"}
         else:
-            capture = {"metric": "recorded frames/s", "value": args.capture_frames * n_gpus / cap_s, "unit": "frames/s",
+            capture = {"metric": "recorded frames/s", "value": recorded_frames / cap_s, "unit": "frames/s",
                        "frames_per_gpu": args.capture_frames, "streams_per_gpu": args.capture_streams,
                        "ms_per_frame_per_gpu": cap_s / args.capture_frames * 1e3, "workload": cap_info["workload"],
                        "raw_MB_per_frame": cap_info["raw_MB_per_frame"], "compressed_MB_per_frame": cap_info["compressed_MB_per_frame"],
-                       "frames_dropped": cap_info["frames_dropped"], "budget_MB": cap_info["budget_MB"],
+                       "frames_recorded": recorded_frames, "frames_dropped": cap_info["frames_dropped"], "budget_MB": cap_info["budget_MB"],
                        "stream_files_in": capture_root}
             # rh_lz4f_compress against the HBM roofline: the bytes it must read and write (raw frames in, LZ4F streams
             # out) over the HIP-event time of its launches (this rank's)
@@ -277,7 +325,7 @@ def main():
 
     parity_failed = False
     if rank == 0:
-        total_quads = args.quads * args.steps * n_gpus
+        total_quads = args.quads * args.steps * n_gpus          # every one of the n_gpus ranks drew `steps` frames of `quads`
         value = total_quads / elapsed
         ms_per_step = elapsed / args.steps * 1e3
         # Algorithmic bytes of one tile-kernel launch (one frame): every instance record read once, every blended
@@ -298,7 +346,7 @@ def main():
         traffic = pmc_traffic_bytes("c1") if default_workload else (pmc_traffic_bytes("c2") if c2_profiled else None)
         out = {
             "metric": "instanced quads/s at 4K alpha-blend" if args.workload == "c1" else "instanced quads/s at 4K additive tiny quads", "value": value, "unit": "quads/s",
-            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "n_gpus": n_gpus, "ranks": n_gpus, "backend": backend, "devices": devices, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32->unorm8",
             "data": "synthetic",
             "config": {"workload": (f"{args.quads} instanced textured quads {args.side}x{args.side} px, pre-multiplied alpha blend, "

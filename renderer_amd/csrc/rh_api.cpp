@@ -115,6 +115,7 @@ struct rh_device {
     const void* pending_pass = nullptr;         // (a PassCmd of the command buffer being submitted, or of `pending_cb`)
     const void* pending_fused = nullptr;        // (the CopyCmd performed by that pass, or null)
     rh_cmdbuf* pending_cb = nullptr;            // the last command buffer of a submit, kept while its last pass awaits its count
+    std::vector<rh_cmdbuf*> kept_cbs;           // command buffers whose release was put off by rh_submit_static (releasing may free memory)
     uint32_t pending_capacity = 0;
     // allocation caches (exact-size reuse; capture buffers come and go every frame)
     std::multimap<size_t, void*> free_device, free_pinned;
@@ -283,9 +284,18 @@ int staged_upload(rh_device* dev, void* dst, const void* src, size_t len) {
 }
 
 int set_device(rh_device* dev) { RH_HIP(hipSetDevice(dev->ordinal)); return 0; }
-int resolve_pending(rh_device* dev, bool blocking = true);
+int resolve_pending(rh_device* dev, bool blocking = true, bool may_rerun = true);
+void release_kept(rh_device* dev);
 // What every entry point that queues work on the device's stream, reads results or hands out device memory starts with.
-int enter(rh_device* dev) { return set_device(dev) || resolve_pending(dev); }
+int enter(rh_device* dev) { if (set_device(dev)) return 1; release_kept(dev); return resolve_pending(dev); }
+
+// rh_submit_static: every rh_device of a GPU works in that GPU's one static scratch array, each on a stream of its own,
+// and a call returns with its kernels still queued.  One event per GPU, recorded behind the last kernel of every call and
+// waited for (on the device) by the next call on that GPU from whichever rh_device, keeps returned calls from
+// overlapping on the GPU.  Created with the first rh_device of the GPU, kept until the process ends.
+constexpr int RH_MAX_ORDINALS = 64;
+std::mutex g_static_mutex;
+hipEvent_t g_static_tail[RH_MAX_ORDINALS] = {};
 
 uint32_t unorm8(double c) {
     float o = (float)c;
@@ -356,6 +366,13 @@ int rh_device_create(int hip_ordinal, uint32_t width, uint32_t height, rh_device
         carve(h.tile_start, STATE_HEADER_BYTES + (size_t)RH_STATIC_MAX_TILES * 8);
         carve(h.rec, (size_t)RH_STATIC_RECORD_BYTES); carve(h.ext, (size_t)RH_STATIC_RECORD_BYTES);
         if ((size_t)(at - (uint8_t*)base) > bytes) { rh_device_destroy(dev); return fail("rh_device_create: the static scratch array is smaller than its areas"); }
+        if (hip_ordinal < RH_MAX_ORDINALS) {
+            std::lock_guard<std::mutex> lock(g_static_mutex);
+            if (!g_static_tail[hip_ordinal] && hipEventCreateWithFlags(&g_static_tail[hip_ordinal], hipEventDisableTiming) != hipSuccess) {
+                g_static_tail[hip_ordinal] = nullptr;
+                rh_device_destroy(dev); return fail("rh_device_create: creating the event of the static scratch array failed");
+            }
+        }
     }
     *out = dev;
     return 0;
@@ -369,6 +386,7 @@ void rh_device_destroy(rh_device* dev) {
     (void)hipStreamSynchronize(dev->stream);
     dev->pending_pass = nullptr;                // (nobody will look at the results of a pass still awaiting its count)
     if (dev->pending_cb) { rh_cmdbuf* cb = dev->pending_cb; dev->pending_cb = nullptr; rh_cmdbuf_release(cb); }
+    { std::vector<rh_cmdbuf*> kept; kept.swap(dev->kept_cbs); for (rh_cmdbuf* cb : kept) rh_cmdbuf_release(cb); }
     std::vector<rh_buffer*> pending; pending.swap(dev->pending_maps);
     for (rh_buffer* b : pending) rh_buffer_release(b);
     rh_texture* screen = dev->screen; dev->screen = nullptr;
@@ -475,6 +493,8 @@ int rh_buffer_create(rh_device* dev, size_t size, uint32_t usage, const void* in
     // not cover is cleared (a never-set uniform, the headroom of a grown Buffer, capture rows the copy does not reach)
     hipError_t e = hipSuccess;
     const size_t filled = (init && init_len) ? init_len : 0;
+    // (queued on the main stream: the binning of the next pass may read this buffer, so it must not run ahead of these)
+    dev->main_dirty = true;
     if (filled) e = hipMemcpyAsync(b->dptr, init, filled, hipMemcpyHostToDevice, dev->stream);
     if (e == hipSuccess && filled < size) e = hipMemsetAsync((uint8_t*)b->dptr + filled, 0, size - filled, dev->stream);
     if (e != hipSuccess) { device_free(dev, size, b->dptr); delete b; device_release(dev); return fail("rh_buffer_create: initialisation failed: %s", hipGetErrorString(e)); }
@@ -573,6 +593,7 @@ int rh_texture_create(rh_device* dev, uint32_t width, uint32_t height, uint32_t 
     if (device_alloc(dev, t->bytes, &t->dptr)) { delete t; return 1; }
     device_retain(dev);
     // wgpu textures start zero-initialised
+    dev->main_dirty = true;
     hipError_t e = hipMemsetAsync(t->dptr, 0, t->bytes, dev->stream);
     if (e != hipSuccess) { device_free(dev, t->bytes, t->dptr); delete t; device_release(dev); return fail("rh_texture_create: clear failed: %s", hipGetErrorString(e)); }
     *out = t;
@@ -1199,7 +1220,15 @@ int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer, rh_device::Pa
 // Looks at the pair count of the pass that was queued without waiting for it (before anything else is queued behind
 // it): normally it fitted and there is nothing to do; otherwise its kernels have written nothing, and the pass runs
 // again in the waiting form.
-int resolve_pending(rh_device* dev, bool blocking) {
+void release_kept(rh_device* dev) {
+    if (dev->kept_cbs.empty()) return;
+    std::vector<rh_cmdbuf*> kept; kept.swap(dev->kept_cbs);
+    for (rh_cmdbuf* cb : kept) rh_cmdbuf_release(cb);
+}
+
+// `may_rerun` false (rh_submit_static, which must not allocate): a pass that has to run again is an error, and the
+// release of its command buffer -- which may hand memory back -- is left to the next call that may.
+int resolve_pending(rh_device* dev, bool blocking, bool may_rerun) {
     if (!dev->pending_pass) return 0;
     if (!blocking && hipEventQuery(dev->counted) == hipErrorNotReady) return 0;
     const PassCmd& c = *static_cast<const PassCmd*>(dev->pending_pass);
@@ -1212,6 +1241,12 @@ int resolve_pending(rh_device* dev, bool blocking) {
     const uint64_t total = dev->h_total[0];
     if (e != hipSuccess) rc = fail("render pass: waiting for the pair count failed: %s", hipGetErrorString(e));
     else if (dev->h_total[1]) { dev->h_total[1] = 0; rc = fail("render pass: a binning workgroup gave up waiting for its predecessors; the results of the pass are undefined"); }
+    else if (!may_rerun && ((total >= RH_WANTS_CLIP && !c.pipeline->clips) || (total < 0x7fffffffull && total > capacity))) {
+        // (left pending: the next call that may allocate runs it again)
+        dev->pending_pass = &c; dev->pending_cb = kept;
+        return fail("rh_submit_static: a render pass of an earlier rh_submit has to run again (its (tile, triangle pair) array was too small, "
+                    "or it met its pipeline's first clipped triangle), which allocates; call rh_device_synchronize first");
+    }
     else if (total >= RH_WANTS_CLIP && !c.pipeline->clips) {
         // a triangle crosses a clip plane (nothing was written): the pass runs again, now and from now on with the kernels that clip
         c.pipeline->clips = true;
@@ -1231,7 +1266,7 @@ int resolve_pending(rh_device* dev, bool blocking) {
             rc = execute_pass(dev, c, false, dev->grown, false, fused);
         }
     }
-    if (kept) rh_cmdbuf_release(kept);
+    if (kept) { if (may_rerun) rh_cmdbuf_release(kept); else dev->kept_cbs.push_back(kept); }
     return rc;
 }
 
@@ -1280,7 +1315,12 @@ int rh_submit(rh_device* dev, rh_cmdbuf* const* list, size_t n) {
 int rh_submit_static(rh_device* dev, rh_cmdbuf* const* list, size_t n) {
     if (!dev || (!list && n)) return fail("rh_submit_static: bad argument");
     if (!dev->held.rec.ptr) return fail("rh_submit_static: the static scratch array of this device is not available");
-    if (enter(dev)) return 1;
+    if (set_device(dev) || resolve_pending(dev, true, false)) return 1;
+    hipEvent_t const tail = dev->ordinal < RH_MAX_ORDINALS ? g_static_tail[dev->ordinal] : nullptr;
+    if (!tail) return fail("rh_submit_static: GPU %d has no event for its static scratch array", dev->ordinal);
+    // the kernels of the previous call on this GPU (from any rh_device) may still be reading the array
+    RH_HIP(hipStreamWaitEvent(dev->stream, tail, 0));
+    struct RecordTail { hipEvent_t e; hipStream_t s; ~RecordTail() { (void)hipEventRecord(e, s); } } record_tail{tail, dev->stream};
     for (size_t i = 0; i < n; i++) {
         const rh_cmdbuf* cb = list[i];
         if (!cb) continue;
@@ -1972,7 +2012,11 @@ int rh_decoder_run(rh_decoder* d) {
             const uint32_t id = (bd >> 4) & 7u;
             if (id < 4) { S.state = RH_STREAM_FAILED; continue; }
             S.max_block = 1u << (8 + 2 * id);                             // 4: 64 KiB ... 7: 4 MiB
-            if (d->dev && S.max_block > 65536u) return fail("rh_decoder: stream %u uses %u-byte blocks; the device decoder takes 64 KiB blocks (the reference's setting)", si, S.max_block);
+            if (d->dev && S.max_block > 65536u) {
+                // only this stream fails (the message stays in rh_last_error); the others decode as usual
+                (void)fail("rh_decoder: stream %u uses %u-byte blocks; the device decoder takes 64 KiB blocks (the reference's setting)", si, S.max_block);
+                S.state = RH_STREAM_FAILED; continue;
+            }
             S.trailer = (flg >> 4) & 1 ? 4 : 0; S.content_checksum = (flg >> 2) & 1;
             S.at += header; S.header_done = true;
         }

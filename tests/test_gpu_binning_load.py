@@ -236,3 +236,39 @@ def test_pipeline_goes_back_to_the_usual_kernels_when_nothing_is_clipped(oracle)
         assert_same(hs.read_color(), want_clipped, "clipped again")
     finally:
         r.close()
+
+
+def test_headroom_of_a_buffer_created_between_two_passes_reads_zeros(oracle):
+    """A buffer created between two passes takes a recycled allocation and is cleared by work queued on the main stream,
+    behind the tile kernel of the pass before; the next pass's binning, which may run beside that kernel on a stream of
+    its own, must not read the buffer before it has been cleared.  Here the instance buffer grows into a block that held
+    other floats, and the draw covers more instances than were uploaded: the rest must read as zeros (quads at the
+    centre), as wgpu's zero-initialised buffers give."""
+    import ctypes as C
+    from renderer_amd import Renderer, _ffi
+    from renderer_amd.buffer import HEADROOM, next_power_of_two
+    W, H = 1920, 1080
+    heavy = scenes.random_quads_scene(1000, 96, W, H, seed=131)        # a tile kernel long enough to run beside
+    r = Renderer(W, H)
+    try:
+        hs = scenes.HipScene(heavy, renderer=r)
+        hs.draw(); hs.draw()                                           # from now on passes are queued whole
+        uploaded, drawn = 3000, 4000
+        size = next_power_of_two(uploaded * 8 + HEADROOM)
+        assert drawn * 8 <= size and size > next_power_of_two(1000 * 8 + HEADROOM)
+        # a block of exactly that size, full of offsets that would put quads all over the target, goes back to the cache
+        junk = np.random.default_rng(132).uniform(-0.9, 0.9, size // 4).astype(np.float32)
+        h = C.c_void_p()
+        _ffi.check(_ffi.lib().rh_buffer_create(r.device, size, 2, junk.ctypes.data, junk.nbytes, C.byref(h)))
+        hs.draw()
+        _ffi.lib().rh_buffer_release(h)
+        hs.draw()                                                      # its tile kernel is at work ...
+        inst = scenes.random_quads_scene(uploaded, 96, W, H, seed=133)["instances"]
+        r.set_instanced(hs.pipeline, (0, 0), inst)                     # ... while the buffer grows into the junk block
+        r.render(hs.pipeline, hs.clear, hs.viewport, (drawn, 4))
+        r.finish_frame()
+        got = hs.read_color()
+        scene = dict(heavy, instances=np.concatenate([inst, np.zeros((drawn - uploaded, 2), np.float32)]))
+        assert_same(got, scenes.draw_oracle(scene)["color"], "instances beyond the uploaded ones")
+    finally:
+        r.close()

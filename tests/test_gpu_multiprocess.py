@@ -60,3 +60,19 @@ def test_bench_with_two_ranks_prints_one_json_line(tmp_path):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and d["scaling"] == "weak"
     assert d["roofline"]["frac"] > 0 and d["capture"]["value"] > 0 and d["capture"]["frames_per_gpu"] == 8
+
+
+def test_bench_started_plainly_with_gpus_2_starts_two_ranks_itself(tmp_path):
+    """`python bench.py --gpus 2` with no launcher around it: the process starts the two ranks itself (before any GPU
+    call of its own) and relays rank 0's line, which names the ranks that really ran."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["RH_REHEARSE_ON_ONE_GPU"] = "1"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--quads", "50000",
+           "--no-cpu-baseline", "--capture-frames", "0"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=280, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks"] == 2 and d["devices"] == [0, 0] and d["backend"].startswith("gloo")

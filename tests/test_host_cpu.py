@@ -176,3 +176,19 @@ def test_option_numbers_of_the_python_mirror_match_the_header():
     assert len(declared) >= 8
     for name, value in declared.items():
         assert getattr(_ffi, "OPTION_" + name) == value, name
+
+
+def test_bench_refuses_a_gpu_count_the_launcher_did_not_start():
+    """bench.py never scales a value by its --gpus argument: with a launcher's WORLD_SIZE that disagrees it leaves with
+    an error before touching a GPU, and started plainly with --gpus N on a host with fewer GPUs it refuses too."""
+    import subprocess
+    import sys
+    bench = os.path.join(ROOT, "bench.py")
+    env = dict(os.environ, WORLD_SIZE="1")
+    out = subprocess.run([sys.executable, bench, "--gpus", "2"], capture_output=True, text=True, timeout=120, env=env)
+    assert out.returncode == 2 and "must agree" in out.stderr and out.stdout.strip() == ""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "RH_REHEARSE_ON_ONE_GPU")}
+    env["CUDA_VISIBLE_DEVICES"] = ""
+    env["HIP_VISIBLE_DEVICES"] = ""
+    out = subprocess.run([sys.executable, bench, "--gpus", "64"], capture_output=True, text=True, timeout=120, env=env)
+    assert out.returncode == 2 and "GPU(s)" in out.stderr and out.stdout.strip() == ""

@@ -91,3 +91,67 @@ def test_static_submit_rejects_a_pass_that_needs_clipping(oracle):
             r.flush_static()
     finally:
         r.close()
+
+
+def test_static_submit_behind_a_pass_that_has_to_run_again(oracle):
+    """rh_submit leaves its last pass queued without waiting for its pair count; when that pass did not fit the room it
+    was given it has to run again, which allocates.  rh_submit_static must not do that behind the caller's back: it waits
+    for the count and reports an error; after rh_device_synchronize (which runs the pass again) it works."""
+    from renderer_amd import Renderer, RendererError
+    W, H = 640, 360
+    r = Renderer(W, H)
+    try:
+        small = scenes.random_quads_scene(300, 14, W, H, seed=75)
+        hs_small = scenes.HipScene(small, renderer=r)
+        hs_small.draw()                                   # the device's first pass: sizes the room for the next ones
+        big = scenes.random_quads_scene(30_000, 14, W, H, seed=76)
+        hs = scenes.HipScene(big, renderer=r)
+        hs.draw()                                         # queued whole with too little room; nobody has looked yet
+        reruns = None
+        r.render(hs_small.pipeline, hs_small.clear, hs_small.viewport, hs_small.count)
+        with pytest.raises(RendererError, match="has to run again"):
+            r.flush_static()
+        r.synchronize()                                   # runs the big pass again, with room
+        reruns = r.last_pass_stats()["reruns"]
+        assert reruns >= 1
+        assert_same(hs.read_color(), scenes.draw_oracle(big)["color"], "the pass that ran again")
+        r.render(hs_small.pipeline, hs_small.clear, hs_small.viewport, hs_small.count)
+        r.flush_static()
+        assert_same(hs_small.read_color(), scenes.draw_oracle(small)["color"], "static submit afterwards")
+    finally:
+        r.close()
+
+
+def test_static_submits_of_two_devices_on_one_gpu_do_not_overlap(oracle):
+    """Two rh_devices on one GPU share that GPU's static array, each with a stream of its own; a call returns with its
+    kernels queued.  The second device's call waits (on the GPU) for the first one's kernels."""
+    from renderer_amd import Renderer, _ffi
+    import ctypes as C
+    W, H = 640, 360
+    a, b = Renderer(W, H), Renderer(W, H)
+    try:
+        sa = scenes.random_quads_scene(30_000, 14, W, H, seed=77)
+        sb = scenes.random_quads_scene(20_000, 10, W, H, seed=78)
+        ha, hb = scenes.HipScene(sa, renderer=a), scenes.HipScene(sb, renderer=b)
+        ha.draw(); hb.draw()                             # footprint copies made, rooms sized
+        a.synchronize(); b.synchronize()
+        for _ in range(3):
+            for r, hs in ((a, ha), (b, hb)):
+                hs.set_initial(np.full((H, W, 4), 0x33, np.uint8))
+                r.render(hs.pipeline, hs.clear, hs.viewport, hs.count)
+            # both calls return at once: no host synchronisation between them
+            cmds = []
+            for r in (a, b):
+                n = len(r.commands)
+                arr = (C.c_void_p * n)(*[c.value for c in r.commands])
+                cmds.append((r, list(r.commands)))
+                r.commands = []; r.flushes += 1
+                _ffi.check(_ffi.lib().rh_submit_static(r.device, arr, n))
+            a.synchronize(); b.synchronize()
+            for r, cs in cmds:
+                for c in cs:
+                    _ffi.lib().rh_cmdbuf_release(c)
+            assert_same(ha.read_color(), scenes.draw_oracle(sa)["color"], "first device")
+            assert_same(hb.read_color(), scenes.draw_oracle(sb)["color"], "second device")
+    finally:
+        a.close(); b.close()

@@ -77,6 +77,10 @@ enum {
                                          waves on each.  0: never; 1: the finest bands of which they all fit the round;
                                          2 (default): where those are halves, quarters for as many tiles as there is
                                          room left (identical results) */
+    RH_OPTION_EAGER_COUNT = 8,        /* 1 (default): rh_submit, before it returns, looks whether the pair count of its last
+                                         pass has already arrived (without waiting for it); 0: it leaves that to the next
+                                         call, so that the pass is certainly still awaiting its count when rh_submit
+                                         returns (for testing what the next call does with it) */
 };
 
 #define RH_MAX_ATTRIBUTES 8

@@ -25,6 +25,7 @@ OPTION_GENERAL_KERNELS = 4
 OPTION_BINNING_TICKETS = 5
 OPTION_EARLY_BINNING = 6
 OPTION_TAIL_SPLIT = 7
+OPTION_EAGER_COUNT = 8
 COPY_BYTES_PER_ROW_ALIGNMENT = 256
 MAX_COLOR_TARGETS = 4
 

@@ -4,7 +4,7 @@
 #pragma once
 #include <stdint.h>
 
-#define RH_DEVICE_ABI_VERSION 16u
+#define RH_DEVICE_ABI_VERSION 17u
 #define RH_MODULE_MAGIC 0x52484d4fu   // "RHMO"
 
 #define RH_DEV_MAX_ATTRIBUTES 8
@@ -73,12 +73,15 @@ struct rh_draw_params {
 };
 
 // Packed tile rectangle of a cluster: lo = x0 | y0 << 16, hi = x1 | y1 << 16 (inclusive); x0 > x1 marks "touches nothing".
+// Bit 15 of hi: RH_RANGE_GENERAL.
 // Tile columns take ten bits.  Above x0, `lo` carries how many sub-records the cluster's first (bits 10-12) and second
 // triangle (bits 13-15) need when a triangle of the cluster is clipped, 0..4 each: the cluster then makes that many
 // (tile, cluster) pairs per tile instead of one, the pair's value carrying the number of the sub-record in its top three
 // bits (0..3: first triangle, 4..7: second; cluster indices stay below 2^29).  Both zero: the usual cluster, one pair.
 struct rh_tile_range { uint32_t lo, hi; };
 #define RH_RANGE_X0(lo) ((lo) & 0x3ffu)
+#define RH_RANGE_X1(hi) ((hi) & 0x3ffu)
+#define RH_RANGE_GENERAL 0x8000u        /* bit 15 of `hi`: the cluster is not a lean quad (its pairs carry rh::PAIR_GENERAL, bit 28) */
 #define RH_RANGE_SUBS_A(lo) (((lo) >> 10) & 7u)
 #define RH_RANGE_SUBS_B(lo) (((lo) >> 13) & 7u)
 #define RH_RANGE_SUBS(sa, sb) (((sa) << 10) | ((sb) << 13))
@@ -178,7 +181,8 @@ struct rh_attach_dev {
 
 struct rh_tile_args {
     rh_draw_params p;
-    const uint8_t* rec;         // set-up records of the sorted pairs (rh_setup_args::rec)
+    const uint8_t* rec;         // set-up records of the sorted pairs (rh_setup_args::rec): only those of general pairs are there
+    const uint32_t* vals;       // values of the sorted pairs (rh_setup_args::clusters): cluster | rh::PAIR_GENERAL | sub-record << 29
     const uint8_t* ext;
     uint32_t ext_bytes;
     const uint32_t* tile_start; // [tiles]

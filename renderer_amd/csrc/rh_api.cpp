@@ -88,6 +88,7 @@ struct rh_device {
     hipStream_t bin_stream = nullptr;           // created when the first pass takes it (a process has few hardware queues)
     int bin_priority = 0;
     int early_binning = 1;
+    int eager_count = 1;                        // RH_OPTION_EAGER_COUNT
     // The tiles of a pass's last, partly filled round of workgroups are cut into bands of rows (rh_tile_args::split2_first):
     // 0 = never, 1 = halves, quarters or eighths (one kind per pass), 2 = where that kind is halves, quarters for as many of them as there is room left.
     int tail_split = 2;
@@ -442,6 +443,7 @@ int rh_device_set_option(rh_device* dev, int option, int value) {
     if (option == RH_OPTION_BINNING_TICKETS) { dev->binning_tickets = value ? 1 : 0; return 0; }
     if (option == RH_OPTION_TIMING) { dev->timing = value ? 1 : 0; return 0; }
     if (option == RH_OPTION_EARLY_BINNING) { dev->early_binning = value ? 1 : 0; return 0; }
+    if (option == RH_OPTION_EAGER_COUNT) { dev->eager_count = value ? 1 : 0; return 0; }
     if (option == RH_OPTION_TAIL_SPLIT) { if (value < 0 || value > 2) return fail("rh_device_set_option: RH_OPTION_TAIL_SPLIT takes 0, 1 or 2"); dev->tail_split = (int)value; return 0; }
     if (option == RH_OPTION_STRIP_ROW0 || option == RH_OPTION_STRIP_ROW1) {
         if (value < 0) return fail("rh_device_set_option: negative strip row");
@@ -557,9 +559,13 @@ int rh_buffer_unmap(rh_buffer* buf) {
     return 0;
 }
 
+static int poll_maps(rh_device* dev, int wait);
 int rh_poll(rh_device* dev, int wait) {
     if (!dev) return fail("rh_poll: null device");
     if (set_device(dev) || resolve_pending(dev, wait != 0)) return 1;
+    return poll_maps(dev, wait);
+}
+static int poll_maps(rh_device* dev, int wait) {
     size_t done = 0;
     for (; done < dev->pending_maps.size(); done++) {
         rh_buffer* b = dev->pending_maps[done];
@@ -974,8 +980,9 @@ int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer, rh_device::Pa
     p.tpi = pl->topology == RH_TOPOLOGY_TRIANGLE_STRIP ? (c.vertex_count >= 3 ? c.vertex_count - 2 : 0) : c.vertex_count / 3;
     p.cpi = (p.tpi + 1) / 2;
     const uint64_t n_clusters64 = (uint64_t)p.cpi * c.instance_count;
-    // (the top three bits of a (tile, cluster) pair's value number the sub-records of a clipped cluster)
-    if (n_clusters64 >= (1ull << 29)) return fail("render pass: %llu triangle pairs exceed the 29-bit cluster index", (unsigned long long)n_clusters64);
+    // (the top three bits of a (tile, cluster) pair's value number the sub-records of a clipped cluster, the next says
+    // whether the cluster's records come from the set-up launch)
+    if (n_clusters64 >= (1ull << 28)) return fail("render pass: %llu triangle pairs exceed the 28-bit cluster index", (unsigned long long)n_clusters64);
     p.n_clusters = (uint32_t)n_clusters64;
     p.samples = pl->samples; p.bbox_pad = pl->samples > 1 ? 128 : 0;
     const bool empty_scissor = p.sc_x0 >= p.sc_x1 || p.sc_y0 >= p.sc_y1;
@@ -1101,7 +1108,7 @@ int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer, rh_device::Pa
     rh_tile_args ta;
     memset(&ta, 0, sizeof ta);
     ta.p = p; ta.p.n_clusters = n_clusters;
-    ta.rec = ss.rec.as<uint8_t>(); ta.ext = ss.ext.as<uint8_t>(); ta.ext_bytes = ext_bytes;
+    ta.rec = ss.rec.as<uint8_t>(); ta.vals = sorted_vals; ta.ext = ss.ext.as<uint8_t>(); ta.ext_bytes = ext_bytes;
     ta.tile_start = tile_start; ta.tile_end = tile_end;
     ta.pair_total = pair_total; ta.pair_capacity = (uint32_t)total;
     ta.n_att = (uint32_t)c.attachments.size();
@@ -1308,7 +1315,7 @@ int rh_submit(rh_device* dev, rh_cmdbuf* const* list, size_t n) {
         }
         rh_cmdbuf_release(cb);
     }
-    if (!rc) rc = rh_poll(dev, 0);
+    if (!rc) rc = dev->eager_count ? rh_poll(dev, 0) : poll_maps(dev, 0);
     return rc;
 }
 

@@ -115,11 +115,12 @@ extern "C" __global__ __launch_bounds__(256) void rh_bin_emit(const rh_tile_rang
     __shared__ uint32_t big_cluster[WG], big_off[WG];
     if (threadIdx.x == 0) big_n = 0;
     const uint32_t c = blockIdx.x * WG + threadIdx.x;
-    uint32_t tx0 = 1, ty0 = 0, tx1 = 0, ty1 = 0, count = 0, sa = 0, sb = 0, per_tile = 1;
+    uint32_t tx0 = 1, ty0 = 0, tx1 = 0, ty1 = 0, count = 0, sa = 0, sb = 0, per_tile = 1, general = 0;
     if (c < n_clusters) {
         rh_tile_range r = ranges[c];
         sa = RH_RANGE_SUBS_A(r.lo); sb = RH_RANGE_SUBS_B(r.lo); per_tile = sa + sb ? sa + sb : 1u;     // a clipped cluster: a pair per tile and sub-record
-        tx0 = RH_RANGE_X0(r.lo); ty0 = r.lo >> 16; tx1 = r.hi & 0xffffu; ty1 = r.hi >> 16;
+        tx0 = RH_RANGE_X0(r.lo); ty0 = r.lo >> 16; tx1 = RH_RANGE_X1(r.hi); ty1 = r.hi >> 16;
+        general = (r.hi & RH_RANGE_GENERAL) ? (1u << 28) : 0u;           // rh::PAIR_GENERAL: travels in the pairs' values
         if (tx0 <= tx1) count = (tx1 - tx0 + 1) * (ty1 - ty0 + 1) * per_tile;
     }
     uint32_t total;
@@ -132,7 +133,7 @@ extern "C" __global__ __launch_bounds__(256) void rh_bin_emit(const rh_tile_rang
             for (uint32_t tx = tx0; tx <= tx1; tx++)
                 for (uint32_t k = 0; k < per_tile; k++) {
                     const uint32_t sub = k < sa ? k : (sa + sb ? 4u + (k - sa) : 0u);
-                    keys[off] = ty * tiles_x + tx; vals[off] = c | (sub << 29); off++;
+                    keys[off] = ty * tiles_x + tx; vals[off] = c | general | (sub << 29); off++;
                 }
     }
     __syncthreads();
@@ -141,11 +142,11 @@ extern "C" __global__ __launch_bounds__(256) void rh_bin_emit(const rh_tile_rang
         const uint32_t cc = blockIdx.x * WG + big_cluster[b];
         rh_tile_range r = ranges[cc];
         const uint32_t ba = RH_RANGE_SUBS_A(r.lo), bb = RH_RANGE_SUBS_B(r.lo), per = ba + bb ? ba + bb : 1u;
-        const uint32_t x0 = RH_RANGE_X0(r.lo), y0 = r.lo >> 16, x1 = r.hi & 0xffffu, y1 = r.hi >> 16;
-        const uint32_t w = x1 - x0 + 1, cnt = w * (y1 - y0 + 1) * per, o = big_off[b];
+        const uint32_t x0 = RH_RANGE_X0(r.lo), y0 = r.lo >> 16, x1 = RH_RANGE_X1(r.hi), y1 = r.hi >> 16;
+        const uint32_t w = x1 - x0 + 1, cnt = w * (y1 - y0 + 1) * per, o = big_off[b], gen = (r.hi & RH_RANGE_GENERAL) ? (1u << 28) : 0u;
         for (uint32_t i = threadIdx.x; i < cnt; i += WG) {
             const uint32_t t = i / per, k = i - t * per, sub = k < ba ? k : (ba + bb ? 4u + (k - ba) : 0u);
-            keys[o + i] = (y0 + t / w) * tiles_x + (x0 + t % w); vals[o + i] = cc | (sub << 29);
+            keys[o + i] = (y0 + t / w) * tiles_x + (x0 + t % w); vals[o + i] = cc | gen | (sub << 29);
         }
     }
 }

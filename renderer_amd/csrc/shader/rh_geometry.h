@@ -153,8 +153,28 @@ __device__ __noinline__ void clip_triangle(const rh_draw_params& p, uint32_t ins
 // cluster | sub << CLIP_SUB_SHIFT; sub s covers triangles 2*(s mod 4) and 2*(s mod 4) + 1 of the fan of the cluster's
 // first (s < 4) or second triangle (a triangle that needs no clipping is a fan of one).  Only the sub-records whose fan
 // triangles exist get pairs (rh_tile_range carries their numbers).
-constexpr uint32_t CLIP_SUB_SHIFT = 29u, CLIP_CLUSTER_MASK = (1u << CLIP_SUB_SHIFT) - 1u;
+constexpr uint32_t CLIP_SUB_SHIFT = 29u;
 static_assert((CLIP_MAX_VERTS - 2 + 1) / 2 == 4, "four records of two fan triangles per clipped triangle");
+// Bit 28 of a pair's value: the cluster is NOT a lean quad (below): its set-up record is written by the set-up launch and
+// read back by the tile kernel.  Clear: the tile kernel sets the quad up itself, in LDS, when it meets the pair, and no
+// record of it ever goes through memory.  Cluster indices stay below 2^28.
+constexpr uint32_t PAIR_GENERAL = 1u << 28, CLIP_CLUSTER_MASK = PAIR_GENERAL - 1u;
+
+// Edge coefficients below this magnitude (512 px) make f32 edge evaluation exact (edges_inside_f32 in the fragment stage).
+constexpr int32_t F32_EDGE_LIMIT = 1 << 17;
+
+// A *lean quad*: the two triangles (v0, v1, v2), (v1, v3, v2) of a 4-vertex strip whose snapped corners form an
+// axis-aligned rectangle split along v1-v2, every vertex inside the clip volume with w = 1 (affine varyings), sides below
+// 512 px, in a single-sampled pass -- what the reference's quads are.  Its pixel set is the rectangle's exactly and the
+// shared diagonal alone says which triangle a pixel belongs to.  `shape` (out): the rectangle test alone.
+RH_DEVICE bool lean_quad(const rh_draw_params& p, const SnappedVertex& v0, const SnappedVertex& v1, const SnappedVertex& v2, const SnappedVertex& v3, bool& shape) {
+    const bool columns = v0.X == v1.X && v2.X == v3.X && v0.Y == v2.Y && v1.Y == v3.Y;
+    const bool rows = v0.Y == v1.Y && v2.Y == v3.Y && v0.X == v2.X && v1.X == v3.X;
+    const int32_t rminX = min(v0.X, v3.X), rmaxX = max(v0.X, v3.X), rminY = min(v0.Y, v3.Y), rmaxY = max(v0.Y, v3.Y);
+    shape = p.samples == 1u && (columns || rows) && v0.X != v3.X && v0.Y != v3.Y;
+    return shape && v0.ok && v1.ok && v2.ok && v3.ok && rmaxX - rminX < F32_EDGE_LIMIT && rmaxY - rminY < F32_EDGE_LIMIT &&
+           v0.rw == 1.0f && v1.rw == 1.0f && v2.rw == 1.0f && v3.rw == 1.0f;
+}
 
 // Vertex indices of triangle `i` of an instance.  Strip: (i, i+1, i+2) for even i, (i, i+2, i+1) for odd i
 // (Vulkan 1.3 primitive topologies); list: (3i, 3i+1, 3i+2).  The reference selects the topology at

@@ -98,6 +98,9 @@ struct Texture2D {
         if (static_rgba8 || ((format == FORMAT_RGBA_U8 || format == FORMAT_BGRA_U8) && W >= 2 && H >= 2)) {
             // 4-byte texels: the taps of a row are adjacent and the rows are one pitch apart: two 8-byte loads
             uint32_t t00, t10, t01, t11;
+#if defined(RH_EXP) && RH_EXP == 1      /* diagnostic build: no texture read, no filter */
+            if (static_rgba8 && static_poly) return make_float4(a, b, a * b, 0.8f);
+#endif
             if (static_rgba8 && static_poly) {
                 const float Sf = poly_S, invS = poly_invS, WSf = poly_WS;
                 const float xqf = floorf(ibf * invS), phf = __builtin_fmaf(xqf, -Sf, ibf);        // x = xq * S + ph, exact
@@ -105,6 +108,9 @@ struct Texture2D {
                 const uint32_t off = (uint32_t)__builtin_fmaf(jbf, (float)(W << 4), permf * 16.0f);   // exact: below 2^24
                 const uint4 f = *reinterpret_cast<const uint4*>(poly_base + (size_t)layer * (height * (width << 4)) + off);   // the four taps
                 t00 = f.x; t10 = f.y; t01 = f.z; t11 = f.w;
+#if defined(RH_EXP) && RH_EXP == 2      /* diagnostic build: the read, but no filter */
+                return make_float4(__uint_as_float(t00 ^ t10) * a, __uint_as_float(t01 ^ t11) * b, 0.5f, 0.8f);
+#endif
             } else {
                 uint32_t off;
                 if (static_rgba8) off = layer * (height * (width << 2)) + (uint32_t)__builtin_fmaf(jbf, (float)(W << 2), ibf * 4.0f);   // exact: below 2^24

@@ -79,9 +79,6 @@ RH_DEVICE uint32_t hdr_box(uint32_t h) { return (h & 31u) | (((h >> 5) & 31u) <<
 RH_DEVICE uint32_t hdr_flags(uint32_t h) { return (h >> 20) & 63u; }
 RH_DEVICE int hdr_grad(uint32_t h) { return (int)h >> 26; }
 constexpr uint32_t FLAG_PERSP_A = 1u, FLAG_PERSP_B = 2u, FLAG_HAS_A = 4u, FLAG_HAS_B = 8u, FLAG_BIG = 16u, FLAG_RECT = 32u;
-// Edge coefficients below this magnitude (512 px) make f32 edge evaluation exact; see edges_inside_f32.
-constexpr int32_t F32_EDGE_LIMIT = 1 << 17;
-
 } // namespace rh
 
 extern "C" __device__ const rh_module_info_t rh_module_info = {
@@ -116,6 +113,9 @@ RH_DEVICE float blend_factor(uint32_t f, float src_alpha) {
 // BLEND: 0 = factors read at run time, 1 = (One, OneMinusSrcAlpha), 2 = (One, One); the results are identical.
 template <int BLEND>
 RH_DEVICE uint32_t blend(uint32_t dst, float4 s, uint32_t src_factor, uint32_t dst_factor) {
+#if defined(RH_EXP) && RH_EXP == 3          /* diagnostic build: no blend arithmetic */
+    return dst ^ __float_as_uint(s.x + s.y + s.z + s.w);
+#endif
     float df;
     if (BLEND == 1) df = 1.0f - s.w;
     else if (BLEND == 2) df = 1.0f;
@@ -285,7 +285,7 @@ RH_DEVICE void write_records(const PairSetup& s, int ox, int oy, uint32_t* w, ui
         }
     }
     // the extended record: only for clusters whose fragments read it
-    if (bbox != BBOX_EMPTY && (!rect || s.persp_a || s.persp_b)) {
+    if (ext && bbox != BBOX_EMPTY && (!rect || s.persp_a || s.persp_b)) {
 #pragma unroll
         for (int t = 0; t < 2; t++) {
             uint32_t* o = ext + t * EXT_TRI_WORDS;
@@ -294,7 +294,7 @@ RH_DEVICE void write_records(const PairSetup& s, int ox, int oy, uint32_t* w, ui
             o[EOFF_Q] = __float_as_uint(ts[t]->q0); o[EOFF_Q + 1] = __float_as_uint(ts[t]->qx); o[EOFF_Q + 2] = __float_as_uint(ts[t]->qy);
         }
     }
-    if (S > 1 && bbox != BBOX_EMPTY) {
+    if (S > 1 && ext && bbox != BBOX_EMPTY) {
         MsRecord<S>& m = *reinterpret_cast<MsRecord<S>*>(ext + EXT_WORDS);
         if (has_a) store_ms_edges<S>(m, 0, s.ta, ox, oy);
         if (has_b) store_ms_edges<S>(m, 1, s.tb, ox, oy);
@@ -322,6 +322,108 @@ __device__ __noinline__ void setup_clipped(const rh_draw_params& p, uint32_t ins
     }
     if (s.has_a || s.has_b) s.bbox = (uint32_t)s.bx0 | ((uint32_t)s.by0 << 8) | ((uint32_t)s.bx1 << 16) | ((uint32_t)s.by1 << 24);
     write_records<S>(s, ox, oy, w, ext);
+}
+
+// The two triangles (v0, v1, v2), (v1, v3, v2) of a strip quad for the tile at (ox, oy).  A quad whose snapped corners
+// form an axis-aligned rectangle split along v1-v2 is drawn from its exact pixel box and the shared diagonal alone (edge 1
+// of triangle A) when its varyings are affine and its sides short enough for the f32 coverage path (a lean quad,
+// rh_geometry.h).  `known_lean`: the caller knows that it is one (the tile kernel: the binning kernels said so with the
+// same test on the same vertices), so the code of every other case folds away.
+template <int S>
+RH_DEVICE void setup_strip_quad(const rh_draw_params& p, const SnappedVertex& v0, const SnappedVertex& v1, const SnappedVertex& v2, const SnappedVertex& v3,
+                                int ox, int oy, PairSetup& s, bool known_lean) {
+    bool shape = true, lean = true;
+    if (!known_lean) { lean = lean_quad(p, v0, v1, v2, v3, shape); if (S != 1) { shape = false; lean = false; } }
+    s.has_a = setup_triangle(p, v0, v1, v2, ox, oy, s.ta, s.persp_a, s.big, s.bx0, s.by0, s.bx1, s.by1, lean ? 2u : 7u);
+    s.has_b = setup_triangle(p, v1, v3, v2, ox, oy, s.tb, s.persp_b, s.big, s.bx0, s.by0, s.bx1, s.by1, lean ? 0u : 7u);
+    s.rect = shape && s.has_a && s.has_b && !s.big;
+    if (s.has_a || s.has_b) {
+        if (s.rect) {
+            // Exact pixel set of the rectangle under the top-left rule: left and top edges take pixel centres on them,
+            // right and bottom edges do not.  Inside it every pixel belongs to exactly one of the two triangles, decided
+            // by the shared diagonal alone (edge 1 of triangle A).
+            const int32_t rminX = min(v0.X, v3.X), rmaxX = max(v0.X, v3.X), rminY = min(v0.Y, v3.Y), rmaxY = max(v0.Y, v3.Y);
+            const int ex0 = max(max(p.sc_x0, ox), (rminX + 255) >> 8), ex1 = min(min(p.sc_x1 - 1, ox + TILE - 1), (rmaxX - 1) >> 8);
+            const int ey0 = max(max(p.sc_y0, oy), (rminY + 255) >> 8), ey1 = min(min(p.sc_y1 - 1, oy + TILE - 1), (rmaxY - 1) >> 8);
+            if (ex0 <= ex1 && ey0 <= ey1) s.bbox = (uint32_t)(ex0 - ox) | ((uint32_t)(ey0 - oy) << 8) | ((uint32_t)(ex1 - ox) << 16) | ((uint32_t)(ey1 - oy) << 24);
+        } else s.bbox = (uint32_t)s.bx0 | ((uint32_t)s.by0 << 8) | ((uint32_t)s.bx1 << 16) | ((uint32_t)s.by1 << 24);
+    }
+}
+
+// The record of a lean quad (pair value without its flags: the cluster), set up by the tile wave itself: lane = pair,
+// written straight to the pair's place in the LDS staging area `w`; nothing of it goes through memory.  The arithmetic
+// is that of run_vertex / setup_triangle / setup_strip_quad / write_records for such a quad, operation for operation
+// (the set-up launch computes the same record when the device option RH_OPTION_SETUP_LAUNCH sends lean quads to it, and
+// the tests compare the two), with what a lean quad makes constant left out: every vertex is inside the clip volume
+// with w = 1, both triangles have the rectangle's bounding box, nothing is perspective or BIG, and only the shared
+// diagonal's constant is needed.  A quad without pixels in the tile leaves an empty header and nothing else.
+struct LeanVertex { int32_t X, Y; Varyings var; };
+RH_DEVICE LeanVertex run_vertex_lean(const rh_draw_params& p, uint32_t vertex, uint32_t instance) {
+    VertexContext c; c.p = &p; c.vertex_index = vertex; c.instance_index = instance;
+    LeanVertex r;
+    const float4 pos = vertex_main(c, r.var);
+    r.X = snap(__builtin_fmaf(pos.x, p.vp_hw, p.vp_ox)); r.Y = snap(__builtin_fmaf(pos.y, -p.vp_hh, p.vp_oy));
+    return r;
+}
+// Triangle (a, b, c) of a lean quad: its TRI_WORDS dwords of the record to `o`; `diag` (triangle A): the shared diagonal
+// (edge 1) to dg[0..2]; `g`: the largest |d varying / dx| of the triangle.
+RH_DEVICE void lean_triangle(const LeanVertex& a, LeanVertex b, LeanVertex c, int ox, int oy, uint32_t* o, bool diag, uint32_t* dg, float& g) {
+    const int64_t area2 = (int64_t)(b.X - a.X) * (c.Y - a.Y) - (int64_t)(c.X - a.X) * (b.Y - a.Y);
+    if (area2 < 0) { const LeanVertex t = b; b = c; c = t; }
+    if (diag) {
+        const int32_t A_ = b.Y - c.Y, B_ = c.X - b.X;
+        const int64_t C_ = -((int64_t)A_ * b.X + (int64_t)B_ * b.Y);
+        const bool tl_ = (A_ > 0) || (A_ == 0 && B_ > 0);
+        const int64_t Cq_ = (C_ + (tl_ ? 0 : -1)) >> RH_SUBPIXEL_BITS;
+        int32_t T = (int32_t)clamp_i64(Cq_ + (int64_t)A_ * ox + (int64_t)B_ * oy, (int64_t)1 << 30);
+        const int32_t lim = 1 << 24;
+        T = T < -lim ? -lim : (T > lim ? lim : T);
+        dg[0] = __float_as_uint((float)A_); dg[1] = __float_as_uint((float)B_); dg[2] = __float_as_uint((float)T);
+    }
+    o[OFF_XR] = __float_as_uint((float)(a.X - ox * 256)); o[OFF_YR] = __float_as_uint((float)(a.Y - oy * 256));
+    const float k = 1.0f / 256.0f;
+    const float e1x = (float)(b.X - a.X) * k, e1y = (float)(b.Y - a.Y) * k;
+    const float e2x = (float)(c.X - a.X) * k, e2y = (float)(c.Y - a.Y) * k;
+    const float area = __builtin_fmaf(e1x, e2y, -(e2x * e1y));
+    const float inv = 1.0f / area;
+    const float* fa = reinterpret_cast<const float*>(&a.var);
+    const float* fb = reinterpret_cast<const float*>(&b.var);
+    const float* fc = reinterpret_cast<const float*>(&c.var);
+    g = 0.0f;
+#pragma unroll
+    for (int v = 0; v < NV; v++) {
+        const float f0 = fa[v], d1 = fb[v] - f0, d2 = fc[v] - f0;
+        const float dvdx = (__builtin_fmaf(d1, e2y, -(d2 * e1y)) * inv) * k;
+        const float dvdy = (__builtin_fmaf(d2, e1x, -(d1 * e2x)) * inv) * k;
+        o[OFF_V0 + v] = __float_as_uint(f0); o[OFF_DVDX + v] = __float_as_uint(dvdx); o[OFF_DVDY + v] = __float_as_uint(dvdy);
+        g = fmaxf(g, fabsf(dvdx));
+    }
+#pragma unroll
+    for (int i = 2 + 3 * NV; i < TRI_WORDS; i++) o[i] = 0u;
+}
+RH_DEVICE void setup_lean_pair(const rh_draw_params& p, uint32_t cluster, int ox, int oy, uint32_t* w) {
+    const uint32_t instance = cluster / p.cpi, first = (cluster - instance * p.cpi) * 2u;
+    const LeanVertex v0 = run_vertex_lean(p, first, instance), v3 = run_vertex_lean(p, first + 3u, instance);
+    // the bounding box of either triangle is the rectangle's (tri_pixel_bbox, cut to the tile), and the exact pixel set of
+    // the rectangle under the top-left rule (setup_strip_quad)
+    const int32_t minX = min(v0.X, v3.X), maxX = max(v0.X, v3.X), minY = min(v0.Y, v3.Y), maxY = max(v0.Y, v3.Y), pad = p.bbox_pad;
+    const int bx0 = max(max(p.sc_x0, (minX - pad + 255) >> 8), ox), bx1 = min(min(p.sc_x1 - 1, (maxX + pad) >> 8), ox + TILE - 1);
+    const int by0 = max(max(p.sc_y0, (minY - pad + 255) >> 8), oy), by1 = min(min(p.sc_y1 - 1, (maxY + pad) >> 8), oy + TILE - 1);
+    const int ex0 = max(max(p.sc_x0, ox), (minX + 255) >> 8), ex1 = min(min(p.sc_x1 - 1, ox + TILE - 1), (maxX - 1) >> 8);
+    const int ey0 = max(max(p.sc_y0, oy), (minY + 255) >> 8), ey1 = min(min(p.sc_y1 - 1, oy + TILE - 1), (maxY - 1) >> 8);
+    if (bx0 > bx1 || by0 > by1 || ex0 > ex1 || ey0 > ey1) { w[0] = HDR_EMPTY; return; }
+    const uint32_t bbox = (uint32_t)(ex0 - ox) | ((uint32_t)(ey0 - oy) << 8) | ((uint32_t)(ex1 - ox) << 16) | ((uint32_t)(ey1 - oy) << 24);
+    const LeanVertex v1 = run_vertex_lean(p, first + 1u, instance), v2 = run_vertex_lean(p, first + 2u, instance);
+    uint4* const q = reinterpret_cast<uint4*>(w);
+    uint32_t t[TRI_WORDS], dg[3];
+    float g, gb;
+    lean_triangle(v0, v1, v2, ox, oy, t, true, dg, g);
+    q[0] = make_uint4(hdr_pack(bbox, FLAG_HAS_A | FLAG_HAS_B | FLAG_RECT, (int)((__float_as_uint(g * (256.0f * 1.41421356f)) >> 23) & 0xffu) - 127), dg[0], dg[1], dg[2]);
+#pragma unroll
+    for (int i = 0; i < TRI_WORDS / 4; i++) q[HDR_WORDS / 4 + i] = make_uint4(t[4 * i], t[4 * i + 1], t[4 * i + 2], t[4 * i + 3]);
+    lean_triangle(v1, v3, v2, ox, oy, t, false, dg, gb);
+#pragma unroll
+    for (int i = 0; i < TRI_WORDS / 4; i++) q[(HDR_WORDS + TRI_WORDS) / 4 + i] = make_uint4(t[4 * i], t[4 * i + 1], t[4 * i + 2], t[4 * i + 3]);
 }
 
 // Sets up the triangles of pair value `value` (cluster | sub-record << CLIP_SUB_SHIFT) for the tile at (ox, oy) and
@@ -360,33 +462,11 @@ RH_DEVICE void setup_pair(const rh_draw_params& p, uint32_t value, int ox, int o
         }
     }
     PairSetup s;
-    int32_t rminX = 0, rmaxX = 0, rminY = 0, rmaxY = 0;
-    if (has_second && strip) {
-        const SnappedVertex& v3 = b1;
-        // a strip quad whose snapped corners form an axis-aligned rectangle split along v1-v2: with affine varyings and
-        // sides short enough for the f32 coverage path it is drawn from the shared diagonal alone (edge 1 of triangle A)
-        const bool columns = v0.X == v1.X && v2.X == v3.X && v0.Y == v2.Y && v1.Y == v3.Y;
-        const bool rows = v0.Y == v1.Y && v2.Y == v3.Y && v0.X == v2.X && v1.X == v3.X;
-        rminX = min(v0.X, v3.X); rmaxX = max(v0.X, v3.X); rminY = min(v0.Y, v3.Y); rmaxY = max(v0.Y, v3.Y);
-        const bool shape = S == 1 && (columns || rows) && v0.X != v3.X && v0.Y != v3.Y;
-        const bool lean = shape && rmaxX - rminX < F32_EDGE_LIMIT && rmaxY - rminY < F32_EDGE_LIMIT &&
-                          v0.rw == 1.0f && v1.rw == 1.0f && v2.rw == 1.0f && v3.rw == 1.0f;
-        s.has_a = setup_triangle(p, v0, v1, v2, ox, oy, s.ta, s.persp_a, s.big, s.bx0, s.by0, s.bx1, s.by1, lean ? 2u : 7u);
-        s.has_b = setup_triangle(p, v1, v3, v2, ox, oy, s.tb, s.persp_b, s.big, s.bx0, s.by0, s.bx1, s.by1, lean ? 0u : 7u);
-        s.rect = shape && s.has_a && s.has_b && !s.big;
-    } else {
+    if (has_second && strip) setup_strip_quad<S>(p, v0, v1, v2, b1, ox, oy, s, false);
+    else {
         s.has_a = setup_triangle(p, v0, v1, v2, ox, oy, s.ta, s.persp_a, s.big, s.bx0, s.by0, s.bx1, s.by1);
         if (has_second) s.has_b = setup_triangle(p, b0, b1, b2, ox, oy, s.tb, s.persp_b, s.big, s.bx0, s.by0, s.bx1, s.by1);
-    }
-    if (s.has_a || s.has_b) {
-        if (s.rect) {
-            // Exact pixel set of the rectangle under the top-left rule: left and top edges take pixel centres on them,
-            // right and bottom edges do not.  Inside it every pixel belongs to exactly one of the two triangles, decided
-            // by the shared diagonal alone (edge 1 of triangle A).
-            const int ex0 = max(max(p.sc_x0, ox), (rminX + 255) >> 8), ex1 = min(min(p.sc_x1 - 1, ox + TILE - 1), (rmaxX - 1) >> 8);
-            const int ey0 = max(max(p.sc_y0, oy), (rminY + 255) >> 8), ey1 = min(min(p.sc_y1 - 1, oy + TILE - 1), (rmaxY - 1) >> 8);
-            if (ex0 <= ex1 && ey0 <= ey1) s.bbox = (uint32_t)(ex0 - ox) | ((uint32_t)(ey0 - oy) << 8) | ((uint32_t)(ex1 - ox) << 16) | ((uint32_t)(ey1 - oy) << 24);
-        } else s.bbox = (uint32_t)s.bx0 | ((uint32_t)s.by0 << 8) | ((uint32_t)s.bx1 << 16) | ((uint32_t)s.by1 << 24);
+        if (s.has_a || s.has_b) s.bbox = (uint32_t)s.bx0 | ((uint32_t)s.by0 << 8) | ((uint32_t)s.bx1 << 16) | ((uint32_t)s.by1 << 24);
     }
     uint32_t w[REC_WORDS];
     write_records<S>(s, ox, oy, w, ext);
@@ -403,13 +483,20 @@ RH_DEVICE void setup_kernel(const rh_setup_args& a) {
     __shared__ uint4 stage[256 * (REC_WORDS / 4)];
     const uint32_t first = blockIdx.x * 256u, i = first + threadIdx.x;
     if (first >= n) return;
+    uint32_t tile = 0u, value = 0u;
     if (i < n) {
-        const uint32_t tile = a.tiles[i];
+        tile = a.tiles[i]; value = a.clusters[i];
         // the ends of a tile's run of pairs
         if (i == 0u || a.tiles[i - 1u] != tile) a.tile_start[tile] = i;
         if (i == n - 1u || a.tiles[i + 1u] != tile) a.tile_end[tile] = i + 1u;
+    }
+    // Lean quads (pair values without PAIR_GENERAL) are set up by the tile kernel itself: a workgroup all of whose pairs
+    // are lean writes no records at all.  (One with some general pair writes its whole run, the lean ones included:
+    // nobody reads those.)
+    if (!__syncthreads_or(i < n && (value & PAIR_GENERAL) != 0u)) return;
+    if (i < n) {
         const int ox = (int)(tile % a.p.tiles_x) * TILE, oy = (int)(tile / a.p.tiles_x) * TILE;
-        setup_pair<S, CLIP>(a.p, a.clusters[i], ox, oy, &stage[threadIdx.x * (REC_WORDS / 4)], reinterpret_cast<uint32_t*>(a.ext + (size_t)i * a.ext_bytes));
+        setup_pair<S, CLIP>(a.p, value & ~PAIR_GENERAL, ox, oy, &stage[threadIdx.x * (REC_WORDS / 4)], reinterpret_cast<uint32_t*>(a.ext + (size_t)i * a.ext_bytes));
     }
     __syncthreads();
     const uint32_t pieces = min(256u, n - first) * (REC_WORDS / 4);
@@ -606,9 +693,30 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
     const float* const recf = reinterpret_cast<const float*>(lds.rec);
 
     // 2. rounds of records
+    int picked_grad = -1000;                            // the gradient hint the footprint copies were last picked for
+    // (the values of a round's pairs are fetched a round ahead: the set-up below starts with them)
+    uint32_t value_next = (start < end && lane < (int)min((uint32_t)ROUND, end - start)) ? a.vals[start + (uint32_t)lane] : PAIR_GENERAL;
     for (uint32_t base = start; base < end; base += ROUND) {
         const int n = (int)min((uint32_t)ROUND, end - base);
-        stage_records(lds.rec, a.rec, base, n, lane);
+        {
+            // lane = pair of this round.  General pairs bring the record the set-up launch wrote; a lean quad is set up
+            // here and now, straight into the staging area.
+            const uint32_t value = value_next;
+            const uint32_t nb = base + ROUND;
+            value_next = (nb < end && lane < (int)min((uint32_t)ROUND, end - nb)) ? a.vals[nb + (uint32_t)lane] : PAIR_GENERAL;
+            const bool lean = (value & PAIR_GENERAL) == 0u;
+            if (!__any(lean)) stage_records(lds.rec, a.rec, base, n, lane);
+            else {
+                uint32_t* const w = &lds.rec[lane * REC_WORDS];
+                if (lean) setup_lean_pair(p, value & CLIP_CLUSTER_MASK, ox, oy, w);
+                else if (lane < n) {
+                    const uint4* const src = reinterpret_cast<const uint4*>(a.rec + (size_t)(base + (uint32_t)lane) * (REC_WORDS * 4));
+#pragma unroll
+                    for (int i = 0; i < REC_WORDS / 4; i++) reinterpret_cast<uint4*>(w)[i] = src[i];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            }
+        }
         RH_PHASE_MARK(1)
         // lane = record of this round (all wave-parallel)
         const uint32_t hdr = lane < n ? lds.rec[lane * REC_WORDS] : HDR_EMPTY;
@@ -632,6 +740,17 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
             const uint32_t info = (uint32_t)lane | (fl << 6) | ((hdr >> 26) << 12) | ((uint32_t)npx << 18) | (small ? 0x80000000u : 0u);
             box_v = (uint32_t)__builtin_amdgcn_ds_permute(dest << 2, (int)bb);
             info_v = (uint32_t)__builtin_amdgcn_ds_permute(dest << 2, (int)(hit ? info : 0u));
+        }
+        // What the passes of a hit need as wave-uniform numbers is worked out here for all the hits at once, each in the
+        // lane of its hit, and fetched by the scalar side hit by hit (the SIMD issues one instruction of ANY kind per ~2.3
+        // cycles, scalar ones included: what is done once per round for 32 hits is nearly free, what is done per hit is not):
+        //   boxw = x0 | y0 << 8 | width << 16, invw = 1 / width, last = pixels - 1
+        uint32_t boxw_v; float invw_v, last_v;
+        {
+            const uint32_t bw = ((box_v >> 16) & 0xffu) - (box_v & 0xffu) + 1u;
+            boxw_v = (box_v & 0xffffu) | (bw << 16);
+            invw_v = __builtin_amdgcn_rcpf((float)bw);
+            last_v = (float)((info_v >> 18) & 0x7ffu) - 1.0f;
         }
         // A pack = up to PACK_MAX consecutive small hits whose boxes are pairwise disjoint and whose pixels fit
         // the 64 lanes of ONE pass (disjoint boxes cannot touch the same pixel, so their relative order is
@@ -667,12 +786,13 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
         int k = 0;
         while (k < nh) {
             const uint32_t info = __builtin_amdgcn_readlane(info_v, k);
-            // per-lane inputs of the passes of this hit (or pack): record, box, first pixel index, pixel count
+            // per-lane inputs of the passes of this hit (or pack): record, box, first pixel index, last pixel index
             uint32_t flags;
             const float* rf;
-            const float* ef = nullptr;                       // extended record (one hit per pass only)
-            float hx0f, hy0f, wf, idx0_f, limit_f;
-            int npass, grad_log2;
+            float hx0f, hy0f, wf, invw, idx0_f, last_f;
+            int npass;
+            const int grad_log2 = (int)(info << 14) >> 26;           // (a pack: its first member's; a hint only)
+            uint32_t rec_index = info & 0x3fu;
             if (info >> 31) {
                 const uint32_t run = __builtin_amdgcn_readlane(run_v, k);
                 const int c1 = (int)((run >> 10) & 127u), c2 = (int)((run >> 17) & 127u), c3 = (int)(run >> 24);
@@ -680,75 +800,72 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
                 const int slot = (g1 ? 1 : 0) + (g2 ? 1 : 0) + (g3 ? 1 : 0);
                 const int st = g3 ? c3 : (g2 ? c2 : (g1 ? c1 : 0));
                 const int src = (k + slot) << 2;
-                const uint2 m = make_uint2((uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)box_v), (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)info_v));
-                hx0f = (float)(m.x & 0xffu); hy0f = (float)((m.x >> 8) & 0xffu);
-                wf = (float)(int)(((m.x >> 16) & 0xffu) - (m.x & 0xffu) + 1u);
+                const uint2 m = make_uint2((uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)boxw_v), (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)info_v));
+                hx0f = (float)(m.x & 0xffu); hy0f = (float)((m.x >> 8) & 0xffu); wf = (float)((m.x >> 16) & 0xffu);
+                invw = __builtin_amdgcn_rcpf(wf);
                 idx0_f = (float)(lane - st);
-                limit_f = (float)((int)((run >> 3) & 127u) - st);         // lane < total <=> lane - st < total - st
+                last_f = (float)((int)((run >> 3) & 127u) - st - 1);      // the lanes past the pack's pixels shade its last pixel again
                 npass = 1;
                 rf = recf + (int)(m.y & 0x3fu) * REC_WORDS;
                 flags = FLAG_RECT | FLAG_HAS_A | FLAG_HAS_B;
-                grad_log2 = (int)(info << 14) >> 26;                        // (the first member's: a hint only)
                 k += (int)(run & 7u);
             } else {
-                const uint32_t box = __builtin_amdgcn_readlane(box_v, k);
-                const int w = (int)((box >> 16) & 0xffu) - (int)(box & 0xffu) + 1, npix = (int)((info >> 18) & 0x7ffu);
-                hx0f = (float)(box & 0xffu); hy0f = (float)((box >> 8) & 0xffu); wf = (float)w;
+                const uint32_t boxw = __builtin_amdgcn_readlane(boxw_v, k);
+                invw = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(invw_v), k));
+                last_f = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(last_v), k));
+                hx0f = (float)(boxw & 0xffu); hy0f = (float)((boxw >> 8) & 0xffu); wf = (float)(boxw >> 16);
                 idx0_f = lane_f;
-                limit_f = (float)npix;
-                npass = (npix + 63) >> 6;
-                rf = recf + (int)(info & 0x3fu) * REC_WORDS;
+                npass = (int)(((info >> 18) & 0x7ffu) + 63u) >> 6;
+                rf = recf + (int)rec_index * REC_WORDS;
                 flags = (info >> 6) & 0x3fu;
-                grad_log2 = (int)(info << 14) >> 26;
-                if ((flags & (FLAG_RECT | FLAG_PERSP_A | FLAG_PERSP_B)) != FLAG_RECT)
-                    ef = reinterpret_cast<const float*>(a.ext + (size_t)(base + (info & 0x3fu)) * a.ext_bytes);
                 k++;
             }
-            if (TEX == 3) {
+            if (TEX == 3 && grad_log2 != picked_grad) {
                 // the footprint copy of every texture slot for this primitive (uniform; unused slots fold away)
-                const int g = grad_log2;
+                picked_grad = grad_log2;
 #pragma unroll
-                for (int i = 0; i < RH_DEV_MAX_SLOTS; i++) fctx.poly[i].pick(p.slots[i], g);
+                for (int i = 0; i < RH_DEV_MAX_SLOTS; i++) fctx.poly[i].pick(p.slots[i], grad_log2);
             }
-            const float invw = __builtin_amdgcn_rcpf(wf), half_invw = 0.5f * invw;
+            const float half_invw = 0.5f * invw;
             float idx_f = idx0_f;
             if ((flags & (FLAG_RECT | FLAG_PERSP_A | FLAG_PERSP_B)) == FLAG_RECT) {
                 // Axis-aligned rectangle with affine varyings (what the reference's quads are): every pixel of the box is
-                // covered and the shared diagonal alone says by which triangle.  The SIMD issues one instruction of ANY
-                // kind per ~2.3 cycles (scalar ones and branches included), so this loop is kept free of per-pass tests.
+                // covered and the shared diagonal alone says by which triangle.  The loop is kept free of per-pass tests
+                // and of lane masks: a lane past the last pixel shades the last pixel once more -- same inputs, same
+                // result, the same bytes written to the same place.
                 const float4 dh = *reinterpret_cast<const float4*>(rf);                     // header, diagonal A, B, T
                 const float3 dg = make_float3(dh.y, dh.z, dh.w);
-                const float pbase_f = __builtin_fmaf(hy0f, (float)(TILE * 4), hx0f * 4.0f);  // byte offset of the box origin in the tile
                 uint8_t* const px_bytes = reinterpret_cast<uint8_t*>(tile_px);
                 for (int pass = 0; pass < npass; pass++, idx_f += 64.0f) {
+                    const float idc = fminf(idx_f, last_f);
                     // floor((idx + 0.5) / w): the half keeps the quotient at least 1/128 away from an integer
-                    const float row_f = floorf(__builtin_fmaf(idx_f, invw, half_invw));
-                    const float col_f = __builtin_fmaf(-row_f, wf, idx_f);
-                    if (idx_f < limit_f) {
-                        const float lxf = hx0f + col_f, lyf = hy0f + row_f;          // tile-relative pixel, exact small integers
-                        const uint32_t pb = (uint32_t)__builtin_fmaf(row_f, (float)(TILE * 4), __builtin_fmaf(col_f, 4.0f, pbase_f));
-                        // triangle B where the diagonal's edge function is negative: its planes sit TRI_WORDS further on
-                        const uint32_t in_b = __float_as_uint(__builtin_fmaf(dg.x, lxf, __builtin_fmaf(dg.y, lyf, dg.z))) >> 31;
-                        const float* const tp = rf + HDR_WORDS + in_b * (uint32_t)TRI_WORDS;
-                        const float dx = __builtin_fmaf(lxf, 256.0f, -tp[OFF_XR]), dy = __builtin_fmaf(lyf, 256.0f, -tp[OFF_YR]);   // exact
-                        Varyings var; float* vf = reinterpret_cast<float*>(&var);
+                    const float row_f = floorf(__builtin_fmaf(idc, invw, half_invw));
+                    const float col_f = __builtin_fmaf(-row_f, wf, idc);
+                    const float lxf = hx0f + col_f, lyf = hy0f + row_f;          // tile-relative pixel, exact small integers
+                    const uint32_t pb = (uint32_t)__builtin_fmaf(lyf, (float)(TILE * 4), lxf * 4.0f);
+                    // triangle B where the diagonal's edge function is negative: its planes sit TRI_WORDS further on
+                    const uint32_t in_b = __float_as_uint(__builtin_fmaf(dg.x, lxf, __builtin_fmaf(dg.y, lyf, dg.z))) >> 31;
+                    const float* const tp = rf + HDR_WORDS + in_b * (uint32_t)TRI_WORDS;
+                    const float dx = __builtin_fmaf(lxf, 256.0f, -tp[OFF_XR]), dy = __builtin_fmaf(lyf, 256.0f, -tp[OFF_YR]);   // exact
+                    Varyings var; float* vf = reinterpret_cast<float*>(&var);
 #pragma unroll
-                        for (int v = 0; v < NV; v++) vf[v] = __builtin_fmaf(tp[OFF_DVDY + v], dy, __builtin_fmaf(tp[OFF_DVDX + v], dx, tp[OFF_V0 + v]));
-                        Outputs out;
-                        fragment_main(fctx, var, out);
+                    for (int v = 0; v < NV; v++) vf[v] = __builtin_fmaf(tp[OFF_DVDY + v], dy, __builtin_fmaf(tp[OFF_DVDX + v], dx, tp[OFF_V0 + v]));
+                    Outputs out;
+                    fragment_main(fctx, var, out);
 #pragma unroll
-                        for (int t = 0; t < NA; t++) {
-                            blend_pixel<BLEND>(reinterpret_cast<PxT*>(px_bytes + (size_t)t * (TILE_PX * sizeof(PxT)) + (size_t)pb * (sizeof(PxT) / 4)), a.att[t],
-                                               out.color[t < RH_FRAGMENT_OUTPUTS ? t : RH_FRAGMENT_OUTPUTS - 1], a.src_factor, a.dst_factor);
-                        }
+                    for (int t = 0; t < NA; t++) {
+                        blend_pixel<BLEND>(reinterpret_cast<PxT*>(px_bytes + (size_t)t * (TILE_PX * sizeof(PxT)) + (size_t)pb * (sizeof(PxT) / 4)), a.att[t],
+                                           out.color[t < RH_FRAGMENT_OUTPUTS ? t : RH_FRAGMENT_OUTPUTS - 1], a.src_factor, a.dst_factor);
                     }
                 }
                 continue;
             }
+            // (only hits that run alone come here: the extended record of this one)
+            const float* const ef = reinterpret_cast<const float*>(a.ext + (size_t)(base + rec_index) * a.ext_bytes);
             const bool has_a = (flags & FLAG_HAS_A) != 0u, has_b = (flags & FLAG_HAS_B) != 0u;
             const bool any_persp = (flags & (FLAG_PERSP_A | FLAG_PERSP_B)) != 0u;
             for (int pass = 0; pass < npass; pass++, idx_f += 64.0f) {
-                const bool live = idx_f < limit_f;
+                const bool live = idx_f <= last_f;
                 // floor((idx + 0.5) / w): the half keeps the quotient at least 1/128 away from an integer
                 const float row_f = floorf(__builtin_fmaf(idx_f, invw, half_invw));
                 const float col_f = __builtin_fmaf(-row_f, wf, idx_f);
@@ -1015,8 +1132,10 @@ RH_DEVICE void tile_dispatch_wide(const rh_tile_args& a) {
 
 } // namespace rh
 
+// Waves per SIMD the register allocation aims at: what the LDS of a tile workgroup admits anyway (one attachment: 6.5 KB,
+// 24 workgroups per CU; two: 10.5 KB, 15; ...).
 #ifndef RH_TILE_MIN_WAVES
-#define RH_TILE_MIN_WAVES 8        // 64 registers per lane: eight tile waves per SIMD
+#define RH_TILE_MIN_WAVES 6        // 80 registers per lane
 #endif
 extern "C" __global__ __launch_bounds__(256) void rh_setup(rh_setup_args a) { rh::setup_kernel<1>(a); }
 extern "C" __global__ __launch_bounds__(256) void rh_setup_ms2(rh_setup_args a) { rh::setup_kernel<2>(a); }
@@ -1027,9 +1146,9 @@ extern "C" __global__ __launch_bounds__(256) void rh_setup_clip_ms2(rh_setup_arg
 extern "C" __global__ __launch_bounds__(256) void rh_setup_clip_ms4(rh_setup_args a) { rh::setup_kernel<4, true>(a); }
 extern "C" __global__ __launch_bounds__(256) void rh_setup_clip_ms8(rh_setup_args a) { rh::setup_kernel<8, true>(a); }
 extern "C" __global__ __launch_bounds__(RH_TILE_THREADS, RH_TILE_MIN_WAVES) void rh_tile_1(rh_tile_args a) { rh::tile_dispatch<1>(a); }
-extern "C" __global__ __launch_bounds__(RH_TILE_THREADS, RH_TILE_MIN_WAVES) void rh_tile_2(rh_tile_args a) { rh::tile_dispatch<2>(a); }
-extern "C" __global__ __launch_bounds__(RH_TILE_THREADS, RH_TILE_MIN_WAVES) void rh_tile_3(rh_tile_args a) { rh::tile_dispatch<3>(a); }
-extern "C" __global__ __launch_bounds__(RH_TILE_THREADS, RH_TILE_MIN_WAVES) void rh_tile_4(rh_tile_args a) { rh::tile_dispatch<4>(a); }
+extern "C" __global__ __launch_bounds__(RH_TILE_THREADS, 4) void rh_tile_2(rh_tile_args a) { rh::tile_dispatch<2>(a); }
+extern "C" __global__ __launch_bounds__(RH_TILE_THREADS, 3) void rh_tile_3(rh_tile_args a) { rh::tile_dispatch<3>(a); }
+extern "C" __global__ __launch_bounds__(RH_TILE_THREADS, 2) void rh_tile_4(rh_tile_args a) { rh::tile_dispatch<4>(a); }
 extern "C" __global__ __launch_bounds__(RH_TILE_THREADS) void rh_tile_ms2(rh_tile_args a) { rh::tile_kernel_ms<2>(a); }
 extern "C" __global__ __launch_bounds__(RH_TILE_THREADS) void rh_tile_ms4(rh_tile_args a) { rh::tile_kernel_ms<4>(a); }
 extern "C" __global__ __launch_bounds__(RH_TILE_THREADS) void rh_tile_ms8(rh_tile_args a) { rh::tile_kernel_ms<8>(a); }

@@ -32,8 +32,10 @@ __device__ __noinline__ int clipped_bbox(const rh_draw_params& p, uint32_t insta
 // one pair per tile and sub-record, the numbers of sub-records packed above tx0 (see rh_tile_range).  Otherwise such a triangle is left out: the pass has
 // to run again with the clipping kernels.  Either way `wants_clip` is set when a triangle of the cluster crosses a clip
 // plane (the host goes back to the usual kernels when a pipeline's passes have not met one for a while).
+// `lean` (out): the cluster is a lean quad (rh_geometry.h): the tile kernel sets it up itself.
 template <bool CLIP>
-__device__ __forceinline__ uint32_t cluster_tiles(const rh_draw_params& p, uint32_t cluster, uint32_t& tx0, uint32_t& ty0, uint32_t& tx1, uint32_t& ty1, bool& wants_clip) {
+__device__ __forceinline__ uint32_t cluster_tiles(const rh_draw_params& p, uint32_t cluster, uint32_t& tx0, uint32_t& ty0, uint32_t& tx1, uint32_t& ty1, bool& wants_clip, bool& lean) {
+    lean = false;
     const uint32_t instance = cluster / p.cpi, local = cluster - instance * p.cpi;
     int bx0 = 0x7fffffff, by0 = 0x7fffffff, bx1 = -1, by1 = -1;
     const uint32_t tri0 = local * 2u;
@@ -61,6 +63,8 @@ __device__ __forceinline__ uint32_t cluster_tiles(const rh_draw_params& p, uint3
         if (second) {
             const rh::SnappedVertex v3 = rh::run_vertex(p, tri0 + 3u, instance);
             triangle(1, v1, v3, v2, tri0 + 1u, tri0 + 3u, tri0 + 2u);
+            bool shape;
+            lean = rh::lean_quad(p, v0, v1, v2, v3, shape);
         }
     } else {
         for (uint32_t k = 0; k < (second ? 2u : 1u); k++) {
@@ -103,9 +107,9 @@ __device__ __forceinline__ void bin_count(const rh_bin_count_args& a) {
     uint32_t count = 0;
     if (cluster < p.n_clusters) {
         rh_tile_range r; uint32_t tx0, ty0, tx1, ty1;
-        bool wants_clip = false;
-        count = cluster_tiles<CLIP>(p, cluster, tx0, ty0, tx1, ty1, wants_clip);
-        r.lo = tx0 | (ty0 << 16); r.hi = tx1 | (ty1 << 16);
+        bool wants_clip = false, lean = false;
+        count = cluster_tiles<CLIP>(p, cluster, tx0, ty0, tx1, ty1, wants_clip, lean);
+        r.lo = tx0 | (ty0 << 16); r.hi = tx1 | (ty1 << 16) | (lean ? 0u : RH_RANGE_GENERAL);
         a.ranges[cluster] = r;
         if (wants_clip) *a.wants_clip = 1u;
     }
@@ -129,7 +133,7 @@ constexpr uint32_t HUGE_SLOTS = 8u;
 __device__ __forceinline__ void write_cluster_pairs(const rh_bin_pairs_args& a, uint32_t (*digits)[256], uint32_t lo, uint32_t hi, uint32_t cluster,
                                                     unsigned long long o, uint32_t t, uint32_t threads) {
     const uint32_t sa = RH_RANGE_SUBS_A(lo), sb = RH_RANGE_SUBS_B(lo), per_tile = sa + sb ? sa + sb : 1u;
-    const uint32_t x0 = RH_RANGE_X0(lo), y0 = lo >> 16, x1 = hi & 0xffffu, y1 = hi >> 16;
+    const uint32_t x0 = RH_RANGE_X0(lo), y0 = lo >> 16, x1 = RH_RANGE_X1(hi), y1 = hi >> 16;
     const uint32_t w = x1 - x0 + 1u, n = w * (y1 - y0 + 1u) * per_tile;
     for (uint32_t i = t; i < n; i += threads) {
         if (o + i >= a.capacity) break;
@@ -169,12 +173,14 @@ __device__ __forceinline__ void bin_pairs(const rh_bin_pairs_args& a) {
     const uint32_t part = a.ticketed ? s_part : blockIdx.x, n_parts = (p.n_clusters + PART - 1u) / PART;
     if (part >= n_parts) return;
     const uint32_t cluster0 = part * PART + threadIdx.x * PER;
-    uint32_t tx0[PER], ty0[PER], tx1[PER], ty1[PER], cnt[PER], count = 0u;
+    uint32_t tx0[PER], ty0[PER], tx1[PER], ty1[PER], cnt[PER], value[PER], count = 0u;
     bool wants_clip = false;
 #pragma unroll
     for (uint32_t j = 0; j < PER; j++) {
         tx0[j] = 1u; ty0[j] = 0u; tx1[j] = 0u; ty1[j] = 0u; cnt[j] = 0u;
-        if (cluster0 + j < p.n_clusters) cnt[j] = cluster_tiles<CLIP>(p, cluster0 + j, tx0[j], ty0[j], tx1[j], ty1[j], wants_clip);
+        bool lean = false;
+        if (cluster0 + j < p.n_clusters) cnt[j] = cluster_tiles<CLIP>(p, cluster0 + j, tx0[j], ty0[j], tx1[j], ty1[j], wants_clip, lean);
+        value[j] = (cluster0 + j) | (lean ? 0u : rh::PAIR_GENERAL);     // what the cluster's pairs carry
         count += cnt[j];
     }
     if (wants_clip) s_wants_clip = 1u;
@@ -246,7 +252,7 @@ __device__ __forceinline__ void bin_pairs(const rh_bin_pairs_args& a) {
                         if (off >= a.capacity) continue;
                         const uint32_t tile = ty * p.tiles_x + tx;
                         const uint32_t sub = k < sa ? k : (sa + sb ? 4u + (k - sa) : 0u);
-                        a.keys[off] = tile; a.vals[off] = (cluster0 + j) | (sub << rh::CLIP_SUB_SHIFT);
+                        a.keys[off] = tile; a.vals[off] = value[j] | (sub << rh::CLIP_SUB_SHIFT);
                         for (uint32_t k = 0; k < passes; k++) atomicAdd(&digits[k][(tile >> (8u * k)) & 0xffu], 1u);
                     }
         else off += cnt[j];
@@ -254,12 +260,12 @@ __device__ __forceinline__ void bin_pairs(const rh_bin_pairs_args& a) {
         bool queued = false;
         if (huge) {
             const uint32_t slot = atomicAdd(&s_huge_n, 1u);
-            if (slot < HUGE_SLOTS) { s_huge[slot] = make_uint4(tx0[j] | (ty0[j] << 16), tx1[j] | (ty1[j] << 16), cluster0 + j, 0u); s_huge_off[slot] = first; queued = true; }
+            if (slot < HUGE_SLOTS) { s_huge[slot] = make_uint4(tx0[j] | (ty0[j] << 16), tx1[j] | (ty1[j] << 16), value[j], 0u); s_huge_off[slot] = first; queued = true; }
         }
         // clusters with more than 32 pairs are written by the whole wave, one after the other
         for (unsigned long long todo = __ballot(big && !queued); todo; todo &= todo - 1ull) {
             const int src = __builtin_ctzll(todo);
-            const uint32_t lo = __shfl(tx0[j] | (ty0[j] << 16), src), hi = __shfl(tx1[j] | (ty1[j] << 16), src), cc = __shfl(cluster0 + j, src);
+            const uint32_t lo = __shfl(tx0[j] | (ty0[j] << 16), src), hi = __shfl(tx1[j] | (ty1[j] << 16), src), cc = __shfl(value[j], src);
             const unsigned long long o = __shfl(first, src);
             write_cluster_pairs(a, digits, lo, hi, cc, o, lane, 64u);
         }

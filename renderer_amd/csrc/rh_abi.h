@@ -4,7 +4,7 @@
 #pragma once
 #include <stdint.h>
 
-#define RH_DEVICE_ABI_VERSION 17u
+#define RH_DEVICE_ABI_VERSION 18u
 #define RH_MODULE_MAGIC 0x52484d4fu   // "RHMO"
 
 #define RH_DEV_MAX_ATTRIBUTES 8
@@ -33,6 +33,7 @@ struct rh_module_info_t {
     uint32_t vertex_tag;     // hash of the vertex function's source name: ties a fragment object to its vertex object
     uint32_t rec_bytes;      // fragment objects: bytes of one set-up record (depends on the number of varyings)
     uint32_t ext_bytes;      // fragment objects: bytes of one extended record of a single-sampled pass
+    uint32_t poly_item_bytes;   // fragment objects: the form of footprint copies its bilinear body reads (rh_slot_dev::poly): 16 or 32
 };
 
 struct rh_slot_dev {
@@ -43,8 +44,14 @@ struct rh_slot_dev {
     uint32_t size_bytes;     // buffers: capacity in bytes (whole buffer is bound, reference src/instanced.rs:18);
                              // textures with `poly`: bytes of one footprint copy
     // Textures: null, or RH_POLY_COPIES copies of the texture made for bilinear sampling.  An item of a copy is the
-    // whole 2x2 footprint of a texel, 16 bytes: t(x, y), t(x+1, y), t(x, y+1), t(x+1, y+1) (clamped to the layer), so a
-    // fragment fetches its four taps with ONE load.  Copy k regroups the items of every row by their phase modulo
+    // whole 2x2 footprint of a texel: t(x, y), t(x+1, y), t(x, y+1), t(x+1, y+1) (clamped to the layer), so a fragment
+    // fetches its four taps at ONE address.  Two forms (rh_module_info_t::poly_item_bytes):
+    //   16 bytes: the four texels as they are;
+    //   32 bytes: per channel c two dwords of f16 pairs, { t(x,y).c | (t(x+1,y).c - t(x,y).c) << 16 } and the same for
+    //     the row below: 8-bit values and their differences are exact in f16, and an f32 fma that reads f16 operands
+    //     (v_fma_mix_f32) does a horizontal lerp fma(a, right - left, left) in one instruction where the byte form takes
+    //     two conversions, a subtraction and the fma -- the same f32 result, bit for bit.
+    // Copy k regroups the items of every row by their phase modulo
     // S = 2^k: item x sits at column (x mod S) * (width / S) + x / S.  A minified draw samples texels S apart; in the
     // copy for its S they are neighbours, so the lanes of a wave share cache lines instead of fetching one line per
     // fragment (a CU fills its L1 at 64 B per clock: at one 128-byte line per fragment that is the whole frame time).

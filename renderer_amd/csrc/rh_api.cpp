@@ -161,6 +161,7 @@ struct rh_texture {
     // phase-regrouped copies for minified sampling (rh_slot_dev::poly): made when a pass first samples the texture with
     // the specialised bilinear body, and again whenever the texels may have changed since
     void* poly = nullptr;
+    uint32_t poly_item_bytes = 0;  // the form of the copies `poly` holds (rh_module_info_t::poly_item_bytes); 0: none yet
     bool poly_valid = false;
     bool poly_always = false;      // the texels can change behind the library's back (render target, device pointer handed out)
 };
@@ -655,7 +656,7 @@ void rh_texture_release(rh_texture* tex) {
     rh_device* dev = tex->dev;
     (void)hipSetDevice(dev->ordinal);
     device_free(dev, tex->bytes, tex->dptr);
-    if (tex->poly) device_free(dev, tex->bytes * 4 * RH_POLY_COPIES, tex->poly);
+    if (tex->poly) device_free(dev, tex->bytes / 4 * tex->poly_item_bytes * RH_POLY_COPIES, tex->poly);
     delete tex;
     device_release(dev);
 }
@@ -1141,22 +1142,32 @@ int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer, rh_device::Pa
         if (all_rgba8 && !(any_linear && any_nearest)) tex_class = any_nearest ? 2 : 1;
         // The specialised bilinear body can read its textures through footprint copies regrouped by phase
         // (rh_slot_dev::poly): made here, on the pass's stream, when the texels may have changed since they were made.
-        // (Item offsets are computed in f32: 16 bytes a texel, exact up to 2^20 texels.)
-        bool all_poly = blend_class && tex_class == 1 && !dev->general_kernels && pl->samples == 1 && total > 0;
+        // (Item offsets are computed in f32, exact below 2^24 bytes: 2^20 texels of 16-byte items, 2^19 of 32-byte ones.)
+        const uint32_t item_bytes = pl->fs->info.poly_item_bytes;
+        const size_t poly_max_bytes = item_bytes == 32u ? ((size_t)2 << 20) : ((size_t)4 << 20);
+        bool all_poly = blend_class && tex_class == 1 && !dev->general_kernels && pl->samples == 1 && total > 0 && (item_bytes == 16u || item_bytes == 32u);
         for (const SlotRef& sl : pl->slots)
-            if (sl.kind == RH_SLOT_TEXTURE && (sl.tex->width % 32u != 0 || sl.tex->bytes > ((size_t)4 << 20) || (no_alloc && !sl.tex->poly))) all_poly = false;
+            if (sl.kind == RH_SLOT_TEXTURE && (sl.tex->width % 32u != 0 || sl.tex->bytes > poly_max_bytes ||
+                                               (no_alloc && !(sl.tex->poly && sl.tex->poly_item_bytes == item_bytes)))) all_poly = false;
         if (all_poly) {
             for (size_t i = 0; i < pl->slots.size(); i++) {
                 rh_texture* t = pl->slots[i].tex;
                 if (!t || pl->slots[i].kind != RH_SLOT_TEXTURE) continue;
-                if (!t->poly) { if (device_alloc(dev, t->bytes * 4 * RH_POLY_COPIES, &t->poly)) return 1; t->poly_valid = false; }     // (no_alloc: every copy exists, see all_poly)
+                if (t->poly && t->poly_item_bytes != item_bytes) {
+                    // (copies made for a code object that reads the other form: freed behind everything queued that reads them)
+                    device_free(dev, t->bytes / 4 * t->poly_item_bytes * RH_POLY_COPIES, t->poly); t->poly = nullptr;
+                }
+                if (!t->poly) {         // (no_alloc: every copy exists, see all_poly)
+                    if (device_alloc(dev, t->bytes / 4 * item_bytes * RH_POLY_COPIES, &t->poly)) return 1;
+                    t->poly_item_bytes = item_bytes; t->poly_valid = false;
+                }
                 if (!t->poly_valid || t->poly_always) {
-                    rhk::polyphase_build(t->dptr, t->poly, t->width, t->height, t->layers, sm);
+                    rhk::polyphase_build(t->dptr, t->poly, t->width, t->height, t->layers, item_bytes, sm);
                     RH_HIP(hipGetLastError());
                     t->poly_valid = true;
                 }
                 ta.p.slots[i].poly = t->poly;
-                ta.p.slots[i].size_bytes = (uint32_t)(t->bytes * 4);
+                ta.p.slots[i].size_bytes = (uint32_t)(t->bytes / 4 * item_bytes);
             }
             tex_class = 3;
         }

@@ -41,7 +41,7 @@ int sort_passes_chained(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, ui
 uint32_t sort_pass_resident_parts(uint32_t compute_units);
 
 // Fills the RH_POLY_COPIES footprint copies of an RGBA8 texture (dst: RH_POLY_COPIES * width * height * layers items of 16 bytes).
-void polyphase_build(const void* src, void* dst, uint32_t width, uint32_t height, uint32_t layers, hipStream_t s);
+void polyphase_build(const void* src, void* dst, uint32_t width, uint32_t height, uint32_t layers, uint32_t item_bytes, hipStream_t s);
 
 void copy_texture_to_buffer(const uint8_t* tex, uint32_t tex_pitch_bytes, uint32_t ox, uint32_t oy, uint32_t bpt, uint32_t w, uint32_t h,
                             uint8_t* dst, uint32_t dst_pitch, hipStream_t s);

@@ -462,6 +462,33 @@ extern "C" __global__ __launch_bounds__(256) void rh_polyphase_build(const uint3
     }
 }
 
+// The same with 32-byte items: per channel { t(x,y) | (t(x+1,y) - t(x,y)) << 16 } and the same for the row below, as f16
+// pairs (exact: 8-bit values and their differences); see rh_slot_dev::poly.
+extern "C" __global__ __launch_bounds__(256) void rh_polyphase_build_h(const uint32_t* src, uint4* dst, uint32_t width, uint32_t height, uint32_t layers) {
+    const size_t texels = (size_t)width * height * layers;
+    const size_t i = (size_t)blockIdx.x * WG + threadIdx.x;
+    if (i >= texels) return;
+    const uint32_t x = (uint32_t)(i % width);
+    const size_t row = i / width;
+    const uint32_t y = (uint32_t)(row % height);
+    const size_t dx = x + 1 < width ? 1 : 0, dy = y + 1 < height ? width : 0;
+    const uint32_t t00 = src[i], t10 = src[i + dx], t01 = src[i + dy], t11 = src[i + dy + dx];
+    auto pair = [](uint32_t left, uint32_t right, int c) -> uint32_t {
+        const int l = (int)((left >> (8 * c)) & 0xffu), r = (int)((right >> (8 * c)) & 0xffu);
+        const _Float16 lo = (_Float16)(float)l, hi = (_Float16)(float)(r - l);
+        return (uint32_t)__builtin_bit_cast(unsigned short, lo) | ((uint32_t)__builtin_bit_cast(unsigned short, hi) << 16);
+    };
+    const uint4 v0 = make_uint4(pair(t00, t10, 0), pair(t01, t11, 0), pair(t00, t10, 1), pair(t01, t11, 1));
+    const uint4 v1 = make_uint4(pair(t00, t10, 2), pair(t01, t11, 2), pair(t00, t10, 3), pair(t01, t11, 3));
+    const size_t row_base = row * width;
+#pragma unroll
+    for (uint32_t k = 0; k < RH_POLY_COPIES; k++) {
+        const uint32_t S = 1u << k;
+        const size_t at = 2u * (k * texels + row_base + (x & (S - 1u)) * (width >> k) + (x >> k));
+        dst[at] = v0; dst[at + 1] = v1;
+    }
+}
+
 // ---- clearing the state area of a pass ------------------------------------------------------------------------------------
 // (one launch of a few microseconds; the runtime's fill is two launches for a size that is not a multiple of its unit)
 extern "C" __global__ __launch_bounds__(256) void rh_clear(uint4* p, uint32_t n16) {
@@ -555,10 +582,11 @@ void clear(void* p, size_t bytes, hipStream_t s) {          // bytes: a multiple
     if (n16) hipLaunchKernelGGL(rh_clear, dim3(div_up(n16, WG)), dim3(WG), 0, s, (uint4*)p, n16);
 }
 
-void polyphase_build(const void* src, void* dst, uint32_t width, uint32_t height, uint32_t layers, hipStream_t s) {
+void polyphase_build(const void* src, void* dst, uint32_t width, uint32_t height, uint32_t layers, uint32_t item_bytes, hipStream_t s) {
     const size_t texels = (size_t)width * height * layers;
     if (texels == 0) return;
-    hipLaunchKernelGGL(rh_polyphase_build, dim3(div_up(texels, WG)), dim3(WG), 0, s, (const uint32_t*)src, (uint4*)dst, width, height, layers);
+    if (item_bytes == 32u) hipLaunchKernelGGL(rh_polyphase_build_h, dim3(div_up(texels, WG)), dim3(WG), 0, s, (const uint32_t*)src, (uint4*)dst, width, height, layers);
+    else hipLaunchKernelGGL(rh_polyphase_build, dim3(div_up(texels, WG)), dim3(WG), 0, s, (const uint32_t*)src, (uint4*)dst, width, height, layers);
 }
 
 void copy_texture_to_buffer(const uint8_t* tex, uint32_t tex_pitch_bytes, uint32_t ox, uint32_t oy, uint32_t bpt, uint32_t w, uint32_t h,

@@ -33,6 +33,15 @@ typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));   // 
 
 RH_DEVICE v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 
+// The form of footprint copies the bilinear body reads (rh_slot_dev::poly): 32 = f16 pairs read by v_fma_mix_f32, 16 = the
+// texels as bytes.  Identical results; the code object tells the host which one to build (rh_module_info_t).
+#ifndef RH_POLY_ITEM_BYTES
+#define RH_POLY_ITEM_BYTES 32
+#endif
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+// fma(a, hi half, lo half) of a dword holding two f16: one v_fma_mix_f32
+RH_DEVICE float lerp_h2(float a, uint32_t w) { const h2 h = __builtin_bit_cast(h2, w); return __builtin_fmaf(a, (float)h.y, (float)h.x); }
+
 // Byte k of a dword as f32 (exact).  Written as the instruction itself: left to the compiler, a difference of two
 // converted bytes becomes an integer subtraction plus a conversion, two instructions outside the f32 add/mul/fma
 // class.  A SIMD issues one instruction of that class beside one of any other kind (from two different waves), so the
@@ -105,9 +114,20 @@ struct Texture2D {
                 const float Sf = poly_S, invS = poly_invS, WSf = poly_WS;
                 const float xqf = floorf(ibf * invS), phf = __builtin_fmaf(xqf, -Sf, ibf);        // x = xq * S + ph, exact
                 const float permf = __builtin_fmaf(phf, WSf, xqf);
+#if RH_POLY_ITEM_BYTES == 32
+                const uint32_t off = (uint32_t)__builtin_fmaf(jbf, (float)(W << 5), permf * 32.0f);   // exact: below 2^24
+                const uint4* const item = reinterpret_cast<const uint4*>(poly_base + (size_t)layer * (height * (width << 5)) + off);
+                const uint4 f0 = item[0], f1 = item[1];                  // channels 0, 1 and 2, 3: { left | right - left } of the upper, of the lower row
+#define RH_LERP_H2(ch, UP, LO) { const float top = lerp_h2(a, UP), bot = lerp_h2(a, LO); \
+                                 r.ch = __builtin_fmaf(b, bot, __builtin_fmaf(-b, top, top)) * scale; }
+                RH_LERP_H2(x, f0.x, f0.y) RH_LERP_H2(y, f0.z, f0.w) RH_LERP_H2(z, f1.x, f1.y) RH_LERP_H2(w, f1.z, f1.w)
+#undef RH_LERP_H2
+                return r;
+#else
                 const uint32_t off = (uint32_t)__builtin_fmaf(jbf, (float)(W << 4), permf * 16.0f);   // exact: below 2^24
                 const uint4 f = *reinterpret_cast<const uint4*>(poly_base + (size_t)layer * (height * (width << 4)) + off);   // the four taps
                 t00 = f.x; t10 = f.y; t01 = f.z; t11 = f.w;
+#endif
 #if defined(RH_EXP) && RH_EXP == 2      /* diagnostic build: the read, but no filter */
                 return make_float4(__uint_as_float(t00 ^ t10) * a, __uint_as_float(t01 ^ t11) * b, 0.5f, 0.8f);
 #endif

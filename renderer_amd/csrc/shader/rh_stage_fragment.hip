@@ -83,7 +83,7 @@ constexpr uint32_t FLAG_PERSP_A = 1u, FLAG_PERSP_B = 2u, FLAG_HAS_A = 4u, FLAG_H
 
 extern "C" __device__ const rh_module_info_t rh_module_info = {
     RH_MODULE_MAGIC, RH_DEVICE_ABI_VERSION, RH_MODULE_STAGE_FRAGMENT, (uint32_t)rh::N_VARYINGS, (uint32_t)RH_FRAGMENT_OUTPUTS,
-    rh::fnv1a(RH_VERTEX_TAG), (uint32_t)(rh::REC_WORDS * 4), (uint32_t)(rh::EXT_WORDS * 4)
+    rh::fnv1a(RH_VERTEX_TAG), (uint32_t)(rh::REC_WORDS * 4), (uint32_t)(rh::EXT_WORDS * 4), (uint32_t)RH_POLY_ITEM_BYTES
 };
 
 // Diagnostic builds (-DRH_PHASE_TIMING, tools/phase_timing.sh): a few sample tiles print how many cycles their wave

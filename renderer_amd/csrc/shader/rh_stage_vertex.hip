@@ -9,7 +9,7 @@
 
 extern "C" __device__ const rh_module_info_t rh_module_info = {
     RH_MODULE_MAGIC, RH_DEVICE_ABI_VERSION, RH_MODULE_STAGE_VERTEX, (uint32_t)rh::N_VARYINGS, 0u,
-    rh::fnv1a(RH_VERTEX_TAG), 0u, 0u
+    rh::fnv1a(RH_VERTEX_TAG), 0u, 0u, 0u
 };
 
 namespace {

@@ -729,15 +729,21 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
         const unsigned long long mask = __ballot(hit);
         const int nh = __popcll(mask);
         if (nh == 0) continue;
+#if defined(RH_EXP) && RH_EXP == 5          /* diagnostic build: records staged, no hit is shaded */
+        if (nh < 1000) continue;
+#endif
         // Small axis-aligned quads may share one pass (see below); anything else runs alone, 64 pixels per pass.
-        const bool small = (fl & (FLAG_RECT | FLAG_PERSP_A | FLAG_PERSP_B)) == FLAG_RECT && npx <= 64;
+        const bool lean_hit = (fl & (FLAG_RECT | FLAG_PERSP_A | FLAG_PERSP_B)) == FLAG_RECT;
+        const bool small = lean_hit && npx <= 64;
         // Compact the hits, in submission order, into the first nh lanes (a lane permutation, no memory):
-        //   box = the box, info = record of the round | flags << 6 | gradient hint (6 bits) << 12 | pixels << 18 | small << 31
+        //   box = the box, info = record of the round | flags << 6 | gradient hint (6 bits) << 12 | pixels << 18 |
+        //   lean << 29 | (gradient hint differs from the hit's before: added below) << 30 | small << 31
+        constexpr uint32_t INFO_LEAN = 1u << 29, INFO_REPICK = 1u << 30, INFO_SMALL = 1u << 31;
         uint32_t box_v, info_v;
         {
             const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
             const int dest = hit ? below : nh + lane - below;
-            const uint32_t info = (uint32_t)lane | (fl << 6) | ((hdr >> 26) << 12) | ((uint32_t)npx << 18) | (small ? 0x80000000u : 0u);
+            const uint32_t info = (uint32_t)lane | (fl << 6) | ((hdr >> 26) << 12) | ((uint32_t)npx << 18) | (lean_hit ? INFO_LEAN : 0u) | (small ? INFO_SMALL : 0u);
             box_v = (uint32_t)__builtin_amdgcn_ds_permute(dest << 2, (int)bb);
             info_v = (uint32_t)__builtin_amdgcn_ds_permute(dest << 2, (int)(hit ? info : 0u));
         }
@@ -751,11 +757,19 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
             boxw_v = (box_v & 0xffffu) | (bw << 16);
             invw_v = __builtin_amdgcn_rcpf((float)bw);
             last_v = (float)((info_v >> 18) & 0x7ffu) - 1.0f;
+            if (TEX == 3) {
+                // (the footprint copies are picked again only where the gradient hint changes from one hit to the next)
+                const uint32_t before = (uint32_t)__builtin_amdgcn_ds_bpermute(((lane - 1) & 63) << 2, (int)info_v);
+                const int mine = (int)(info_v << 14) >> 26, prev = lane == 0 ? picked_grad : (int)(before << 14) >> 26;
+                if (mine != prev) info_v |= INFO_REPICK;
+                picked_grad = (int)(__builtin_amdgcn_readlane(info_v, nh - 1) << 14) >> 26;        // what the round leaves picked
+            }
         }
         // A pack = up to PACK_MAX consecutive small hits whose boxes are pairwise disjoint and whose pixels fit
         // the 64 lanes of ONE pass (disjoint boxes cannot touch the same pixel, so their relative order is
         // immaterial).  Every lane works out the pack that would start at its hit:
         //   run = length | pixels << 3 | lane at which member 1, 2, 3 starts << 10, 17, 24 (127 = no such member)
+        // (members behind the first share its gradient hint: their bit 30 is clear)
         uint32_t run_v;
         {
             const uint32_t n0 = (info_v >> 18) & 0x7ffu;
@@ -771,10 +785,11 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
                     return (p & 0xffu) > ((q >> 16) & 0xffu) || ((p >> 16) & 0xffu) < (q & 0xffu) ||
                            ((p >> 8) & 0xffu) > (q >> 24) || (p >> 24) < ((q >> 8) & 0xffu);
                 };
+                auto joins = [](uint32_t inf) { return (inf & (INFO_SMALL | INFO_REPICK)) == INFO_SMALL; };
                 const uint32_t n1 = (m1.y >> 18) & 0x7ffu, n2 = (m2.y >> 18) & 0x7ffu, n3 = (m3.y >> 18) & 0x7ffu;
-                const bool ok1 = (info_v >> 31) != 0u && lane + 1 < nh && (m1.y >> 31) != 0u && n0 + n1 <= 64u && apart(box_v, m1.x);
-                const bool ok2 = ok1 && lane + 2 < nh && (m2.y >> 31) != 0u && n0 + n1 + n2 <= 64u && apart(box_v, m2.x) && apart(m1.x, m2.x);
-                const bool ok3 = ok2 && lane + 3 < nh && (m3.y >> 31) != 0u && n0 + n1 + n2 + n3 <= 64u &&
+                const bool ok1 = (info_v >> 31) != 0u && lane + 1 < nh && joins(m1.y) && n0 + n1 <= 64u && apart(box_v, m1.x);
+                const bool ok2 = ok1 && lane + 2 < nh && joins(m2.y) && n0 + n1 + n2 <= 64u && apart(box_v, m2.x) && apart(m1.x, m2.x);
+                const bool ok3 = ok2 && lane + 3 < nh && joins(m3.y) && n0 + n1 + n2 + n3 <= 64u &&
                                  apart(box_v, m3.x) && apart(m1.x, m3.x) && apart(m2.x, m3.x);
                 len = 1u + (ok1 ? 1u : 0u) + (ok2 ? 1u : 0u) + (ok3 ? 1u : 0u);
                 c1 = ok1 ? n0 : 127u; c2 = ok2 ? n0 + n1 : 127u; c3 = ok3 ? n0 + n1 + n2 : 127u;
@@ -782,18 +797,55 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
             }
             run_v = len | (total << 3) | (c1 << 10) | (c2 << 17) | (c3 << 24);
         }
+        // The passes of an axis-aligned rectangle with affine varyings (what the reference's quads are): every pixel of
+        // the box is covered and the shared diagonal alone says by which triangle.  The loop is kept free of per-pass
+        // tests and of lane masks: a lane past the last pixel shades the last pixel once more -- same inputs, same result,
+        // the same bytes written to the same place.  The arguments are wave-uniform for a hit that runs alone, per lane
+        // for a pack.
+        auto lean_passes = [&](const float hx0f, const float hy0f, const float wf, const float invw, float idx_f, const float last_f, const int npass, const float* const rf) {
+            const float half_invw = 0.5f * invw;
+            const float4 dh = *reinterpret_cast<const float4*>(rf);                     // header, diagonal A, B, T
+            const float3 dg = make_float3(dh.y, dh.z, dh.w);
+            uint8_t* const px_bytes = reinterpret_cast<uint8_t*>(tile_px);
+#if defined(RH_EXP) && RH_EXP == 4          /* diagnostic build: the hits are walked, no pass runs */
+            if (dg.x == 12345.0f)
+#endif
+            for (int pass = 0; pass < npass; pass++, idx_f += 64.0f) {
+                // (both are small non-negative integers: the minimum of their bit patterns)
+                const float idc = __uint_as_float(min(__float_as_uint(idx_f), __float_as_uint(last_f)));
+                // floor((idx + 0.5) / w): the half keeps the quotient at least 1/128 away from an integer
+                const float row_f = floorf(__builtin_fmaf(idc, invw, half_invw));
+                const float col_f = __builtin_fmaf(-row_f, wf, idc);
+                const float lxf = hx0f + col_f, lyf = hy0f + row_f;          // tile-relative pixel, exact small integers
+                const uint32_t pb = (uint32_t)__builtin_fmaf(lyf, (float)(TILE * 4), lxf * 4.0f);
+                // triangle B where the diagonal's edge function is negative: its planes sit TRI_WORDS further on
+                const uint32_t in_b = __float_as_uint(__builtin_fmaf(dg.x, lxf, __builtin_fmaf(dg.y, lyf, dg.z))) >> 31;
+                const float* const tp = rf + HDR_WORDS + in_b * (uint32_t)TRI_WORDS;
+                const float dx = __builtin_fmaf(lxf, 256.0f, -tp[OFF_XR]), dy = __builtin_fmaf(lyf, 256.0f, -tp[OFF_YR]);   // exact
+                Varyings var; float* vf = reinterpret_cast<float*>(&var);
+#pragma unroll
+                for (int v = 0; v < NV; v++) vf[v] = __builtin_fmaf(tp[OFF_DVDY + v], dy, __builtin_fmaf(tp[OFF_DVDX + v], dx, tp[OFF_V0 + v]));
+                Outputs out;
+                fragment_main(fctx, var, out);
+#pragma unroll
+                for (int t = 0; t < NA; t++) {
+                    blend_pixel<BLEND>(reinterpret_cast<PxT*>(px_bytes + (size_t)t * (TILE_PX * sizeof(PxT)) + (size_t)pb * (sizeof(PxT) / 4)), a.att[t],
+                                       out.color[t < RH_FRAGMENT_OUTPUTS ? t : RH_FRAGMENT_OUTPUTS - 1], a.src_factor, a.dst_factor);
+                }
+            }
+        };
         // Hits in order; k and everything read with readlane is wave-uniform and lives on the scalar unit.
         int k = 0;
         while (k < nh) {
             const uint32_t info = __builtin_amdgcn_readlane(info_v, k);
-            // per-lane inputs of the passes of this hit (or pack): record, box, first pixel index, last pixel index
-            uint32_t flags;
-            const float* rf;
-            float hx0f, hy0f, wf, invw, idx0_f, last_f;
-            int npass;
-            const int grad_log2 = (int)(info << 14) >> 26;           // (a pack: its first member's; a hint only)
-            uint32_t rec_index = info & 0x3fu;
-            if (info >> 31) {
+            if (TEX == 3 && (info & INFO_REPICK)) {
+                // the footprint copy of every texture slot for this primitive (uniform; unused slots fold away)
+                const int grad_log2 = (int)(info << 14) >> 26;
+#pragma unroll
+                for (int i = 0; i < RH_DEV_MAX_SLOTS; i++) fctx.poly[i].pick(p.slots[i], grad_log2);
+            }
+            if (info & INFO_SMALL) {
+                // a pack: every lane takes the box and the record of the member its pixel belongs to
                 const uint32_t run = __builtin_amdgcn_readlane(run_v, k);
                 const int c1 = (int)((run >> 10) & 127u), c2 = (int)((run >> 17) & 127u), c3 = (int)(run >> 24);
                 const bool g1 = lane >= c1, g2 = lane >= c2, g3 = lane >= c3;
@@ -801,65 +853,25 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
                 const int st = g3 ? c3 : (g2 ? c2 : (g1 ? c1 : 0));
                 const int src = (k + slot) << 2;
                 const uint2 m = make_uint2((uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)boxw_v), (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)info_v));
-                hx0f = (float)(m.x & 0xffu); hy0f = (float)((m.x >> 8) & 0xffu); wf = (float)((m.x >> 16) & 0xffu);
-                invw = __builtin_amdgcn_rcpf(wf);
-                idx0_f = (float)(lane - st);
-                last_f = (float)((int)((run >> 3) & 127u) - st - 1);      // the lanes past the pack's pixels shade its last pixel again
-                npass = 1;
-                rf = recf + (int)(m.y & 0x3fu) * REC_WORDS;
-                flags = FLAG_RECT | FLAG_HAS_A | FLAG_HAS_B;
+                const float wf = (float)((m.x >> 16) & 0xffu);
+                // (the lanes past the pack's pixels shade its last pixel again)
+                lean_passes((float)(m.x & 0xffu), (float)((m.x >> 8) & 0xffu), wf, __builtin_amdgcn_rcpf(wf), (float)(lane - st),
+                            (float)((int)((run >> 3) & 127u) - st - 1), 1, recf + (int)(m.y & 0x3fu) * REC_WORDS);
                 k += (int)(run & 7u);
-            } else {
-                const uint32_t boxw = __builtin_amdgcn_readlane(boxw_v, k);
-                invw = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(invw_v), k));
-                last_f = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(last_v), k));
-                hx0f = (float)(boxw & 0xffu); hy0f = (float)((boxw >> 8) & 0xffu); wf = (float)(boxw >> 16);
-                idx0_f = lane_f;
-                npass = (int)(((info >> 18) & 0x7ffu) + 63u) >> 6;
-                rf = recf + (int)rec_index * REC_WORDS;
-                flags = (info >> 6) & 0x3fu;
-                k++;
-            }
-            if (TEX == 3 && grad_log2 != picked_grad) {
-                // the footprint copy of every texture slot for this primitive (uniform; unused slots fold away)
-                picked_grad = grad_log2;
-#pragma unroll
-                for (int i = 0; i < RH_DEV_MAX_SLOTS; i++) fctx.poly[i].pick(p.slots[i], grad_log2);
-            }
-            const float half_invw = 0.5f * invw;
-            float idx_f = idx0_f;
-            if ((flags & (FLAG_RECT | FLAG_PERSP_A | FLAG_PERSP_B)) == FLAG_RECT) {
-                // Axis-aligned rectangle with affine varyings (what the reference's quads are): every pixel of the box is
-                // covered and the shared diagonal alone says by which triangle.  The loop is kept free of per-pass tests
-                // and of lane masks: a lane past the last pixel shades the last pixel once more -- same inputs, same
-                // result, the same bytes written to the same place.
-                const float4 dh = *reinterpret_cast<const float4*>(rf);                     // header, diagonal A, B, T
-                const float3 dg = make_float3(dh.y, dh.z, dh.w);
-                uint8_t* const px_bytes = reinterpret_cast<uint8_t*>(tile_px);
-                for (int pass = 0; pass < npass; pass++, idx_f += 64.0f) {
-                    const float idc = fminf(idx_f, last_f);
-                    // floor((idx + 0.5) / w): the half keeps the quotient at least 1/128 away from an integer
-                    const float row_f = floorf(__builtin_fmaf(idc, invw, half_invw));
-                    const float col_f = __builtin_fmaf(-row_f, wf, idc);
-                    const float lxf = hx0f + col_f, lyf = hy0f + row_f;          // tile-relative pixel, exact small integers
-                    const uint32_t pb = (uint32_t)__builtin_fmaf(lyf, (float)(TILE * 4), lxf * 4.0f);
-                    // triangle B where the diagonal's edge function is negative: its planes sit TRI_WORDS further on
-                    const uint32_t in_b = __float_as_uint(__builtin_fmaf(dg.x, lxf, __builtin_fmaf(dg.y, lyf, dg.z))) >> 31;
-                    const float* const tp = rf + HDR_WORDS + in_b * (uint32_t)TRI_WORDS;
-                    const float dx = __builtin_fmaf(lxf, 256.0f, -tp[OFF_XR]), dy = __builtin_fmaf(lyf, 256.0f, -tp[OFF_YR]);   // exact
-                    Varyings var; float* vf = reinterpret_cast<float*>(&var);
-#pragma unroll
-                    for (int v = 0; v < NV; v++) vf[v] = __builtin_fmaf(tp[OFF_DVDY + v], dy, __builtin_fmaf(tp[OFF_DVDX + v], dx, tp[OFF_V0 + v]));
-                    Outputs out;
-                    fragment_main(fctx, var, out);
-#pragma unroll
-                    for (int t = 0; t < NA; t++) {
-                        blend_pixel<BLEND>(reinterpret_cast<PxT*>(px_bytes + (size_t)t * (TILE_PX * sizeof(PxT)) + (size_t)pb * (sizeof(PxT) / 4)), a.att[t],
-                                           out.color[t < RH_FRAGMENT_OUTPUTS ? t : RH_FRAGMENT_OUTPUTS - 1], a.src_factor, a.dst_factor);
-                    }
-                }
                 continue;
             }
+            const uint32_t rec_index = info & 0x3fu;
+            const float* const rf = recf + (int)rec_index * REC_WORDS;
+            const uint32_t boxw = __builtin_amdgcn_readlane(boxw_v, k);
+            const float invw = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(invw_v), k));
+            const float last_f = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(last_v), k));
+            const float hx0f = (float)(boxw & 0xffu), hy0f = (float)((boxw >> 8) & 0xffu), wf = (float)(boxw >> 16);
+            const int npass = (int)(((info >> 18) & 0x7ffu) + 63u) >> 6;
+            k++;
+            if (info & INFO_LEAN) { lean_passes(hx0f, hy0f, wf, invw, lane_f, last_f, npass, rf); continue; }
+            const uint32_t flags = (info >> 6) & 0x3fu;
+            const float half_invw = 0.5f * invw;
+            float idx_f = lane_f;
             // (only hits that run alone come here: the extended record of this one)
             const float* const ef = reinterpret_cast<const float*>(a.ext + (size_t)(base + rec_index) * a.ext_bytes);
             const bool has_a = (flags & FLAG_HAS_A) != 0u, has_b = (flags & FLAG_HAS_B) != 0u;

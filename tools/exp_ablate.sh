@@ -6,6 +6,8 @@
 export RH_EARLY_BINNING=${RH_EARLY_BINNING:-0}
 for spec in "$@"; do
   name=${spec%%:*}; flags=${spec#*:}
+  # (a variant named prev* is built from tools/data/prev/rh_stage_fragment.hip: an earlier version of the source put there by hand)
+  case $name in prev*) export FRAG_SRC=tools/data/prev/rh_stage_fragment.hip;; *) unset FRAG_SRC;; esac
   tools/build_frag_variant.sh $name $flags 2>&1 | grep -v "warning\|^$" ; [ -f /tmp/$name.frag.co ] || exit 1
 done
 for round in $(seq ${ROUNDS:-2}); do

@@ -645,6 +645,9 @@ template <int NA, bool WIDE = false>
 struct TileLds {
     alignas(16) uint32_t rec[ROUND * REC_WORDS];     // first: record fields are reached with small immediate offsets
     typename Px<WIDE>::T px[NA][TILE_PX];
+#ifdef RH_LDS_PAD                                    /* diagnostic build: fewer workgroups per CU */
+    uint32_t pad[RH_LDS_PAD];
+#endif
 };
 
 // Brings records [first, first + n) into the staging area (16-byte pieces, consecutive lanes consecutive pieces).

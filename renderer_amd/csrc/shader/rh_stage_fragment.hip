@@ -754,10 +754,11 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
         // lane of its hit, and fetched by the scalar side hit by hit (the SIMD issues one instruction of ANY kind per ~2.3
         // cycles, scalar ones included: what is done once per round for 32 hits is nearly free, what is done per hit is not):
         //   boxw = x0 | y0 << 8 | width << 16, invw = 1 / width, last = pixels - 1
+        //   (the top byte of boxw: the hit's passes)
         uint32_t boxw_v; float invw_v, last_v;
         {
             const uint32_t bw = ((box_v >> 16) & 0xffu) - (box_v & 0xffu) + 1u;
-            boxw_v = (box_v & 0xffffu) | (bw << 16);
+            boxw_v = (box_v & 0xffffu) | (bw << 16) | (((((info_v >> 18) & 0x7ffu) + 63u) >> 6) << 24);
             invw_v = __builtin_amdgcn_rcpf((float)bw);
             last_v = (float)((info_v >> 18) & 0x7ffu) - 1.0f;
             if (TEX == 3) {
@@ -868,8 +869,8 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
             const uint32_t boxw = __builtin_amdgcn_readlane(boxw_v, k);
             const float invw = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(invw_v), k));
             const float last_f = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(last_v), k));
-            const float hx0f = (float)(boxw & 0xffu), hy0f = (float)((boxw >> 8) & 0xffu), wf = (float)(boxw >> 16);
-            const int npass = (int)(((info >> 18) & 0x7ffu) + 63u) >> 6;
+            const float hx0f = (float)(boxw & 0xffu), hy0f = (float)((boxw >> 8) & 0xffu), wf = (float)((boxw >> 16) & 0xffu);
+            const int npass = (int)(boxw >> 24);
             k++;
             if (info & INFO_LEAN) { lean_passes(hx0f, hy0f, wf, invw, lane_f, last_f, npass, rf); continue; }
             const uint32_t flags = (info >> 6) & 0x3fu;

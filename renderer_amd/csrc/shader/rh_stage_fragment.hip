@@ -401,29 +401,56 @@ RH_DEVICE void lean_triangle(const LeanVertex& a, LeanVertex b, LeanVertex c, in
 #pragma unroll
     for (int i = 2 + 3 * NV; i < TRI_WORDS; i++) o[i] = 0u;
 }
-RH_DEVICE void setup_lean_pair(const rh_draw_params& p, uint32_t cluster, int ox, int oy, uint32_t* w) {
-    const uint32_t instance = cluster / p.cpi, first = (cluster - instance * p.cpi) * 2u;
-    const LeanVertex v0 = run_vertex_lean(p, first, instance), v3 = run_vertex_lean(p, first + 3u, instance);
+// Two lanes set a quad up together, lanes l and l + 32 of the wave (a round brings 32 pairs): lane l runs vertices 0 and 1
+// and sets up triangle A with the header and the diagonal, lane l + 32 runs vertices 3 and 2 and sets up triangle B; what
+// the other needs of one's vertices changes sides through the wave's lane permute.  `half`: 0 for lane l, 1 for l + 32;
+// both lanes are active together (they hold the same pair value).
+RH_DEVICE uint32_t from_partner(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, (int)v); }
+RH_DEVICE void setup_lean_pair(const rh_draw_params& p, uint32_t cluster, int ox, int oy, uint32_t* w, int lane) {
+    const bool half = lane >= 32;
+#if defined(RH_EXP) && RH_EXP == 6          /* diagnostic build: no set-up at all */
+    w[0] = HDR_EMPTY; return;
+#endif
+    const uint32_t instance = p.cpi == 1u ? cluster : cluster / p.cpi, first = (cluster - instance * p.cpi) * 2u;     // (a quad per instance: no division)
+    // the corner this lane runs (vertex 0 or 3) and the partner's
+    const LeanVertex corner = run_vertex_lean(p, first + (half ? 3u : 0u), instance);
+    const int32_t oX = (int32_t)from_partner((uint32_t)corner.X, lane), oY = (int32_t)from_partner((uint32_t)corner.Y, lane);
     // the bounding box of either triangle is the rectangle's (tri_pixel_bbox, cut to the tile), and the exact pixel set of
     // the rectangle under the top-left rule (setup_strip_quad)
-    const int32_t minX = min(v0.X, v3.X), maxX = max(v0.X, v3.X), minY = min(v0.Y, v3.Y), maxY = max(v0.Y, v3.Y), pad = p.bbox_pad;
+    const int32_t minX = min(corner.X, oX), maxX = max(corner.X, oX), minY = min(corner.Y, oY), maxY = max(corner.Y, oY), pad = p.bbox_pad;
     const int bx0 = max(max(p.sc_x0, (minX - pad + 255) >> 8), ox), bx1 = min(min(p.sc_x1 - 1, (maxX + pad) >> 8), ox + TILE - 1);
     const int by0 = max(max(p.sc_y0, (minY - pad + 255) >> 8), oy), by1 = min(min(p.sc_y1 - 1, (maxY + pad) >> 8), oy + TILE - 1);
     const int ex0 = max(max(p.sc_x0, ox), (minX + 255) >> 8), ex1 = min(min(p.sc_x1 - 1, ox + TILE - 1), (maxX - 1) >> 8);
     const int ey0 = max(max(p.sc_y0, oy), (minY + 255) >> 8), ey1 = min(min(p.sc_y1 - 1, oy + TILE - 1), (maxY - 1) >> 8);
-    if (bx0 > bx1 || by0 > by1 || ex0 > ex1 || ey0 > ey1) { w[0] = HDR_EMPTY; return; }
+    if (bx0 > bx1 || by0 > by1 || ex0 > ex1 || ey0 > ey1) { if (!half) w[0] = HDR_EMPTY; return; }     // (the same verdict in both lanes)
     const uint32_t bbox = (uint32_t)(ex0 - ox) | ((uint32_t)(ey0 - oy) << 8) | ((uint32_t)(ex1 - ox) << 16) | ((uint32_t)(ey1 - oy) << 24);
-    const LeanVertex v1 = run_vertex_lean(p, first + 1u, instance), v2 = run_vertex_lean(p, first + 2u, instance);
+    // the vertex on the diagonal this lane runs (vertex 1 or 2) and the partner's
+    const LeanVertex mine = run_vertex_lean(p, first + (half ? 2u : 1u), instance);
+    LeanVertex other;
+    other.X = (int32_t)from_partner((uint32_t)mine.X, lane); other.Y = (int32_t)from_partner((uint32_t)mine.Y, lane);
+    {   const float* mf = reinterpret_cast<const float*>(&mine.var); float* of = reinterpret_cast<float*>(&other.var);
+#pragma unroll
+        for (int v = 0; v < NV; v++) of[v] = __uint_as_float(from_partner(__float_as_uint(mf[v]), lane));
+    }
+    // triangle A = (v0, v1, v2) = (corner, mine, other); triangle B = (v1, v3, v2) = (other, corner, mine)
+    LeanVertex ta, tb, tc;
+    ta.X = half ? other.X : corner.X; ta.Y = half ? other.Y : corner.Y;
+    tb.X = half ? corner.X : mine.X; tb.Y = half ? corner.Y : mine.Y;
+    tc.X = half ? mine.X : other.X; tc.Y = half ? mine.Y : other.Y;
+    {   const float* cf = reinterpret_cast<const float*>(&corner.var); const float* mf = reinterpret_cast<const float*>(&mine.var);
+        const float* of = reinterpret_cast<const float*>(&other.var);
+        float* fa = reinterpret_cast<float*>(&ta.var); float* fb = reinterpret_cast<float*>(&tb.var); float* fc = reinterpret_cast<float*>(&tc.var);
+#pragma unroll
+        for (int v = 0; v < NV; v++) { fa[v] = half ? of[v] : cf[v]; fb[v] = half ? cf[v] : mf[v]; fc[v] = half ? mf[v] : of[v]; }
+    }
     uint4* const q = reinterpret_cast<uint4*>(w);
     uint32_t t[TRI_WORDS], dg[3];
-    float g, gb;
-    lean_triangle(v0, v1, v2, ox, oy, t, true, dg, g);
-    q[0] = make_uint4(hdr_pack(bbox, FLAG_HAS_A | FLAG_HAS_B | FLAG_RECT, (int)((__float_as_uint(g * (256.0f * 1.41421356f)) >> 23) & 0xffu) - 127), dg[0], dg[1], dg[2]);
+    float g;
+    lean_triangle(ta, tb, tc, ox, oy, t, !half, dg, g);
+    if (!half) q[0] = make_uint4(hdr_pack(bbox, FLAG_HAS_A | FLAG_HAS_B | FLAG_RECT, (int)((__float_as_uint(g * (256.0f * 1.41421356f)) >> 23) & 0xffu) - 127), dg[0], dg[1], dg[2]);
+    uint4* const qt = q + HDR_WORDS / 4 + (half ? TRI_WORDS / 4 : 0);
 #pragma unroll
-    for (int i = 0; i < TRI_WORDS / 4; i++) q[HDR_WORDS / 4 + i] = make_uint4(t[4 * i], t[4 * i + 1], t[4 * i + 2], t[4 * i + 3]);
-    lean_triangle(v1, v3, v2, ox, oy, t, false, dg, gb);
-#pragma unroll
-    for (int i = 0; i < TRI_WORDS / 4; i++) q[(HDR_WORDS + TRI_WORDS) / 4 + i] = make_uint4(t[4 * i], t[4 * i + 1], t[4 * i + 2], t[4 * i + 3]);
+    for (int i = 0; i < TRI_WORDS / 4; i++) qt[i] = make_uint4(t[4 * i], t[4 * i + 1], t[4 * i + 2], t[4 * i + 3]);
 }
 
 // Sets up the triangles of pair value `value` (cluster | sub-record << CLIP_SUB_SHIFT) for the tile at (ox, oy) and
@@ -698,20 +725,23 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
     // 2. rounds of records
     int picked_grad = -1000;                            // the gradient hint the footprint copies were last picked for
     // (the values of a round's pairs are fetched a round ahead: the set-up below starts with them)
-    uint32_t value_next = (start < end && lane < (int)min((uint32_t)ROUND, end - start)) ? a.vals[start + (uint32_t)lane] : PAIR_GENERAL;
+    uint32_t value_next = (start < end && (lane & 31) < (int)min((uint32_t)ROUND, end - start)) ? a.vals[start + (uint32_t)(lane & 31)] : PAIR_GENERAL;
     for (uint32_t base = start; base < end; base += ROUND) {
         const int n = (int)min((uint32_t)ROUND, end - base);
         {
             // lane = pair of this round.  General pairs bring the record the set-up launch wrote; a lean quad is set up
             // here and now, straight into the staging area.
+            // (lanes l and l + 32 hold the same pair: they set a lean quad up together, see setup_lean_pair)
+            static_assert(ROUND == 32, "two lanes per pair of a round");
+            const int pl = lane & 31;
             const uint32_t value = value_next;
             const uint32_t nb = base + ROUND;
-            value_next = (nb < end && lane < (int)min((uint32_t)ROUND, end - nb)) ? a.vals[nb + (uint32_t)lane] : PAIR_GENERAL;
+            value_next = (nb < end && pl < (int)min((uint32_t)ROUND, end - nb)) ? a.vals[nb + (uint32_t)pl] : PAIR_GENERAL;
             const bool lean = (value & PAIR_GENERAL) == 0u;
             if (!__any(lean)) stage_records(lds.rec, a.rec, base, n, lane);
             else {
-                uint32_t* const w = &lds.rec[lane * REC_WORDS];
-                if (lean) setup_lean_pair(p, value & CLIP_CLUSTER_MASK, ox, oy, w);
+                uint32_t* const w = &lds.rec[pl * REC_WORDS];
+                if (lean) setup_lean_pair(p, value & CLIP_CLUSTER_MASK, ox, oy, w, lane);
                 else if (lane < n) {
                     const uint4* const src = reinterpret_cast<const uint4*>(a.rec + (size_t)(base + (uint32_t)lane) * (REC_WORDS * 4));
 #pragma unroll

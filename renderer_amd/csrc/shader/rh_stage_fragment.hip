@@ -803,7 +803,7 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
         // the 64 lanes of ONE pass (disjoint boxes cannot touch the same pixel, so their relative order is
         // immaterial).  Every lane works out the pack that would start at its hit:
         //   run = length | pixels << 3 | lane at which member 1, 2, 3 starts << 10, 17, 24 (127 = no such member)
-        // (members behind the first share its gradient hint: their bit 30 is clear)
+        // (the footprint copies a pack reads are the ones picked for its first member or before: a hint, any copy holds the same texels)
         uint32_t run_v;
         {
             const uint32_t n0 = (info_v >> 18) & 0x7ffu;
@@ -819,7 +819,7 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
                     return (p & 0xffu) > ((q >> 16) & 0xffu) || ((p >> 16) & 0xffu) < (q & 0xffu) ||
                            ((p >> 8) & 0xffu) > (q >> 24) || (p >> 24) < ((q >> 8) & 0xffu);
                 };
-                auto joins = [](uint32_t inf) { return (inf & (INFO_SMALL | INFO_REPICK)) == INFO_SMALL; };
+                auto joins = [](uint32_t inf) { return (inf & INFO_SMALL) != 0u; };
                 const uint32_t n1 = (m1.y >> 18) & 0x7ffu, n2 = (m2.y >> 18) & 0x7ffu, n3 = (m3.y >> 18) & 0x7ffu;
                 const bool ok1 = (info_v >> 31) != 0u && lane + 1 < nh && joins(m1.y) && n0 + n1 <= 64u && apart(box_v, m1.x);
                 const bool ok2 = ok1 && lane + 2 < nh && joins(m2.y) && n0 + n1 + n2 <= 64u && apart(box_v, m2.x) && apart(m1.x, m2.x);

@@ -81,6 +81,10 @@ enum {
                                          pass has already arrived (without waiting for it); 0: it leaves that to the next
                                          call, so that the pass is certainly still awaiting its count when rh_submit
                                          returns (for testing what the next call does with it) */
+    RH_OPTION_SETUP_LAUNCH = 9,       /* 0 (default): the tile kernel sets axis-aligned strip quads with affine varyings up
+                                         itself, in LDS, and only other primitives get records from the set-up launch; 1:
+                                         every record comes from the set-up launch (identical results; for testing the two
+                                         set-up paths against each other) */
 };
 
 #define RH_MAX_ATTRIBUTES 8

@@ -4,7 +4,7 @@
 #pragma once
 #include <stdint.h>
 
-#define RH_DEVICE_ABI_VERSION 18u
+#define RH_DEVICE_ABI_VERSION 19u
 #define RH_MODULE_MAGIC 0x52484d4fu   // "RHMO"
 
 #define RH_DEV_MAX_ATTRIBUTES 8
@@ -77,6 +77,8 @@ struct rh_draw_params {
     uint32_t samples;                                // 1, or 2 / 4 / 8 (multisampled pass)
     int32_t bbox_pad;                                // growth of primitive bounding boxes in 1/256 px: 0, or 128 when
                                                      // samples away from the pixel centre can be covered
+    uint32_t no_lean;                                // 1: no cluster counts as a lean quad (rh_geometry.h): every record comes
+                                                     // from the set-up launch (RH_OPTION_SETUP_LAUNCH; identical results)
 };
 
 // Packed tile rectangle of a cluster: lo = x0 | y0 << 16, hi = x1 | y1 << 16 (inclusive); x0 > x1 marks "touches nothing".

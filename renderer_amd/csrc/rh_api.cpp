@@ -89,6 +89,7 @@ struct rh_device {
     int bin_priority = 0;
     int early_binning = 1;
     int eager_count = 1;                        // RH_OPTION_EAGER_COUNT
+    int setup_launch = 0;                       // RH_OPTION_SETUP_LAUNCH
     // The tiles of a pass's last, partly filled round of workgroups are cut into bands of rows (rh_tile_args::split2_first):
     // 0 = never, 1 = halves, quarters or eighths (one kind per pass), 2 = where that kind is halves, quarters for as many of them as there is room left.
     int tail_split = 2;
@@ -445,6 +446,7 @@ int rh_device_set_option(rh_device* dev, int option, int value) {
     if (option == RH_OPTION_TIMING) { dev->timing = value ? 1 : 0; return 0; }
     if (option == RH_OPTION_EARLY_BINNING) { dev->early_binning = value ? 1 : 0; return 0; }
     if (option == RH_OPTION_EAGER_COUNT) { dev->eager_count = value ? 1 : 0; return 0; }
+    if (option == RH_OPTION_SETUP_LAUNCH) { dev->setup_launch = value ? 1 : 0; return 0; }
     if (option == RH_OPTION_TAIL_SPLIT) { if (value < 0 || value > 2) return fail("rh_device_set_option: RH_OPTION_TAIL_SPLIT takes 0, 1 or 2"); dev->tail_split = (int)value; return 0; }
     if (option == RH_OPTION_STRIP_ROW0 || option == RH_OPTION_STRIP_ROW1) {
         if (value < 0) return fail("rh_device_set_option: negative strip row");
@@ -986,6 +988,7 @@ int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer, rh_device::Pa
     if (n_clusters64 >= (1ull << 28)) return fail("render pass: %llu triangle pairs exceed the 28-bit cluster index", (unsigned long long)n_clusters64);
     p.n_clusters = (uint32_t)n_clusters64;
     p.samples = pl->samples; p.bbox_pad = pl->samples > 1 ? 128 : 0;
+    p.no_lean = dev->setup_launch ? 1u : 0u;
     const bool empty_scissor = p.sc_x0 >= p.sc_x1 || p.sc_y0 >= p.sc_y1;
     const uint32_t n_clusters = empty_scissor ? 0u : p.n_clusters;
 

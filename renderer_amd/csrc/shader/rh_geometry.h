@@ -172,7 +172,7 @@ RH_DEVICE bool lean_quad(const rh_draw_params& p, const SnappedVertex& v0, const
     const bool rows = v0.Y == v1.Y && v2.Y == v3.Y && v0.X == v2.X && v1.X == v3.X;
     const int32_t rminX = min(v0.X, v3.X), rmaxX = max(v0.X, v3.X), rminY = min(v0.Y, v3.Y), rmaxY = max(v0.Y, v3.Y);
     shape = p.samples == 1u && (columns || rows) && v0.X != v3.X && v0.Y != v3.Y;
-    return shape && v0.ok && v1.ok && v2.ok && v3.ok && rmaxX - rminX < F32_EDGE_LIMIT && rmaxY - rminY < F32_EDGE_LIMIT &&
+    return shape && p.no_lean == 0u && v0.ok && v1.ok && v2.ok && v3.ok && rmaxX - rminX < F32_EDGE_LIMIT && rmaxY - rminY < F32_EDGE_LIMIT &&
            v0.rw == 1.0f && v1.rw == 1.0f && v2.rw == 1.0f && v3.rw == 1.0f;
 }
 

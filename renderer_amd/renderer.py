@@ -193,6 +193,11 @@ class Renderer:
         left (identical results)."""
         _ffi.check(_ffi.lib().rh_device_set_option(self.device, _ffi.OPTION_TAIL_SPLIT, int(mode)))
 
+    def set_setup_launch(self, enabled):
+        """True: every set-up record comes from the set-up launch; False (default): the tile kernel sets lean quads up
+        itself (identical results)."""
+        _ffi.check(_ffi.lib().rh_device_set_option(self.device, _ffi.OPTION_SETUP_LAUNCH, 1 if enabled else 0))
+
     def set_timing(self, enabled):
         _ffi.check(_ffi.lib().rh_device_set_option(self.device, _ffi.OPTION_TIMING, 1 if enabled else 0))
 

@@ -205,6 +205,29 @@ def test_general_and_specialised_kernel_bodies_agree(oracle):
         assert_same(got, want, f"general={general}")
 
 
+def test_quads_set_up_by_the_tile_kernel_and_by_the_set_up_launch_agree(oracle):
+    """Axis-aligned strip quads with affine varyings are set up by the tile kernel itself, in LDS, pair by pair; with
+    RH_OPTION_SETUP_LAUNCH the set-up launch writes their records instead, with its general code.  Both give the oracle's
+    bytes: pre-multiplied 16 px quads, tiny additive quads (packs), the letterboxed example with its recording attachment,
+    and a scene that mixes lean quads with projective ones in one pass (records of both kinds in one round)."""
+    cases = [("16 px", scenes.random_quads_scene(20000, 16, 1280, 720, seed=41)),
+             ("tiny", scenes.tiny_quads_scene(60000, 1280, 720, seed=42)),
+             ("example", scenes.example_scene(37, 640, 360, record=True)),
+             ("mixed", scenes.tilted_quads_scene(3000, 640, 360, seed=43))]
+    for name, scene in cases:
+        want = scenes.draw_oracle(scene)
+        for launch in (False, True):
+            hs = scenes.HipScene(scene)
+            try:
+                hs.renderer.set_setup_launch(launch)
+                hs.draw(); hs.draw()                  # (the second: queued before its pair count is known)
+                assert_same(hs.read_color(), want["color"], f"{name}, set-up launch {launch}")
+                if scene.get("record"):
+                    assert_same(hs.read_recording(), want["recording"], f"{name} recording, set-up launch {launch}")
+            finally:
+                hs.close()
+
+
 def test_pass_queued_before_its_pair_count_is_known(oracle):
     """After its first pass a device queues a pass whole, with room for the pairs of the largest pass seen so far
     plus a quarter, and looks at the count afterwards.  Scenes that fit (same size, smaller) and a scene that does not

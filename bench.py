@@ -107,6 +107,123 @@ def launch_ranks(n):
     return subprocess.run(cmd).returncode        # the children inherit stdout: rank 0 writes the line there itself
 
 
+def run_c3(args, dist, rank, world, local_rank, backend, devices, json_fd):
+    """BASELINE.json configs[3]: render-to-texture two-pass at 16384 x 16384 with the target split into strips of tile
+    rows over the ranks (sort-first).  Pass 1 draws 4 M quads of 64x64 px (pre-multiplied alpha, linear filter) into
+    texture A, every rank its strip; the strips of A are all-gathered in place (RCCL; pass 2 samples A anywhere); pass 2
+    draws one quad covering B that samples A, every rank its strip; the strips of B are all-gathered too.  The work of a
+    frame is fixed, so more ranks make the frame shorter: "strong" scaling.  One rank: the same two passes, no exchange."""
+    import ctypes as C
+    import numpy as np
+    import scenes
+    from renderer_amd import Renderer, _ffi, partition
+    S, quads, side = args.width, args.quads, args.side
+    device = f"cuda:{local_rank}" if dist is not None else "cpu"
+    s1 = scenes.random_quads_scene(quads, side, S, S, seed=3)
+    r = Renderer(64, 64, hip_ordinal=local_rank)
+    h1 = scenes.HipScene(s1, renderer=r)                    # pass 1 -> texture A (S x S, RGBA8)
+    a_tex = h1.target_texture
+    a_view = type(a_tex).__new__(type(a_tex))               # A again, with a linear sampler, as pass 2's texture
+    a_view.__dict__.update(a_tex.__dict__)
+    smp = C.c_void_p()
+    _ffi.check(_ffi.lib().rh_sampler_create(r.device, int(Renderer.linear_filtering()), C.byref(smp)))
+    a_view.sampler = smp
+    _ffi.lib().rh_texture_retain(a_view.handle)
+    b_tex = r.texture(S, S, 1, Renderer.nearest_filtering(), Renderer.rgba_u8(), True, True, False)
+    vert, frag = scenes.shader_code("hello")
+    a_position, a_tex_coord, i_offset = r.attribute(0, 2), r.attribute(1, 2), r.instanced()
+    program = r.program(vert, frag, [a_position, a_tex_coord], [i_offset], [], [(a_view, Renderer.visible_to_fragment_shader())])
+    p2 = r.pipeline(program, Renderer.pre_multiplied_blend(), Renderer.triangle_strip_primitive(), 1, [Renderer.texture_target(b_tex)])
+    r.set_attribute(p2, 0, scenes.UNIT_POSITION)
+    r.set_attribute(p2, 1, scenes.QUAD_UV)
+    r.set_instanced(p2, (0, 0), np.zeros((1, 2), dtype=np.float32))
+    clear = Renderer.clear_color(0., 0., 0., 1.)
+    row0, row1 = partition.strip_for_rank(S, rank, world)
+    if world > 1:
+        r.set_strip(row0, row1)
+    exchange_s = [0.0]
+
+    def step():
+        r.render(h1.pipeline, h1.clear, None, h1.count)          # pass 1, this rank's strip of A
+        r.finish_frame()
+        if world > 1:
+            r.synchronize()                                           # (so that the time below is the exchange alone)
+            t = time.perf_counter()
+            partition.exchange_strips(r, a_tex, rank, world, device)  # every rank now holds all of A
+            exchange_s[0] += time.perf_counter() - t
+        r.render(p2, clear, None, (1, 4))                             # pass 2, this rank's strip of B
+        r.finish_frame()
+        if world > 1:
+            r.synchronize()
+            t = time.perf_counter()
+            partition.exchange_strips(r, b_tex, rank, world, device)
+            exchange_s[0] += time.perf_counter() - t
+
+    def barrier():
+        if dist is not None:
+            dist.barrier(device_ids=[local_rank]) if dist.get_backend() == "nccl" else dist.barrier()
+        r.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    r.synchronize()
+    r.set_timing(True); r.drain_timings()
+    exchange_s[0] = 0.0
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    r.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    t = r.drain_timings()
+    if dist is not None:
+        import torch
+        v = torch.tensor([elapsed, exchange_s[0]], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(v, op=dist.ReduceOp.MAX)
+        elapsed, exchange_s[0] = float(v[0]), float(v[1])
+    r.set_timing(False)
+    r.set_strip(0, 0)
+    if rank == 0:
+        n_frag = quads * side * side + S * S
+        # algorithmic bytes of a frame: instance records, a read-modify-write of the target texel per fragment of either pass,
+        # the distinct texels sampled (the quads' texture in pass 1, all of A in pass 2)
+        b_alg = quads * 8 + 8 + n_frag * 2 * 4 + s1["texture"].nbytes + S * S * 4
+        share = (row1 - row0) / S                      # this rank's part of every pass
+        tile_ms = t["tile_ms"] / args.steps            # both passes of a frame, this rank's strips
+        achieved = b_alg * share / (tile_ms * 1e-3) / 1e9 if tile_ms > 0 else 0.0
+        strip_bytes = 2 * S * S * 4 * (world - 1) // max(1, world)     # received per rank and frame: the others' strips of A and of B
+        out = {"metric": "instanced quads/s at 16K two-pass render-to-texture, sort-first strips", "value": quads * args.steps / elapsed, "unit": "quads/s",
+               "n_gpus": world, "ranks": world, "backend": backend, "devices": devices, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+               "dtype": "f32->unorm8", "data": "synthetic",
+               "config": {"workload": f"two-pass {S}x{S} RGBA8 render-to-texture: {quads} quads {side}x{side} px (pre-multiplied alpha, linear filter) into A, "
+                                      f"then one quad sampling A (linear) into B (BASELINE.json configs[3])",
+                          "parallelism": f"sort-first strips of tile rows x{world}, in-place all-gather of A and of B" if world > 1 else "single GPU",
+                          "strip_rows_rank0": [row0, row1]},
+               "exchange": {"ms_per_step": exchange_s[0] / args.steps * 1e3, "bytes_received_per_rank_per_step": strip_bytes,
+                            "note": "host wall time of the two in-place all-gathers of a frame (the slowest rank's), after the rank's own strip is done"},
+               "roofline": {"bound": "hbm", "kernel": "rh_tile_1 (both passes of a frame)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_step": b_alg, "share_of_rank0": share,
+                            "kernel_ms": tile_ms, "binning_ms": t["bin_ms"] / args.steps, "setup_ms": t["setup_ms"] / args.steps,
+                            "fragments_per_s": n_frag * share / (tile_ms * 1e-3) if tile_ms > 0 else 0.0,
+                            "limited_by": "VALU instruction issue (LDS-resident tile)"}}
+        if world == 1 and not args.no_cpu_baseline:
+            # CPU restatement on a bounded sample of pass 1: the same quads at the same density on a 2048 x 2048 target
+            cores = min(16, os.cpu_count() or 1)
+            k = max(1, (S // 2048) ** 2)
+            sample = scenes.random_quads_scene(max(1, quads // k), side, min(S, 2048), min(S, 2048), seed=3)
+            t1 = time.perf_counter()
+            scenes.draw_oracle(sample, threads=cores)
+            cpu_s = time.perf_counter() - t1
+            out["cpu_baseline"] = {"value": len(sample["instances"]) / cpu_s, "unit": "quads/s", "cores": cores, "kind": "port",
+                                   "sample": f"pass 1 at the same density on a {min(S, 2048)}x{min(S, 2048)} target ({len(sample['instances'])} quads of "
+                                             f"{side}x{side} px) on {cores} threads, {cpu_s:.2f} s wall; CPU restatement, not lavapipe"}
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    h1.close(); r.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -116,8 +233,9 @@ def main():
     ap.add_argument("--side", type=int, default=16, help="quad edge in pixels (headline: 16)")
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
-    ap.add_argument("--workload", choices=["c1", "c2"], default="c1",
-                    help="c1 (headline): --quads quads of --side px, alpha blend; c2: --quads quads of 2..8 px, additive")
+    ap.add_argument("--workload", choices=["c1", "c2", "c3"], default="c1",
+                    help="c1 (headline): --quads quads of --side px, alpha blend; c2: --quads quads of 2..8 px, additive; "
+                         "c3: two-pass render-to-texture at 16384x16384 (4 M quads of 64 px), the target split into strips over --gpus ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alone", action="store_true", help="skip the untimed leg that runs the same frames with every launch on one stream (profiling runs: the kernel statistics then hold the timed region only)")
     ap.add_argument("--texture-size", type=int, default=0,
@@ -149,6 +267,14 @@ def main():
         # debugging aid: after that many seconds every thread's Python stack goes to stderr and the process exits
         import faulthandler
         faulthandler.dump_traceback_later(float(os.environ["RH_BENCH_WATCHDOG"]), exit=True)
+    if args.workload == "c3":
+        # (the configuration's own shape unless the caller gives another)
+        if args.quads <= 0:
+            args.quads = 4_000_000
+        if (args.width, args.height, args.side) == (3840, 2160, 16):
+            args.width = args.height = 16384
+            args.side = 64
+        args.height = args.width
     if args.quads <= 0:
         args.quads = 1_000_000 if args.workload == "c1" else 10_000_000
 
@@ -192,6 +318,12 @@ def main():
     import numpy as np
     import scenes
     from renderer_amd import Renderer
+
+    if args.workload == "c3":
+        run_c3(args, dist, rank, world, local_rank, backend, devices, json_fd)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
 
     # every rank renders a different frame of the same distribution
     if args.workload == "c2":

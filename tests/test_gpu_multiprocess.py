@@ -76,3 +76,21 @@ def test_bench_started_plainly_with_gpus_2_starts_two_ranks_itself(tmp_path):
     assert len(lines) == 1, out.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["ranks"] == 2 and d["devices"] == [0, 0] and d["backend"].startswith("gloo")
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_bench_strips_leg_prints_a_line(world):
+    """bench.py --workload c3 (the two-pass render-to-texture configuration split into strips of tile rows), at a small
+    size: one rank, and two ranks in rehearsal mode started by bench.py itself."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["RH_REHEARSE_ON_ONE_GPU"] = "1"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c3", "--gpus", str(world), "--width", "1024", "--quads", "20000",
+           "--side", "32", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=280, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["ranks"] == world and d["scaling"] == "strong" and d["value"] > 0 and d["roofline"]["frac"] > 0
+    assert d["exchange"]["bytes_received_per_rank_per_step"] == (0 if world == 1 else 1024 * 1024 * 4)

@@ -17,7 +17,7 @@ FMT_R_U8, FMT_BGRA_U8, FMT_RGBA_U8, FMT_RGBA_F16, FMT_RGBA_F32 = range(5)
 FILTER_LINEAR, FILTER_NEAREST = 0, 1
 TOPO_TRIANGLE_LIST, TOPO_TRIANGLE_STRIP = 0, 1
 BF_ZERO, BF_ONE, BF_SRC_ALPHA, BF_ONE_MINUS_SRC_ALPHA = range(4)
-SHADER_HELLO, SHADER_SIZED, SHADER_HELLO_LAYER, SHADER_TILTED, SHADER_SPACE = 0, 1, 2, 3, 4
+SHADER_HELLO, SHADER_SIZED, SHADER_HELLO_LAYER, SHADER_TILTED, SHADER_SPACE, SHADER_CROWD = 0, 1, 2, 3, 4, 5
 
 
 def build():
@@ -48,7 +48,7 @@ class OrcTarget(C.Structure):
 class OrcDraw(C.Structure):
     _fields_ = [("shader", C.c_int32), ("topology", C.c_int32), ("vertex_count", C.c_uint32),
                 ("instance_count", C.c_uint32), ("attr", C.c_void_p * 8), ("attr_size", C.c_uint32 * 8),
-                ("storage", C.c_void_p * 4), ("uniform", C.c_void_p * 4), ("tex", OrcTexture * 4),
+                ("storage", C.c_void_p * 4), ("uniform", C.c_void_p * 8), ("tex", OrcTexture * 8),
                 ("has_viewport", C.c_int32), ("viewport", C.c_float * 4), ("clip_to_viewport", C.c_int32),
                 ("src_factor", C.c_uint32), ("dst_factor", C.c_uint32), ("n_targets", C.c_uint32),
                 ("targets", OrcTarget * 4), ("threads", C.c_int32), ("fragments_out", C.c_uint64),

@@ -43,6 +43,7 @@ enum {
     ORC_SHADER_HELLO_NEAREST_LAYER = 2, // hello sampling layer `uniform[0]` of a 2D-array texture
     ORC_SHADER_TILTED = 3,       // projective quads: per-vertex w, a third varying, a uniform read by both stages
     ORC_SHADER_SPACE = 4,        // quads in space: a 4x4 matrix from a uniform, z and w from the vertex stage
+    ORC_SHADER_CROWD = 5,        // hello's vertex stage; the fragment stage adds up six textures, each times a vec4 uniform, times a gain
 };
 
 struct orc_texture {
@@ -68,8 +69,8 @@ struct orc_draw {
     const float* attr[8];            // one tightly packed f32 buffer per attribute location (reference src/attribute.rs:10-29)
     uint32_t attr_size[8];           // 1..4 floats
     const float* storage[4];         // read-only storage buffers, in slot order (reference src/instanced.rs:9-38)
-    const float* uniform[4];         // uniform buffers (reference src/uniform.rs:9-38)
-    orc_texture  tex[4];             // textures in slot order
+    const float* uniform[8];         // uniform buffers (reference src/uniform.rs:9-38)
+    orc_texture  tex[8];             // textures in slot order
     int32_t  has_viewport;           // reference src/render_pass.rs:39-41
     float    viewport[4];            // margin_x, margin_y, width, height
     int32_t  clip_to_viewport;       // 1: fragments outside the viewport rectangle are clipped (strict clip volume)
@@ -253,12 +254,26 @@ void space_vs(const orc_draw& d, uint32_t v, uint32_t inst, VsOut& o) {
     o.var[0] = uv[0]; o.var[1] = uv[1]; o.var[2] = 1.0f;
 }
 
+// Twenty binding slots (reference src/pipeline.rs:25-27: four to a group): uniform[0] = gain, uniform[1..6] = one vec4 weight
+// per texture; colour = gain * sum_i texture_i(uv) * w_i, accumulated in order with one fma per channel; one colour output.
+void crowd_fs(const orc_draw& d, const float* var, float out[][4]) {
+    float acc[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+    for (int i = 0; i < 6; i++) {
+        float c[4]; sample_2d(d.tex[i], var[0], var[1], 0, c);
+        const float* w = d.uniform[1 + i];
+        for (int k = 0; k < 4; k++) acc[k] = fmaf(c[k], w[k], acc[k]);
+    }
+    const float gain = d.uniform[0][0];
+    for (int k = 0; k < 4; k++) out[0][k] = acc[k] * gain;
+}
+
 const Shader SHADERS[] = {
     { 2, 2, hello_vs, hello_fs },
     { 2, 2, sized_vs, hello_fs },
     { 2, 2, hello_vs, layer_fs },
     { 3, 2, tilted_vs, tilted_fs },
     { 3, 2, space_vs, tilted_fs },
+    { 2, 1, hello_vs, crowd_fs },
 };
 
 // ---- triangle setup ----------------------------------------------------------------------------------------------

@@ -4,11 +4,11 @@
 #pragma once
 #include <stdint.h>
 
-#define RH_DEVICE_ABI_VERSION 19u
+#define RH_DEVICE_ABI_VERSION 20u
 #define RH_MODULE_MAGIC 0x52484d4fu   // "RHMO"
 
 #define RH_DEV_MAX_ATTRIBUTES 8
-#define RH_DEV_MAX_SLOTS 16
+#define RH_DEV_MAX_SLOTS 32
 #define RH_DEV_MAX_TARGETS 4
 
 // Rasteriser geometry

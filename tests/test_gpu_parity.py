@@ -697,3 +697,56 @@ def test_captured_frame_of_a_loaded_sparse_pass_with_margins(oracle):
             assert_same(tex.read(), recording, f"recording texture after frame {k + 1}")
     finally:
         r.close()
+
+
+def test_twenty_binding_slots_over_five_bind_groups(oracle):
+    """The reference numbers binding slots flat, four to a bind group, eight groups (src/pipeline.rs:25-27, 90-131;
+    Renderer::uniform_index / texture_index, src/renderer.rs:356-378).  The `crowd` program binds one instanced buffer,
+    seven uniforms and six textures with their samplers: slots 0..19, bind groups 0..4, uniforms and textures beyond the
+    sixteenth slot.  Bit-exact against the oracle's restatement of the same program."""
+    from oracle import loader as O
+    from renderer_amd import Renderer
+    W, H, N = 320, 200, 400
+    rng = np.random.default_rng(77)
+    scene = scenes.random_quads_scene(N, 24, W, H, seed=78)
+    sizes = [(32, 32), (64, 32), (32, 64), (96, 32), (16, 16), (256, 256)]
+    filters = ["linear", "nearest", "linear", "linear", "nearest", "linear"]
+    texels = [rng.integers(0, 256, (h, w, 4), dtype=np.uint8) for (w, h) in sizes]
+    texels[5] = scenes.load_letter_f()
+    gain = np.array([0.35], dtype=np.float32)
+    weights = [rng.uniform(0.05, 0.6, 4).astype(np.float32) for _ in range(6)]
+    r = Renderer(W, H)
+    try:
+        vert, frag = scenes.shader_code("crowd")
+        a_position, a_tex_coord, i_offset = r.attribute(0, 2), r.attribute(1, 2), r.instanced()
+        uniforms = [(r.uniform(), Renderer.visible_to_fragment_shader()) for _ in range(7)]
+        textures = []
+        for (w, h), f in zip(sizes, filters):
+            flt = Renderer.linear_filtering() if f == "linear" else Renderer.nearest_filtering()
+            textures.append((r.texture(w, h, 1, flt, Renderer.rgba_u8(), False, False, True), Renderer.visible_to_fragment_shader()))
+        program = r.program(vert, frag, [a_position, a_tex_coord], [i_offset], uniforms, textures)
+        target = r.texture(W, H, 1, Renderer.nearest_filtering(), Renderer.rgba_u8(), True, True, False)
+        pipeline = r.pipeline(program, Renderer.pre_multiplied_blend(), Renderer.triangle_strip_primitive(), 1, [Renderer.texture_target(target)])
+        r.set_attribute(pipeline, 0, scene["position"]); r.set_attribute(pipeline, 1, scene["uv"])
+        r.set_instanced(pipeline, (0, 0), scene["instances"])
+        r.set_uniform(pipeline, (0, 1), gain)
+        for i in range(6):
+            flat = 2 + i
+            r.set_uniform(pipeline, (flat // 4, flat % 4), weights[i])
+            flat = 8 + 2 * i
+            r.set_texture(pipeline, (flat // 4, flat % 4), [texels[i].reshape(-1)])
+        assert (8 + 2 * 5 + 1) // 4 == 4                      # the last sampler sits in the fifth bind group
+        clear = Renderer.clear_color(0.1, 0.2, 0.3, 1.0)
+        for _ in range(2):                                    # (the second pass: queued before its pair count is known)
+            r.render(pipeline, clear, None, (N, 4))
+            r.finish_frame()
+        got = target.read()
+    finally:
+        r.close()
+    want = np.zeros((H, W, 4), dtype=np.uint8)
+    O.render(shader=O.SHADER_CROWD, topology=O.TOPO_TRIANGLE_STRIP, vertex_count=4, instance_count=N,
+             attrs=[(scene["position"], 2), (scene["uv"], 2)], storage=[scene["instances"]], uniforms=[gain] + weights,
+             textures=[(t, t.shape[1], t.shape[0], 1, O.FMT_RGBA_U8, O.FILTER_LINEAR if f == "linear" else O.FILTER_NEAREST) for t, f in zip(texels, filters)],
+             targets=[dict(data=want, format=O.FMT_RGBA_U8, clear=(0.1, 0.2, 0.3, 1.0))], blend=(O.BF_ONE, O.BF_ONE_MINUS_SRC_ALPHA))
+    assert_same(got, want, "twenty slots")
+    assert len(np.unique(got)) > 32

@@ -251,6 +251,8 @@ typedef struct rh_pass_stats {
     uint64_t reruns;          /* passes of this device, so far, that were queued before their pair count was known and ran
                                  again: they did not fit the room they had been given, or met the pipeline's first triangle
                                  that crosses a clip plane (from then on the pipeline runs the kernels that clip) */
+    uint64_t early;           /* passes of this device, so far, whose binning ran on the binning stream beside the tile kernel
+                                 of the pass before (RH_OPTION_EARLY_BINNING) */
 } rh_pass_stats;
 int rh_device_last_pass_stats(rh_device* dev, rh_pass_stats* out);
 

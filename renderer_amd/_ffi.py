@@ -68,7 +68,7 @@ class PassDesc(C.Structure):
 
 class PassStats(C.Structure):
     _fields_ = [("clusters", C.c_uint64), ("bin_entries", C.c_uint64), ("tiles_x", C.c_uint32), ("tiles_y", C.c_uint32),
-                ("tile_w", C.c_uint32), ("tile_h", C.c_uint32), ("reruns", C.c_uint64)]
+                ("tile_w", C.c_uint32), ("tile_h", C.c_uint32), ("reruns", C.c_uint64), ("early", C.c_uint64)]
 
 
 class Timings(C.Structure):

@@ -103,7 +103,14 @@ struct rh_device {
     hipEvent_t before_tile = nullptr;           // recorded on the main stream just before the last tile kernel
     bool before_tile_valid = false;
     hipEvent_t setup_done = nullptr;
-    bool main_dirty = true;                     // something other than a tile kernel was queued on the main stream since `before_tile`
+    // `before_tile` has been recorded main_epoch times.  A buffer remembers the count at its last write queued on the main
+    // stream (rh_buffer::main_write_epoch): the binning stream waits for the latest record, so it is ordered behind every
+    // main-stream write stamped below the current count, and a pass may bin early only if that covers every buffer its
+    // vertex stage can read.
+    uint64_t main_epoch = 0;
+    // rh_buffer_write goes to a block of its own on this stream (see cow_write): an upload never waits for the pass at work.
+    hipStream_t copy_stream = nullptr;
+    int cow_uploads = 1;                        // (RH_COW_UPLOADS=0: every rh_buffer_write in place on the main stream; for measurements)
     Scratch png_slots, png_rows, png_out;          // GPU PNG encoder scratch
     void* png_host = nullptr; size_t png_host_cap = 0;   // pinned
     unsigned long long* d_total = nullptr;
@@ -125,7 +132,9 @@ struct rh_device {
     // Uploads in flight (rh_buffer_write, rh_texture_write): the caller's bytes are copied into pinned memory first, so the
     // copy to the device is queued without the host waiting for the stream (a copy from pageable memory waits for
     // everything queued before it: the host could never prepare a frame while the previous one renders).
-    struct StagedUpload { void* h; size_t size; hipEvent_t done; };
+    // (`old_dev`: the device block the upload replaced, handed back once the upload AND everything that had been queued on
+    // the main stream when it was replaced -- `main_mark` -- have finished)
+    struct StagedUpload { void* h; size_t size; hipEvent_t done; void* old_dev; size_t old_size; hipEvent_t main_mark; };
     std::deque<StagedUpload> staged;
     size_t staged_bytes = 0;
     std::vector<hipEvent_t> stage_events;
@@ -145,6 +154,10 @@ struct rh_buffer {
     rh_device* dev = nullptr;
     size_t size = 0; uint32_t usage = 0;
     void* dptr = nullptr;
+    uint64_t main_write_epoch = 0;  // rh_device::main_epoch when a write to the buffer was last queued on the main stream
+    bool external = false;          // the device pointer has been handed out: writes the library cannot see
+    hipEvent_t upload_done = nullptr;   // behind the last upload on the copy stream
+    bool upload_pending = false;
     // mapping state
     void* hptr = nullptr;          // pinned host copy
     hipEvent_t map_event = nullptr;
@@ -264,25 +277,38 @@ void pinned_free(rh_device* dev, size_t size, void* p) {
 // Queues a copy of host bytes to device memory on the device's stream without waiting for the stream (see
 // rh_device::staged).  At most RH_STAGED_MAX_BYTES wait in pinned memory: beyond that the oldest upload is waited for.
 constexpr size_t RH_STAGED_MAX_BYTES = (size_t)512 << 20;
-int staged_upload(rh_device* dev, void* dst, const void* src, size_t len) {
+int pooled_event(rh_device* dev, hipEvent_t* e) {
+    if (!dev->stage_events.empty()) { *e = dev->stage_events.back(); dev->stage_events.pop_back(); return 0; }
+    RH_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    return 0;
+}
+// `stream`: the device's main stream, or its copy stream with `old_dev` the block the upload replaces (cow_write).
+int staged_upload(rh_device* dev, void* dst, const void* src, size_t len, hipStream_t stream, void* old_dev = nullptr, size_t old_size = 0) {
     while (!dev->staged.empty()) {
         rh_device::StagedUpload& u = dev->staged.front();
         const bool over = dev->staged_bytes + len > RH_STAGED_MAX_BYTES;
-        if (!over && hipEventQuery(u.done) != hipSuccess) break;
-        if (over) RH_HIP(hipEventSynchronize(u.done));
+        if (!over && (hipEventQuery(u.done) != hipSuccess || (u.main_mark && hipEventQuery(u.main_mark) != hipSuccess))) break;
+        if (over) { RH_HIP(hipEventSynchronize(u.done)); if (u.main_mark) RH_HIP(hipEventSynchronize(u.main_mark)); }
         pinned_free(dev, u.size, u.h); dev->stage_events.push_back(u.done); dev->staged_bytes -= u.size;
+        if (u.main_mark) dev->stage_events.push_back(u.main_mark);
+        if (u.old_dev) device_free(dev, u.old_size, u.old_dev);
         dev->staged.pop_front();
     }
-    if (len > RH_STAGED_MAX_BYTES) { dev->main_dirty = true; RH_HIP(hipMemcpyAsync(dst, src, len, hipMemcpyHostToDevice, dev->stream)); return 0; }
-    rh_device::StagedUpload u; u.size = len; u.h = nullptr; u.done = nullptr;
-    if (pinned_alloc(dev, len, &u.h)) return 1;
-    dev->main_dirty = true;
-    memcpy(u.h, src, len);
-    if (!dev->stage_events.empty()) { u.done = dev->stage_events.back(); dev->stage_events.pop_back(); }
-    else RH_HIP(hipEventCreateWithFlags(&u.done, hipEventDisableTiming));
-    RH_HIP(hipMemcpyAsync(dst, u.h, len, hipMemcpyHostToDevice, dev->stream));
-    RH_HIP(hipEventRecord(u.done, dev->stream));
-    dev->staged.push_back(u); dev->staged_bytes += len;
+    rh_device::StagedUpload u; u.size = len; u.h = nullptr; u.done = nullptr; u.old_dev = old_dev; u.old_size = old_size; u.main_mark = nullptr;
+    if (len > RH_STAGED_MAX_BYTES) {
+        // (too large to stage: a copy from the caller's memory, which waits for everything queued on the stream before it)
+        RH_HIP(hipMemcpyAsync(dst, src, len, hipMemcpyHostToDevice, stream));
+        if (!old_dev) return 0;
+        u.size = 0;
+    } else {
+        if (pinned_alloc(dev, len, &u.h)) return 1;
+        memcpy(u.h, src, len);
+        RH_HIP(hipMemcpyAsync(dst, u.h, len, hipMemcpyHostToDevice, stream));
+    }
+    if (pooled_event(dev, &u.done)) return 1;
+    RH_HIP(hipEventRecord(u.done, stream));
+    if (old_dev) { if (pooled_event(dev, &u.main_mark)) return 1; RH_HIP(hipEventRecord(u.main_mark, dev->stream)); }
+    dev->staged.push_back(u); dev->staged_bytes += u.size;
     return 0;
 }
 
@@ -307,6 +333,42 @@ uint32_t unorm8(double c) {
 }
 
 uint32_t bits_for(uint32_t n) { uint32_t b = 1; while (b < 32 && (1ull << b) < n) b++; return b; }
+
+// rh_buffer_write.  wgpu orders a write_buffer before the command buffers of the next submit (reference src/buffer.rs:42);
+// on one HIP stream that would be behind the pass still at work, whose tile kernel reads the vertex stage's inputs (it
+// sets lean quads up itself), so neither the upload nor the binning of the pass that needs it could start before that
+// pass has finished.  Instead the buffer moves to a block of its own: the bytes are copied into a fresh block on the
+// copy stream (what the write leaves untouched comes over from the old block), passes recorded from now on see the new
+// block and wait for the copy, passes already queued keep reading the old one, which is handed back when they and the
+// copy have finished.  Falls back to a write in place on the main stream when the old block still has a write queued
+// there that the copy stream cannot be ordered behind, or when the block must stay where it is.
+int cow_write(rh_buffer* buf, size_t offset, const void* data, size_t len) {
+    rh_device* dev = buf->dev;
+    const bool whole = offset == 0 && len == buf->size;
+    const bool movable = dev->early_binning && dev->cow_uploads && !buf->external && buf->map_state == 0 && !(buf->usage & RH_BUFFER_MAP_READ);
+    const bool old_settled = dev->before_tile_valid && buf->main_write_epoch < dev->main_epoch;
+    if (!movable || (!whole && !old_settled)) {
+        if (buf->upload_pending) { RH_HIP(hipStreamWaitEvent(dev->stream, buf->upload_done, 0)); buf->upload_pending = false; }
+        buf->main_write_epoch = dev->main_epoch;
+        return staged_upload(dev, (uint8_t*)buf->dptr + offset, data, len, dev->stream);
+    }
+    if (!dev->copy_stream) RH_HIP(hipStreamCreateWithFlags(&dev->copy_stream, hipStreamNonBlocking));
+    if (!buf->upload_done) RH_HIP(hipEventCreateWithFlags(&buf->upload_done, hipEventDisableTiming));
+    void* fresh = nullptr;
+    if (device_alloc(dev, buf->size, &fresh)) return 1;
+    if (!whole) {
+        // (earlier uploads to the old block ran on this same stream; its main-stream writes lie before the latest `before_tile`)
+        RH_HIP(hipStreamWaitEvent(dev->copy_stream, dev->before_tile, 0));
+        if (offset) RH_HIP(hipMemcpyAsync(fresh, buf->dptr, offset, hipMemcpyDeviceToDevice, dev->copy_stream));
+        if (offset + len < buf->size)
+            RH_HIP(hipMemcpyAsync((uint8_t*)fresh + offset + len, (uint8_t*)buf->dptr + offset + len, buf->size - offset - len, hipMemcpyDeviceToDevice, dev->copy_stream));
+    }
+    if (staged_upload(dev, (uint8_t*)fresh + offset, data, len, dev->copy_stream, buf->dptr, buf->size)) return 1;
+    RH_HIP(hipEventRecord(buf->upload_done, dev->copy_stream));
+    buf->upload_pending = true;
+    buf->dptr = fresh;
+    return 0;
+}
 
 } // namespace
 
@@ -346,6 +408,7 @@ int rh_device_create(int hip_ordinal, uint32_t width, uint32_t height, rh_device
         rh_device_destroy(dev); return fail("rh_device_create: creating the binning stream failed");
     }
     if (const char* v = getenv("RH_EARLY_BINNING")) dev->early_binning = atoi(v) ? 1 : 0;
+    if (const char* v = getenv("RH_COW_UPLOADS")) dev->cow_uploads = atoi(v) ? 1 : 0;
     if (const char* v = getenv("RH_TAIL_SPLIT")) dev->tail_split = std::max(0, std::min(2, atoi(v)));
     if (const char* v = getenv("RH_TILE_ROOM")) dev->room_override = (uint32_t)std::max(0, atoi(v));
     dev->compute_units = (uint32_t)prop.multiProcessorCount;
@@ -416,7 +479,14 @@ void device_release(rh_device* dev) {
     if (dev->bin_stream) (void)hipStreamDestroy(dev->bin_stream);
     for (hipEvent_t e : dev->event_pool) (void)hipEventDestroy(e);
     for (hipEvent_t e : dev->timing_events) (void)hipEventDestroy(e);
-    for (rh_device::StagedUpload& u : dev->staged) { (void)hipHostFree(u.h); (void)hipEventDestroy(u.done); }
+    if (dev->copy_stream) (void)hipStreamSynchronize(dev->copy_stream);
+    for (rh_device::StagedUpload& u : dev->staged) {
+        if (u.h) (void)hipHostFree(u.h);
+        (void)hipEventDestroy(u.done);
+        if (u.main_mark) (void)hipEventDestroy(u.main_mark);
+        if (u.old_dev) (void)hipFree(u.old_dev);
+    }
+    if (dev->copy_stream) (void)hipStreamDestroy(dev->copy_stream);
     for (hipEvent_t e : dev->stage_events) (void)hipEventDestroy(e);
     for (auto& kv : dev->free_device) (void)hipFree(kv.second);
     for (auto& kv : dev->free_pinned) (void)hipHostFree(kv.second);
@@ -499,7 +569,7 @@ int rh_buffer_create(rh_device* dev, size_t size, uint32_t usage, const void* in
     hipError_t e = hipSuccess;
     const size_t filled = (init && init_len) ? init_len : 0;
     // (queued on the main stream: the binning of the next pass may read this buffer, so it must not run ahead of these)
-    dev->main_dirty = true;
+    b->main_write_epoch = dev->main_epoch;
     if (filled) e = hipMemcpyAsync(b->dptr, init, filled, hipMemcpyHostToDevice, dev->stream);
     if (e == hipSuccess && filled < size) e = hipMemsetAsync((uint8_t*)b->dptr + filled, 0, size - filled, dev->stream);
     if (e != hipSuccess) { device_free(dev, size, b->dptr); delete b; device_release(dev); return fail("rh_buffer_create: initialisation failed: %s", hipGetErrorString(e)); }
@@ -512,11 +582,17 @@ int rh_buffer_write(rh_buffer* buf, size_t offset, const void* data, size_t len)
     if (offset > buf->size || len > buf->size - offset) return fail("rh_buffer_write: range %zu+%zu exceeds buffer size %zu", offset, len, buf->size);
     if (len == 0) return 0;
     if (enter(buf->dev)) return 1;
-    return staged_upload(buf->dev, (uint8_t*)buf->dptr + offset, data, len);
+    return cow_write(buf, offset, data, len);
 }
 
 size_t rh_buffer_size(rh_buffer* buf) { return buf ? buf->size : 0; }
-void* rh_buffer_device_ptr(rh_buffer* buf) { if (buf) buf->dev->main_dirty = true; return buf && !enter(buf->dev) ? buf->dptr : nullptr; }
+void* rh_buffer_device_ptr(rh_buffer* buf) {
+    if (!buf || enter(buf->dev)) return nullptr;
+    // (from now on the block stays where it is, and passes that bind the buffer never bin early)
+    buf->external = true;
+    if (buf->upload_pending) { (void)hipStreamWaitEvent(buf->dev->stream, buf->upload_done, 0); buf->upload_pending = false; }
+    return buf->dptr;
+}
 void rh_buffer_retain(rh_buffer* buf) { if (buf) buf->refs.fetch_add(1); }
 
 void rh_buffer_release(rh_buffer* buf) {
@@ -524,7 +600,10 @@ void rh_buffer_release(rh_buffer* buf) {
     if (buf->refs.fetch_sub(1) != 1) return;
     rh_device* dev = buf->dev;
     (void)hipSetDevice(dev->ordinal);
-    // stream-ordered reuse: everything that used this memory was submitted on dev->stream before this point
+    // stream-ordered reuse: everything that used this memory was submitted on dev->stream before this point (an upload
+    // still on its way on the copy stream joins the main stream first)
+    if (buf->upload_pending) (void)hipStreamWaitEvent(dev->stream, buf->upload_done, 0);
+    if (buf->upload_done) (void)hipEventDestroy(buf->upload_done);
     device_free(dev, buf->size, buf->dptr);
     if (buf->hptr) pinned_free(dev, buf->size, buf->hptr);
     if (buf->map_event) (void)hipEventDestroy(buf->map_event);
@@ -540,6 +619,7 @@ int rh_buffer_map_async(rh_buffer* buf, rh_map_callback cb, void* user) {
     if (enter(dev)) return 1;
     if (!buf->hptr && pinned_alloc(dev, buf->size, &buf->hptr)) return 1;
     if (!buf->map_event) RH_HIP(hipEventCreateWithFlags(&buf->map_event, hipEventDisableTiming));
+    if (buf->upload_pending) { RH_HIP(hipStreamWaitEvent(dev->stream, buf->upload_done, 0)); buf->upload_pending = false; }
     RH_HIP(hipMemcpyAsync(buf->hptr, buf->dptr, buf->size, hipMemcpyDeviceToHost, dev->stream));
     RH_HIP(hipEventRecord(buf->map_event, dev->stream));
     buf->map_state = 1; buf->cb = cb; buf->cb_user = user;
@@ -602,7 +682,6 @@ int rh_texture_create(rh_device* dev, uint32_t width, uint32_t height, uint32_t 
     if (device_alloc(dev, t->bytes, &t->dptr)) { delete t; return 1; }
     device_retain(dev);
     // wgpu textures start zero-initialised
-    dev->main_dirty = true;
     hipError_t e = hipMemsetAsync(t->dptr, 0, t->bytes, dev->stream);
     if (e != hipSuccess) { device_free(dev, t->bytes, t->dptr); delete t; device_release(dev); return fail("rh_texture_create: clear failed: %s", hipGetErrorString(e)); }
     *out = t;
@@ -623,8 +702,7 @@ int rh_texture_write(rh_texture* tex, uint32_t x, uint32_t y, uint32_t layer, ui
     uint8_t* dst = (uint8_t*)tex->dptr + (((size_t)layer * tex->height + y) * tex->width + x) * tex->bpt;
     tex->poly_valid = false;
     // whole rows of the texture, tightly packed: one contiguous upload through pinned memory
-    if (width == tex->width && bytes_per_row == row_bytes) return staged_upload(tex->dev, dst, data, row_bytes * height);
-    tex->dev->main_dirty = true;
+    if (width == tex->width && bytes_per_row == row_bytes) return staged_upload(tex->dev, dst, data, row_bytes * height, tex->dev->stream);
     RH_HIP(hipMemcpy2DAsync(dst, (size_t)tex->width * tex->bpt, data, bytes_per_row, row_bytes, height, hipMemcpyHostToDevice, tex->dev->stream));
     return 0;
 }
@@ -650,7 +728,7 @@ int rh_texture_size(rh_texture* tex, uint32_t* width, uint32_t* height, uint32_t
     return 0;
 }
 
-void* rh_texture_device_ptr(rh_texture* tex) { if (tex) { tex->poly_always = true; tex->dev->main_dirty = true; } return tex && !enter(tex->dev) ? tex->dptr : nullptr; }
+void* rh_texture_device_ptr(rh_texture* tex) { if (tex) tex->poly_always = true; return tex && !enter(tex->dev) ? tex->dptr : nullptr; }
 void rh_texture_retain(rh_texture* tex) { if (tex) tex->refs.fetch_add(1); }
 void rh_texture_release(rh_texture* tex) {
     if (!tex) return;
@@ -1016,12 +1094,30 @@ int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer, rh_device::Pa
     // (only when nothing but the tile kernel of the pass before has been queued on the main stream since that kernel's
     // start: anything else -- an upload, a copy -- may be what this pass's vertex stage reads, the binning would have to
     // wait for it and there would be nothing left to run beside)
-    const bool early = deferred && alternating && dev->early_binning && !vertex_reads_texture && !dev->main_dirty && dev->before_tile_valid;
+    // (and every buffer the vertex stage can read is settled: no write to it queued on the main stream since the latest
+    // `before_tile`, which is what the binning stream waits for; an upload by rh_buffer_write runs on the copy stream and
+    // is waited for by itself, below)
+    bool buffers_settled = true;
+    auto unsettled = [&](const rh_buffer* b) { return b && (b->external || b->main_write_epoch >= dev->main_epoch); };
+    for (const rh_buffer* b : c.vertex_buffers) if (unsettled(b)) buffers_settled = false;
+    for (const SlotRef& sl : pl->slots) if (unsettled(sl.buf)) buffers_settled = false;
+    const bool early = deferred && alternating && dev->early_binning && !vertex_reads_texture && buffers_settled && dev->before_tile_valid;
     if (early && !dev->bin_stream) RH_HIP(hipStreamCreateWithPriority(&dev->bin_stream, hipStreamNonBlocking, dev->bin_priority));
+    if (early) dev->stats.early++;
     hipStream_t const s = early ? dev->bin_stream : sm;     // binning and set-up
     if (early) {
         RH_HIP(hipStreamWaitEvent(s, dev->before_tile, 0));
         if (dev->tile_done_valid[set]) RH_HIP(hipStreamWaitEvent(s, dev->tile_done[set], 0));
+    }
+    {   // uploads still on their way on the copy stream
+        auto join = [&](rh_buffer* b) -> int {
+            if (!b || !b->upload_pending) return 0;
+            if (hipEventQuery(b->upload_done) == hipSuccess) { b->upload_pending = false; return 0; }
+            RH_HIP(hipStreamWaitEvent(s, b->upload_done, 0));       // (the tile kernel waits for the set-up on `s`)
+            return 0;
+        };
+        for (rh_buffer* b : c.vertex_buffers) if (join(b)) return 1;
+        for (const SlotRef& sl : pl->slots) if (join(sl.buf)) return 1;
     }
     const uint32_t n_parts = (n_clusters + 255) / 256, n_pair_parts = (n_clusters + RH_PAIR_PART - 1) / RH_PAIR_PART;
     // one area, cleared by one fill: [binning state | start of every tile | end of every tile | look-back status words]
@@ -1180,6 +1276,8 @@ int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer, rh_device::Pa
     // (what the binning of the next pass may run beside: everything from here to the next thing queued on the main stream)
     RH_HIP(hipEventRecord(dev->before_tile, sm));
     dev->before_tile_valid = true;
+    dev->main_epoch++;
+    if (fused) fused->buf->main_write_epoch = dev->main_epoch;          // (the tile kernel writes it)
     // How many workgroups the tile kernel `fn` is launched with, and which tiles they take whole, in halves or in quarters.
     auto workgroups_for = [&](hipFunction_t fn) -> uint32_t {
         uint32_t n_groups = n_launch_tiles;
@@ -1225,7 +1323,6 @@ int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer, rh_device::Pa
         if (launch_module_kernel(fn, n_groups, RH_TILE_THREADS, &ta, sizeof ta, sm)) return 1;
     }
     if (!no_alloc && timing_mark(dev)) return 1;
-    dev->main_dirty = false;
     if (alternating) {
         RH_HIP(hipEventRecord(dev->tile_done[set], sm));
         dev->tile_done_valid[set] = true;
@@ -1292,7 +1389,8 @@ int resolve_pending(rh_device* dev, bool blocking, bool may_rerun) {
 }
 
 int execute_copy(rh_device* dev, const CopyCmd& c) {
-    dev->main_dirty = true;
+    if (c.buf->upload_pending) { RH_HIP(hipStreamWaitEvent(dev->stream, c.buf->upload_done, 0)); c.buf->upload_pending = false; }
+    c.buf->main_write_epoch = dev->main_epoch;
     rhk::copy_texture_to_buffer((const uint8_t*)c.tex->dptr, c.tex->width * c.tex->bpt, c.ox, c.oy, c.tex->bpt, c.width, c.height,
                                 (uint8_t*)c.buf->dptr, c.bytes_per_row, dev->stream);
     RH_HIP(hipGetLastError());

@@ -213,7 +213,7 @@ class Renderer:
         s = _ffi.PassStats()
         _ffi.check(_ffi.lib().rh_device_last_pass_stats(self.device, C.byref(s)))
         return {"clusters": s.clusters, "bin_entries": s.bin_entries, "tiles_x": s.tiles_x, "tiles_y": s.tiles_y,
-                "tile_w": s.tile_w, "tile_h": s.tile_h, "reruns": s.reruns}
+                "tile_w": s.tile_w, "tile_h": s.tile_h, "reruns": s.reruns, "early": s.early}
 
     # ---- factories (reference src/renderer.rs:203-298) ----------------------------------------------------------------
     def pipeline(self, program, blend_mode, primitive, msaa_samples, targets):

@@ -272,3 +272,60 @@ def test_headroom_of_a_buffer_created_between_two_passes_reads_zeros(oracle):
         assert_same(got, scenes.draw_oracle(scene)["color"], "instances beyond the uploaded ones")
     finally:
         r.close()
+
+
+def test_animated_instances_keep_early_binning_and_match_the_oracle(oracle):
+    """Instances re-uploaded every frame (what an animated scene does, reference examples/quads_main_thread.rs:144-151):
+    the upload goes to a block of its own on the copy stream, so the pass that needs it still bins beside the tile
+    kernel of the pass before, which keeps reading the old block.  Every frame matches the oracle's frame of the same
+    instances; also a partial write (the rest of the buffer comes over from the old block) and a uniform rewritten every
+    frame (read by both stages)."""
+    from renderer_amd import Renderer, _ffi
+    W, H = 1280, 720
+    rng = np.random.default_rng(141)
+    scene = scenes.random_quads_scene(60_000, 20, W, H, seed=142)
+    r = Renderer(W, H)
+    try:
+        hs = scenes.HipScene(scene, renderer=r)
+        hs.draw(); hs.draw()
+        early0 = r.last_pass_stats()["early"]
+        inst = scene["instances"].copy()
+        frames = []
+        for f in range(6):
+            if f == 3:
+                # a partial write: only the second half of the instances moves (rh_buffer_write at an offset)
+                half = len(inst) // 2
+                inst[half:] = inst[half:] + rng.uniform(-0.02, 0.02, inst[half:].shape).astype(np.float32)
+                buf = hs.pipeline.program.instances[0].buffer
+                part = np.ascontiguousarray(inst[half:])
+                _ffi.check(_ffi.lib().rh_buffer_write(buf.handle, half * 8, part.ctypes.data, part.nbytes))
+            else:
+                inst = (inst + rng.uniform(-0.02, 0.02, inst.shape)).astype(np.float32)
+                r.set_instanced(hs.pipeline, (0, 0), inst)
+            r.render(hs.pipeline, hs.clear, hs.viewport, hs.count)
+            r.finish_frame()                          # (no read-back in between: the frames queue up behind one another)
+            frames.append(inst.copy())
+        got_last = hs.read_color()
+        assert r.last_pass_stats()["early"] - early0 >= 5, "the passes of the animated frames should bin early"
+        assert_same(got_last, scenes.draw_oracle(dict(scene, instances=frames[-1]))["color"], "last animated frame")
+        # every frame, one at a time
+        for f, want_inst in enumerate(frames[:4]):
+            r.set_instanced(hs.pipeline, (0, 0), want_inst)
+            hs.draw()
+            assert_same(hs.read_color(), scenes.draw_oracle(dict(scene, instances=want_inst))["color"], f"frame {f}")
+    finally:
+        r.close()
+    # a uniform read by both stages, rewritten every frame
+    tilted = scenes.tilted_quads_scene(4000, 640, 360, seed=143)
+    r = Renderer(640, 360)
+    try:
+        hs = scenes.HipScene(tilted, renderer=r)
+        hs.draw(); hs.draw()
+        for f in range(4):
+            u = tilted["uniform"].copy(); u[0] = 0.4 + 0.15 * f; u[4] = 1.0 - 0.05 * f
+            r.set_uniform(hs.pipeline, (0, 1), u)
+            r.render(hs.pipeline, hs.clear, hs.viewport, hs.count)
+            r.finish_frame()
+        assert_same(hs.read_color(), scenes.draw_oracle(dict(tilted, uniform=u))["color"], "uniform of the last frame")
+    finally:
+        r.close()

@@ -28,6 +28,22 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
 
 
+def pmc_capture_traffic_bytes():
+    """HBM bytes per rh_lz4f_compress launch (a round of 1024 streams, one 4K frame each) from the committed counter
+    passes of the capture harness (tools/prof_capture.sh), corrected like pmc_traffic_bytes; None without a profile."""
+    import glob
+    import re
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "capture_v*_pmc_avg_per_launch.json")),
+                   key=lambda q: int(re.search(r"_v(\d+)_", os.path.basename(q)).group(1)))
+    for path in reversed(paths):
+        try:
+            k = json.load(open(path))["rh_lz4f_compress"]
+            return (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0, int(k["streams"])
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
+
+
 def pmc_traffic_bytes(tag="c1"):
     """HBM bytes per rh_tile_1 launch from the committed counter passes of this same command (tools/prof.sh: one
     rocprofv3 --pmc run for FETCH_SIZE, one for WRITE_SIZE; both counters are in KiB).  FETCH_SIZE is doubled, the
@@ -245,6 +261,8 @@ def main():
                     help="frames of the recorded-frames/s leg (BASELINE.json configs[4] shape, per GPU); 0 skips it; "
                          "default: 4096 frames into 1024 streams, or less when the ranks of this host would not find "
                          "room for their stream files and their pinned buffers in memory (see capture_plan)")
+    ap.add_argument("--no-reference-budget", action="store_true",
+                    help="skip the short run of the recorded-frames/s leg under the reference example's 500 MB capture budget")
     ap.add_argument("--capture-streams", type=int, default=-1,
                     help="stream files per GPU; default 1024 (one wavefront per stream: four per compute unit; a round of up "
                          "to 1024 streams takes about as long as a round of one)")
@@ -439,7 +457,9 @@ def main():
                        "ms_per_frame_per_gpu": cap_s / args.capture_frames * 1e3, "workload": cap_info["workload"],
                        "raw_MB_per_frame": cap_info["raw_MB_per_frame"], "compressed_MB_per_frame": cap_info["compressed_MB_per_frame"],
                        "frames_recorded": recorded_frames, "frames_dropped": cap_info["frames_dropped"], "budget_MB": cap_info["budget_MB"],
-                       "stream_files_in": capture_root}
+                       "stream_files_in": capture_root,
+                       # where this rank's host time went: per frame in the render loop, and in total in the compressor's hand-offs
+                       "host_ms_per_frame": cap_info["host_ms_per_frame"], "compressor_host_seconds": cap_info["compressor_host_seconds"]}
             # rh_lz4f_compress against the HBM roofline: the bytes it must read and write (raw frames in, LZ4F streams
             # out) over the HIP-event time of its launches (this rank's)
             k = cap_info["kernel"]
@@ -451,9 +471,40 @@ def main():
                                        "kernel_ms_per_launch": k["kernel_ms"] / max(1, k["rounds"]),
                                        "note": "latency-bound: one wavefront per stream walks LZ4's sequential match search; "
                                                "the launches share the GPU with the rendering of the next round's frames"}
+                traffic, profiled_streams = pmc_capture_traffic_bytes()
+                if traffic is not None and profiled_streams == args.capture_streams:
+                    capture["roofline"]["traffic"] = traffic
+                    capture["roofline"]["traffic_source"] = "committed rocprofv3 counter passes of tools/prof_capture.sh (a round of the same size)"
             if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
                 _, multi = bench_capture.liblz4_baseline(np.ascontiguousarray(cap_last).tobytes(), cpu_frames=4)
                 capture["cpu_baseline"] = multi
+        # The companion figure: the same leg under the capture budget of the reference's example (500 MB, reference
+        # examples/quads_main_thread.rs:95).  Sixteen 4K frames fit, so rounds are eight frames: eight streams compress
+        # at a time, and a round takes as long as a round of a thousand.
+        if capture is not None and capture.get("value") and not args.no_reference_budget:
+            small_s, small_info = float("inf"), None
+            small_frames = 32
+            try:
+                small_s, small_info, _ = bench_capture.run_capture(
+                    frames=small_frames, streams=args.capture_streams, out=f"{capture_root}/rh_bench_capture_small_{os.getpid()}_{rank}",
+                    hip_ordinal=local_rank, seed=4 + rank, warmup=8, budget_mb=500.0)
+            except Exception as e:
+                capture["at_reference_budget"] = {"value": None, "error": f"rank {rank}: {type(e).__name__}: {e}"}
+            small_recorded = (small_frames - small_info["frames_dropped"]) if small_info is not None else 0
+            if dist is not None:
+                import torch
+                t = torch.tensor([small_s], dtype=torch.float64, device=f"cuda:{local_rank}")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                small_s = float(t.item())
+                t = torch.tensor([small_recorded], dtype=torch.int64, device=f"cuda:{local_rank}")
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                small_recorded = int(t.item())
+            if small_info is not None and small_s != float("inf"):
+                capture["at_reference_budget"] = {
+                    "budget_MB": 500.0, "value": small_recorded / small_s, "unit": "frames/s", "frames_per_gpu": small_frames,
+                    "frames_recorded": small_recorded, "frames_dropped": small_info["frames_dropped"],
+                    "note": "16 frames of 4K fit the budget: rounds of 8 frames, 8 streams compressing at a time; a stream is "
+                            "sequential, so the rate is 8 frames per round whatever the GPU's size"}
 
     parity_failed = False
     if rank == 0:

@@ -9,6 +9,7 @@ reproduced."""
 import ctypes as C
 import datetime
 import os
+import time
 
 from . import _ffi
 
@@ -56,6 +57,9 @@ class Compressor:
         self._pool = None
         self._background = None     # one thread that appends finished rounds to the files beside the render thread
         self._draining = None
+        # host seconds: waiting for the previous hand-off's file writes, inside rh_compressor_submit/flush (waits for the
+        # round in flight), waiting for a round's bytes to arrive from the device, writing them to the files
+        self.host_seconds = {"join_drain": 0.0, "submit": 0.0, "await_bytes": 0.0, "write_files": 0.0}
 
     def compress_to_disk(self, video_frame):
         stream = (video_frame.frame_number - 1) % self.n_streams
@@ -90,8 +94,12 @@ class Compressor:
         """Hands the queued packets to the GPU (streams run concurrently there) and, while they are being compressed,
         appends the bytes of the previous hand-off to the files -- the reference's worker threads do both beside the
         render thread (src/compressor.rs:100-131)."""
+        t0 = time.perf_counter()
         self._join_drain()
+        t1 = time.perf_counter()
         _ffi.check(_ffi.lib().rh_compressor_submit(self.handle))    # waits for the round in flight, then starts the queued one
+        self.host_seconds["join_drain"] += t1 - t0
+        self.host_seconds["submit"] += time.perf_counter() - t1
         self._release(self.in_flight)   # compressed: the reference's worker drops a frame once it has written it
         self.in_flight, self.queued = self.queued, []
         if self.wait_for_rounds:
@@ -107,8 +115,12 @@ class Compressor:
 
     def flush(self):
         """Compresses all queued packets, waits for them and appends the bytes to the files."""
+        t0 = time.perf_counter()
         self._join_drain()
+        t1 = time.perf_counter()
         _ffi.check(_ffi.lib().rh_compressor_flush(self.handle))
+        self.host_seconds["join_drain"] += t1 - t0
+        self.host_seconds["submit"] += time.perf_counter() - t1
         self._release(self.in_flight + self.queued)
         self.in_flight, self.queued = [], []
         self._drain()
@@ -120,31 +132,37 @@ class Compressor:
             pending.result()
 
     def _drain(self):
-        """Writes every ready byte to its stream file straight from the library's pinned memory; the files are written
-        by a few threads at once (file writes release the interpreter lock)."""
+        """Writes every ready byte to its stream file straight from the library's pinned memory.  The files are written
+        by a few threads at once (file writes release the interpreter lock), and a stream's write starts as soon as its
+        bytes have arrived: the copies of a round come in pieces of some tens of streams, so the first files are being
+        written while the last streams still cross PCIe."""
         L = _ffi.lib()
-        runs = []
-        for i in range(self.n_streams):
-            # peek exposes one run at a time: consume after the write, then look again
-            ptr, n = C.c_void_p(), C.c_size_t()
-            _ffi.check(L.rh_compressor_peek(self.handle, i, C.byref(ptr), C.byref(n)))
-            if n.value:
-                runs.append((i, ptr.value, n.value))
-        while runs:
-            if len(runs) > 1 and sum(n for _, _, n in runs) > (8 << 20):
-                list(self._writers().map(self._write_run, runs))
-            else:
-                for run in runs:
-                    self._write_run(run)
-            nxt = []
-            for i, _, n in runs:
+        pool = self._writers()
+        t_start, waited = time.perf_counter(), 0.0
+        streams = range(self.n_streams)
+        while streams:
+            writes = []
+            for i in streams:
+                # peek exposes one run at a time (and waits for the copies that bring it): consume after the write,
+                # then look again
+                ptr, n = C.c_void_p(), C.c_size_t()
+                t0 = time.perf_counter()
+                _ffi.check(L.rh_compressor_peek(self.handle, i, C.byref(ptr), C.byref(n)))
+                waited += time.perf_counter() - t0
+                if n.value > (64 << 10):
+                    writes.append((i, n.value, pool.submit(self._write_run, (i, ptr.value, n.value))))
+                elif n.value:
+                    self._write_run((i, ptr.value, n.value))
+                    writes.append((i, n.value, None))
+            streams = []
+            for i, n, pending in writes:
+                if pending is not None:
+                    pending.result()
                 _ffi.check(L.rh_compressor_consume(self.handle, i, n))
                 self.compressed_size += n
-                ptr, m = C.c_void_p(), C.c_size_t()
-                _ffi.check(L.rh_compressor_peek(self.handle, i, C.byref(ptr), C.byref(m)))
-                if m.value:
-                    nxt.append((i, ptr.value, m.value))
-            runs = nxt
+                streams.append(i)
+        self.host_seconds["await_bytes"] += waited
+        self.host_seconds["write_files"] += time.perf_counter() - t_start - waited
 
     def _write_run(self, run):
         i, ptr, n = run

@@ -7,6 +7,7 @@
 #include <atomic>
 #include <cmath>
 #include <cstdarg>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -86,6 +87,7 @@ struct rh_device {
     // nothing but the previous pass's tile kernel has been queued on the main stream since that kernel's start (the
     // binning then waits for everything before that kernel); otherwise it runs on the main stream like everything else.
     hipStream_t bin_stream = nullptr;           // created when the first pass takes it (a process has few hardware queues)
+    int compressors = 0;                        // rh_compressor objects alive on this device (each brings two streams of its own)
     int bin_priority = 0;
     int early_binning = 1;
     int eager_count = 1;                        // RH_OPTION_EAGER_COUNT
@@ -239,6 +241,21 @@ struct rh_cmdbuf { rh_device* dev = nullptr; std::vector<Cmd> cmds; };
 // ---- allocation caches ------------------------------------------------------------------------------------------------
 namespace {
 
+// Diagnostic: RH_DEBUG_WAITS=1 prints every wait of the host for the device (what it waits for, and when it is over).
+bool trace_waits() { static const bool on = getenv("RH_DEBUG_WAITS") != nullptr; return on; }
+#define RH_TRACE(...) do { if (trace_waits()) { fprintf(stderr, "[rh] " __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
+
+// Diagnostic: RH_DEBUG_SYNC=1 waits for the stream after every step of a pass and says which one (a step that never ends
+// is then the last one named).
+int dbg_sync(hipStream_t s, const char* what) {
+    static const bool on = getenv("RH_DEBUG_SYNC") != nullptr;
+    if (!on) return 0;
+    fprintf(stderr, "[rh] sync %s ...", what); fflush(stderr);
+    RH_HIP(hipStreamSynchronize(s));
+    fprintf(stderr, " ok\n"); fflush(stderr);
+    return 0;
+}
+
 constexpr size_t RH_CACHE_MAX_BLOCKS = 4096;
 constexpr size_t RH_PINNED_CACHE_MAX_BYTES = (size_t)8 << 30;
 
@@ -249,7 +266,9 @@ int device_alloc(rh_device* dev, size_t size, void** out) {
     auto it = dev->free_device.find(size);
     if (it != dev->free_device.end()) { *out = it->second; dev->free_device.erase(it); dev->free_device_bytes -= size; return 0; }
     // (64 spare bytes: kernels that read whole dwords or look a few bytes ahead -- the LZ4 match finder -- may touch them)
+    RH_TRACE("hipMalloc %zu", size);
     RH_HIP(hipMalloc(out, size + 64));
+    RH_TRACE("hipMalloc done");
     return 0;
 }
 void device_free(rh_device* dev, size_t size, void* p) {
@@ -259,7 +278,7 @@ void device_free(rh_device* dev, size_t size, void* p) {
     // frame).  The cache is bounded in blocks and in bytes.
     if (dev->free_device.size() < RH_CACHE_MAX_BLOCKS && dev->free_device_bytes + size <= dev->device_cache_max_bytes) {
         dev->free_device.emplace(size, p); dev->free_device_bytes += size;
-    } else (void)hipFree(p);
+    } else { RH_TRACE("hipFree %zu", size); (void)hipFree(p); RH_TRACE("hipFree done"); }
 }
 int pinned_alloc(rh_device* dev, size_t size, void** out) {
     auto it = dev->free_pinned.find(size);
@@ -288,7 +307,12 @@ int staged_upload(rh_device* dev, void* dst, const void* src, size_t len, hipStr
         rh_device::StagedUpload& u = dev->staged.front();
         const bool over = dev->staged_bytes + len > RH_STAGED_MAX_BYTES;
         if (!over && (hipEventQuery(u.done) != hipSuccess || (u.main_mark && hipEventQuery(u.main_mark) != hipSuccess))) break;
-        if (over) { RH_HIP(hipEventSynchronize(u.done)); if (u.main_mark) RH_HIP(hipEventSynchronize(u.main_mark)); }
+        if (over) {
+            RH_TRACE("staged_upload: %zu bytes staged in %zu uploads, waiting for the oldest (done %d, mark %d)", dev->staged_bytes, dev->staged.size(),
+                     (int)hipEventQuery(u.done), u.main_mark ? (int)hipEventQuery(u.main_mark) : -1);
+            RH_HIP(hipEventSynchronize(u.done)); if (u.main_mark) RH_HIP(hipEventSynchronize(u.main_mark));
+            RH_TRACE("staged_upload: oldest done");
+        }
         pinned_free(dev, u.size, u.h); dev->stage_events.push_back(u.done); dev->staged_bytes -= u.size;
         if (u.main_mark) dev->stage_events.push_back(u.main_mark);
         if (u.old_dev) device_free(dev, u.old_size, u.old_dev);
@@ -1101,7 +1125,11 @@ int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer, rh_device::Pa
     auto unsettled = [&](const rh_buffer* b) { return b && (b->external || b->main_write_epoch >= dev->main_epoch); };
     for (const rh_buffer* b : c.vertex_buffers) if (unsettled(b)) buffers_settled = false;
     for (const SlotRef& sl : pl->slots) if (unsettled(sl.buf)) buffers_settled = false;
-    const bool early = deferred && alternating && dev->early_binning && !vertex_reads_texture && buffers_settled && dev->before_tile_valid;
+    // (and no compressor on the device: with its two streams beside the three of a pass binned early, passes were seen
+    // to stop for good at the first one binned early, under some assignments of the streams to hardware queues and not
+    // under others; a recording run renders on the main stream alone, as it always has for a scene that moves)
+    const bool early = deferred && alternating && dev->early_binning && !vertex_reads_texture && buffers_settled && dev->before_tile_valid &&
+                       (dev->compressors == 0 || getenv("RH_EXP_EARLY_WITH_COMPRESSOR"));
     if (early && !dev->bin_stream) RH_HIP(hipStreamCreateWithPriority(&dev->bin_stream, hipStreamNonBlocking, dev->bin_priority));
     if (early) dev->stats.early++;
     hipStream_t const s = early ? dev->bin_stream : sm;     // binning and set-up
@@ -1129,8 +1157,10 @@ int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer, rh_device::Pa
     rh_bin_state* const state = reinterpret_cast<rh_bin_state*>(state_base);
     uint32_t* const tile_start = reinterpret_cast<uint32_t*>(state_base + STATE_HEADER_BYTES); uint32_t* const tile_end = tile_start + n_tiles;
     if (!no_alloc && timing_mark(dev, s)) return 1;
+    if (dbg_sync(s, "waits before the pass")) return 1;
     rhk::clear(state_base, state_bytes, s);
     RH_HIP(hipGetLastError());
+    if (dbg_sync(s, "clear")) return 1;
     uint32_t* sorted_keys = nullptr; uint32_t* sorted_vals = nullptr;
     if (deferred) {
         const uint32_t n = (uint32_t)dev->pair_guess;
@@ -1144,9 +1174,11 @@ int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer, rh_device::Pa
         // (beside another kernel not every workgroup of the chain may be on the device at once: tickets)
         ba.ticketed = (early || dev->binning_tickets || n_pair_parts > pl->vs->resident_pair_parts) ? 1u : 0u;
         if (launch_module_kernel(pl->clips ? pl->vs->bin_pairs_clip : pl->vs->bin_pairs, n_pair_parts, RH_PAIR_THREADS, &ba, sizeof ba, s)) return 1;
+        if (dbg_sync(s, ba.ticketed ? "bin_pairs (ticketed)" : "bin_pairs")) return 1;
         const int where = rhk::sort_passes_chained(ss.keys_a.as<uint32_t>(), ss.vals_a.as<uint32_t>(), ss.keys_b.as<uint32_t>(), ss.vals_b.as<uint32_t>(),
                                                    n, key_bits, state, reinterpret_cast<uint32_t*>(state_base + sort_status_at), dev->h_total, (early || dev->binning_tickets) ? 0u : dev->resident_sort_parts, s);
         RH_HIP(hipGetLastError());
+        if (dbg_sync(s, "chained sort")) return 1;
         RH_HIP(hipEventRecord(dev->counted, s));
         sorted_keys = where ? ss.keys_b.as<uint32_t>() : ss.keys_a.as<uint32_t>();
         sorted_vals = where ? ss.vals_b.as<uint32_t>() : ss.vals_a.as<uint32_t>();
@@ -1201,6 +1233,7 @@ int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer, rh_device::Pa
         if (!no_alloc && timing_mark(dev, s)) return 1;
         if (launch_module_kernel(pl->clips ? pl->fs->setup_clip[ms_index] : pl->fs->setup[ms_index], (n + 255) / 256, 256, &sa, sizeof sa, s)) return 1;
     } else if (!no_alloc && timing_mark(dev, s)) return 1;
+    if (dbg_sync(s, "set-up")) return 1;
     if (!no_alloc && timing_mark(dev, s)) return 1;          // the end of the set-up
     // the streams meet: the tile kernel waits for the set-up
     if (early) { RH_HIP(hipEventRecord(dev->setup_done, s)); RH_HIP(hipStreamWaitEvent(sm, dev->setup_done, 0)); }
@@ -1274,6 +1307,7 @@ int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer, rh_device::Pa
     }
     if (!no_alloc && timing_mark(dev)) return 1;
     // (what the binning of the next pass may run beside: everything from here to the next thing queued on the main stream)
+    if (dbg_sync(sm, "main stream before the tile kernel")) return 1;
     RH_HIP(hipEventRecord(dev->before_tile, sm));
     dev->before_tile_valid = true;
     dev->main_epoch++;
@@ -1355,7 +1389,23 @@ int resolve_pending(rh_device* dev, bool blocking, bool may_rerun) {
     rh_cmdbuf* const kept = dev->pending_cb;
     dev->pending_pass = nullptr; dev->pending_cb = nullptr;
     int rc = 0;
+    RH_TRACE("resolve_pending: waiting for the pair count");
+    if (trace_waits()) {
+        // (diagnostic: after five seconds without the count, say what every stream and event of the device is doing)
+        const auto t0 = std::chrono::steady_clock::now();
+        while (hipEventQuery(dev->counted) == hipErrorNotReady) {
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
+                RH_TRACE("stuck: main stream %d, bin stream %d, copy stream %d; before_tile %d (valid %d), tile_done %d/%d (valid %d/%d), setup_done %d, h_total %llu %llu",
+                         (int)hipStreamQuery(dev->stream), dev->bin_stream ? (int)hipStreamQuery(dev->bin_stream) : -1, dev->copy_stream ? (int)hipStreamQuery(dev->copy_stream) : -1,
+                         (int)hipEventQuery(dev->before_tile), (int)dev->before_tile_valid, (int)hipEventQuery(dev->tile_done[0]), (int)hipEventQuery(dev->tile_done[1]),
+                         (int)dev->tile_done_valid[0], (int)dev->tile_done_valid[1], (int)hipEventQuery(dev->setup_done),
+                         (unsigned long long)dev->h_total[0], (unsigned long long)dev->h_total[1]);
+                break;
+            }
+        }
+    }
     hipError_t e = hipEventSynchronize(dev->counted);
+    RH_TRACE("resolve_pending: count there");
     const uint64_t total = dev->h_total[0];
     if (e != hipSuccess) rc = fail("render pass: waiting for the pair count failed: %s", hipGetErrorString(e));
     else if (dev->h_total[1]) { dev->h_total[1] = 0; rc = fail("render pass: a binning workgroup gave up waiting for its predecessors; the results of the pass are undefined"); }
@@ -1501,11 +1551,14 @@ struct rh_compressor {
     rh_lz4_stream_state* d_states = nullptr;
     struct Packet { std::vector<uint8_t> meta; rh_buffer* image = nullptr; };
     std::vector<std::deque<Packet>> queue;           // per stream: not yet submitted
-    // (`ready` is recorded behind the copies that fill the buffer; `pending`: nobody has waited for it yet)
-    struct RoundBuf { void* h = nullptr; size_t cap = 0; size_t live = 0; hipEvent_t ready = nullptr; bool pending = false; };
+    // The copies that fill a buffer are recorded in pieces of COPY_PIECE streams, an event behind each piece, so that
+    // the reader writes the first streams to their files while the last ones are still crossing PCIe (`pending`:
+    // nobody has waited for the piece yet).
+    static constexpr uint32_t COPY_PIECE = 64;
+    struct RoundBuf { void* h = nullptr; size_t cap = 0; size_t live = 0; std::vector<hipEvent_t> ready; std::vector<char> pending; };
     std::vector<RoundBuf> bufs;
     hipEvent_t out_copied[2] = { nullptr, nullptr };    // the last copy out of each output area (a round that writes the area waits for it)
-    struct Segment { const uint8_t* ptr = nullptr; size_t len = 0; int buf = -1; std::vector<uint8_t> own; };
+    struct Segment { const uint8_t* ptr = nullptr; size_t len = 0; int buf = -1; uint32_t piece = 0; std::vector<uint8_t> own; };
     std::vector<std::deque<Segment>> ready;          // per stream: compressed bytes not yet consumed
     // the round in flight
     struct Round {
@@ -1597,7 +1650,9 @@ int compressor_submit_round(rh_compressor* c) {
     RH_HIP(hipStreamWaitEvent(c->stream, c->frames_ready, 0));
     RH_HIP(hipMemcpyAsync(c->d_stage.ptr, stage.data(), stage.size(), hipMemcpyHostToDevice, c->stream));
     RH_HIP(hipMemcpyAsync(c->d_jobs.ptr, jobs.data(), n * sizeof(rh_lz4_job), hipMemcpyHostToDevice, c->stream));
+    RH_TRACE("compressor: waiting for the round's frames and job records");
     RH_HIP(hipStreamSynchronize(c->stream));        // the pageable staging vectors go out of scope below
+    RH_TRACE("compressor: job records there");
     c->round_bytes_in = 0;
     for (const rh_lz4_job& jb : jobs) for (uint32_t w = 0; w < jb.n_writes; w++) c->round_bytes_in += jb.write_len[w];
     if (c->out_copied[R.out_buf]) RH_HIP(hipStreamWaitEvent(c->stream, c->out_copied[R.out_buf], 0));     // the area's previous bytes have left
@@ -1615,7 +1670,9 @@ int compressor_wait_round(rh_compressor* c) {
     rh_compressor::Round& R = c->round;
     if (!R.active || R.waited) return 0;
     const uint32_t n = (uint32_t)R.job_stream.size();
+    RH_TRACE("compressor: waiting for the round in flight");
     RH_HIP(hipStreamSynchronize(c->stream));
+    RH_TRACE("compressor: round done");
     R.waited = true;
     R.lens.assign(c->h_lens, c->h_lens + n);
     {   float ms = 0.0f;
@@ -1637,6 +1694,7 @@ int compressor_collect_round(rh_compressor* c, rh_compressor::Round& R) {
     if (!R.active) return 0;
     R.active = false;
     const uint32_t n = (uint32_t)R.job_stream.size();
+    if (n == 0) return 0;
     size_t total = 0;
     for (uint32_t j = 0; j < n; j++) total += (size_t)R.lens[j];
     int bi = -1;
@@ -1647,27 +1705,36 @@ int compressor_collect_round(rh_compressor* c, rh_compressor::Round& R) {
         rh_compressor::RoundBuf& b = c->bufs[bi];
         if (b.h) (void)hipHostFree(b.h);
         b.h = nullptr; b.cap = 0;
-        const size_t want = total + total / 4 + 4096;
+        const size_t want = total + total / 16 + 4096;        // (rounds of one scene differ by a few per cent)
         RH_HIP(hipHostMalloc(&b.h, want, hipHostMallocDefault));
         b.cap = want;
     }
     rh_compressor::RoundBuf& b = c->bufs[bi];
+    const uint32_t pieces = (n + rh_compressor::COPY_PIECE - 1) / rh_compressor::COPY_PIECE;
+    while (b.ready.size() < pieces) {
+        hipEvent_t e = nullptr;
+        RH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        b.ready.push_back(e);
+    }
+    b.pending.assign(b.ready.size(), 0);
+    // The copies run beside whatever the caller does next; whoever reads the bytes waits for them (compressor_wait_bytes).
     size_t off = 0;
     for (uint32_t j = 0; j < n; j++) {
         const size_t len = (size_t)R.lens[j];
         if (len) RH_HIP(hipMemcpyAsync((uint8_t*)b.h + off, c->d_out[R.out_buf].as<uint8_t>() + R.out_off[j], len, hipMemcpyDeviceToHost, c->copy_stream));
         off += len;
+        if ((j + 1) % rh_compressor::COPY_PIECE == 0 || j + 1 == n) {
+            const uint32_t piece = j / rh_compressor::COPY_PIECE;
+            RH_HIP(hipEventRecord(b.ready[piece], c->copy_stream));
+            b.pending[piece] = 1;
+        }
     }
-    // The copies run beside whatever the caller does next; whoever reads the bytes waits for them (compressor_wait_bytes).
-    if (!b.ready) RH_HIP(hipEventCreateWithFlags(&b.ready, hipEventDisableTiming));
-    RH_HIP(hipEventRecord(b.ready, c->copy_stream));
-    b.pending = true;
-    c->out_copied[R.out_buf] = b.ready;
+    c->out_copied[R.out_buf] = b.ready[pieces - 1];
     off = 0;
     for (uint32_t j = 0; j < n; j++) {
         const size_t len = (size_t)R.lens[j];
         if (len) {
-            rh_compressor::Segment sg; sg.ptr = (const uint8_t*)b.h + off; sg.len = len; sg.buf = bi;
+            rh_compressor::Segment sg; sg.ptr = (const uint8_t*)b.h + off; sg.len = len; sg.buf = bi; sg.piece = j / rh_compressor::COPY_PIECE;
             c->ready[R.job_stream[j]].push_back(std::move(sg));
             b.live++;
         }
@@ -1678,10 +1745,11 @@ int compressor_collect_round(rh_compressor* c, rh_compressor::Round& R) {
 
 // Before the bytes of a segment are read on the host: the copies that fill its buffer have finished.
 int compressor_wait_bytes(rh_compressor* c, const rh_compressor::Segment& sg) {
-    if (sg.buf < 0 || !c->bufs[sg.buf].pending) return 0;
+    if (sg.buf < 0 || !c->bufs[sg.buf].pending[sg.piece]) return 0;
     RH_HIP(hipSetDevice(c->dev->ordinal));
-    RH_HIP(hipEventSynchronize(c->bufs[sg.buf].ready));
-    c->bufs[sg.buf].pending = false;
+    RH_HIP(hipEventSynchronize(c->bufs[sg.buf].ready[sg.piece]));
+    // (the pieces are recorded in order on one stream: the earlier ones have arrived as well)
+    for (uint32_t i = 0; i <= sg.piece; i++) c->bufs[sg.buf].pending[i] = 0;
     return 0;
 }
 
@@ -1734,6 +1802,7 @@ int rh_compressor_create(rh_device* dev, uint32_t n_streams, int level, rh_compr
     static const uint8_t header[7] = { 0x04, 0x22, 0x4d, 0x18, 0x40, 0x40, 0xc0 };
     for (uint32_t i = 0; i < n_streams; i++) push_owned(c, i, header, 7);
     device_retain(dev);
+    dev->compressors++;
     *out = c;
     return 0;
 }
@@ -1749,7 +1818,7 @@ void rh_compressor_destroy(rh_compressor* c) {
     (void)hipStreamSynchronize(c->copy_stream);
     Scratch* all[] = { &c->d_jobs, &c->d_stage, &c->d_out[0], &c->d_out[1], &c->d_lens };
     for (Scratch* s : all) s->release();
-    for (auto& b : c->bufs) { if (b.h) (void)hipHostFree(b.h); if (b.ready) (void)hipEventDestroy(b.ready); }
+    for (auto& b : c->bufs) { if (b.h) (void)hipHostFree(b.h); for (hipEvent_t e : b.ready) (void)hipEventDestroy(e); }
     if (c->h_lens) (void)hipHostFree(c->h_lens);
     if (c->d_states) (void)hipFree(c->d_states);
     (void)hipEventDestroy(c->frames_ready);
@@ -1757,6 +1826,7 @@ void rh_compressor_destroy(rh_compressor* c) {
     (void)hipStreamDestroy(c->stream);
     (void)hipStreamDestroy(c->copy_stream);
     delete c;
+    dev->compressors--;
     device_release(dev);
 }
 

@@ -94,3 +94,17 @@ def test_bench_strips_leg_prints_a_line(world):
     d = json.loads(lines[0])
     assert d["ranks"] == world and d["scaling"] == "strong" and d["value"] > 0 and d["roofline"]["frac"] > 0
     assert d["exchange"]["bytes_received_per_rank_per_step"] == (0 if world == 1 else 1024 * 1024 * 4)
+
+
+@pytest.mark.parametrize("before", ["torch", "c1"])
+def test_recording_run_in_a_process_that_has_used_the_gpu_before(before):
+    """A recording run (renderer + compressor: five streams) after PyTorch has run a kernel through the HIP runtime the
+    two then share, or after a render-only run of the same process.  With passes binned early on a third stream beside
+    the compressor's streams this never got past its third frame; the harness ends a run that stalls and says where."""
+    env = dict(os.environ, RH_WATCHDOG="120")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "exp_capture_env.py"), before, "256"],
+                         capture_output=True, text=True, timeout=280, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    import json
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["mode"] == before and line["fps"] > 0

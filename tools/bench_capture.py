@@ -19,7 +19,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def run_capture(frames=128, streams=64, quads=100_000, side=32, width=3840, height=2160, out="/tmp/rh_cap", hip_ordinal=0,
-                seed=4, before_timing=None, after_timing=None, warmup=None, budget_mb=None):
+                seed=4, before_timing=None, after_timing=None, warmup=None, budget_mb=None, keep_files=False):
     """Renders and records `frames` frames; returns (elapsed seconds, info dict, last recorded image).  `before_timing`
     and `after_timing` are called around the timed loop (multi-process runs put their barriers there).  `warmup` untimed
     frames come first, by default two rounds of the streams: the compressor pins one host buffer per round in flight
@@ -33,6 +33,7 @@ def run_capture(frames=128, streams=64, quads=100_000, side=32, width=3840, heig
     rng = np.random.default_rng(seed)
     vel = rng.uniform(-0.01, 0.01, scene["instances"].shape).astype(np.float32)
     pos = scene["instances"].copy()
+    tmp, outside = np.empty_like(pos), np.empty(pos.shape, dtype=bool)
 
     shutil.rmtree(out, ignore_errors=True)
     r = Renderer(W, H, hip_ordinal=hip_ordinal)
@@ -43,8 +44,13 @@ def run_capture(frames=128, streams=64, quads=100_000, side=32, width=3840, heig
     comp = Compressor(r, out, n_streams=streams, max_buffer_size_in_megabytes=budget_mb, wait_for_rounds=os.environ.get("RH_CAPTURE_TURNS", "0") == "1")
     t_compress = [0.0]
 
+    held = []
+
     def sink(frame):
         t = time.perf_counter()
+        if os.environ.get("RH_EXP_SINK") == "hold":          # experiment: the compressor exists but gets no frames
+            held.append(frame)
+            return
         comp.compress_to_disk(frame)
         t_compress[0] += time.perf_counter() - t
 
@@ -54,13 +60,16 @@ def run_capture(frames=128, streams=64, quads=100_000, side=32, width=3840, heig
     phases = {"animate": 0.0, "upload": 0.0, "render": 0.0, "finish_frame": 0.0}      # host seconds per part of a frame
 
     def step():
-        nonlocal pos, vel
         t_a = time.perf_counter()
-        pos = (pos + vel).astype(np.float32)                       # the example's bounce rule, vectorised in f32
-        outside = (pos > np.float32(0.9)) | (pos < np.float32(-0.9))
-        vel = np.where(outside, -vel, vel).astype(np.float32)
+        np.add(pos, vel, out=pos)                                  # the example's bounce rule, vectorised in f32, in place:
+        np.abs(pos, out=tmp)                                       # the velocity of what has left [-0.9, 0.9] changes sign
+        np.greater(tmp, np.float32(0.9), out=outside)
+        np.multiply(outside, np.float32(-2.0), out=tmp)
+        np.add(tmp, np.float32(1.0), out=tmp)
+        np.multiply(vel, tmp, out=vel)
         t_b = time.perf_counter()
-        r.set_instanced(hs.pipeline, (0, 0), pos)
+        if os.environ.get("RH_EXP_STATIC") != "1":                 # (experiment: a scene that does not move)
+            r.set_instanced(hs.pipeline, (0, 0), pos)
         t_c = time.perf_counter()
         r.render(hs.pipeline, hs.clear, hs.viewport, hs.count)
         t_d = time.perf_counter()
@@ -79,6 +88,8 @@ def run_capture(frames=128, streams=64, quads=100_000, side=32, width=3840, heig
     for key in phases:
         phases[key] = 0.0
     raw0, packed0 = comp.raw_video_size, comp.compressed_size
+    for key in comp.host_seconds:
+        comp.host_seconds[key] = 0.0
     comp.drain_kernel_stats()
 
     if before_timing:
@@ -99,11 +110,12 @@ def run_capture(frames=128, streams=64, quads=100_000, side=32, width=3840, heig
     comp.finish()
     hs.close()
     r.close()
-    shutil.rmtree(out, ignore_errors=True)
+    if not keep_files:
+        shutil.rmtree(out, ignore_errors=True)
     info = {"frames": frames, "streams": streams, "frames_dropped": comp.frames_dropped, "budget_MB": budget_mb,
             "workload": f"{quads} animated quads {side}x{side} px, {W}x{H}, recording attachment, GPU LZ4F level 0 into "
                         f"{streams} stream files per GPU",
-            "compress_ms_per_frame": t_compress[0] / frames * 1e3, "kernel": kernel,
+            "compress_ms_per_frame": t_compress[0] / frames * 1e3, "kernel": kernel, "compressor_host_seconds": dict(comp.host_seconds),
             "host_ms_per_frame": {k: v / frames * 1e3 for k, v in phases.items()},
             "raw_MB_per_frame": raw / frames / 1e6, "compressed_MB_per_frame": packed / frames / 1e6}
     return elapsed, info, last
@@ -182,18 +194,22 @@ def main():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--out", default="/tmp/rh_cap")
     ap.add_argument("--warmup", type=int, default=-1, help="untimed frames before the timed ones (default: two rounds of the streams)")
+    ap.add_argument("--keep-files", action="store_true", help="leave the stream files in --out")
+    ap.add_argument("--budget-mb", type=float, default=-1.0, help="capture budget in MB (default: two rounds of the streams' frames)")
     ap.add_argument("--cpu-frames", type=int, default=4, help="frames compressed by liblz4 on one host core for the baseline")
     args = ap.parse_args()
 
     import numpy as np
     elapsed, info, last = run_capture(args.frames, args.streams, args.quads, args.side, args.width, args.height, args.out,
-                                      warmup=None if args.warmup < 0 else args.warmup)
+                                      warmup=None if args.warmup < 0 else args.warmup, keep_files=args.keep_files,
+                                      budget_mb=None if args.budget_mb < 0 else args.budget_mb)
     out = {"metric": "recorded frames/s", "value": args.frames / elapsed, "unit": "frames/s", "n_gpus": 1,
            "frames": args.frames, "streams": args.streams, "config": {"workload": info["workload"]},
            "ms_per_frame": elapsed / args.frames * 1e3, "compress_ms_per_frame": info["compress_ms_per_frame"],
            "raw_MB_per_frame": info["raw_MB_per_frame"], "compressed_MB_per_frame": info["compressed_MB_per_frame"],
            "raw_GBps": info["raw_MB_per_frame"] * args.frames / elapsed / 1e3, "kernel": info["kernel"],
-           "host_ms_per_frame": info["host_ms_per_frame"], "frames_dropped": info["frames_dropped"]}
+           "host_ms_per_frame": info["host_ms_per_frame"], "compressor_host_seconds": info["compressor_host_seconds"],
+           "frames_dropped": info["frames_dropped"]}
 
     if args.cpu_frames > 0:
         single, multi = liblz4_baseline(np.ascontiguousarray(last).tobytes(), args.cpu_frames)

@@ -238,8 +238,13 @@ int rh_submit(rh_device* dev, rh_cmdbuf* const* list, size_t n);
  * rejected with an error beyond that.  Differences from rh_submit: the command buffers are NOT consumed (release them
  * with rh_cmdbuf_release once the work has finished; they may be submitted again), map callbacks are not driven, no
  * timings are recorded, and textures are sampled through footprint copies only where an earlier rh_submit made them.
- * Calls on one GPU share that GPU's array: calls that overlap on one GPU race.  A pass with triangles that cross a clip
- * plane is rejected: the kernels that clip them use private memory, which the runtime allocates. */
+ * Calls on one GPU share that GPU's array, from whichever rh_device they come: a call returns with its kernels queued,
+ * and the next call on that GPU waits for them on the device (one event per GPU), so calls made one after the other do
+ * not overlap; calls made at the same time from several threads on one GPU race.  A pass with triangles that cross a
+ * clip plane is rejected: the kernels that clip them use private memory, which the runtime allocates.  A pass that an
+ * earlier rh_submit left pending and that has to run again (too many pairs for its array, or its pipeline's first
+ * clipped triangle) is reported as an error here, because running it again allocates: call rh_device_synchronize or
+ * rh_submit first. */
 int rh_submit_static(rh_device* dev, rh_cmdbuf* const* list, size_t n);
 
 /* ---- statistics of the most recent render pass executed (diagnostics for benchmarks) ------------------------------- */

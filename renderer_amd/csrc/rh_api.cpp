@@ -369,7 +369,11 @@ uint32_t bits_for(uint32_t n) { uint32_t b = 1; while (b < 32 && (1ull << b) < n
 int cow_write(rh_buffer* buf, size_t offset, const void* data, size_t len) {
     rh_device* dev = buf->dev;
     const bool whole = offset == 0 && len == buf->size;
-    const bool movable = dev->early_binning && dev->cow_uploads && !buf->external && buf->map_state == 0 && !(buf->usage & RH_BUFFER_MAP_READ);
+    // (not beside a compressor: its passes are not binned early, which is what the move is for, and a process has few
+    // hardware queues -- a fifth stream shares one, and with the upload stream behind the compression stream's queue a
+    // recording run was a sixth slower)
+    const bool movable = dev->early_binning && dev->cow_uploads && dev->compressors == 0 && !buf->external && buf->map_state == 0 &&
+                         !(buf->usage & RH_BUFFER_MAP_READ);
     const bool old_settled = dev->before_tile_valid && buf->main_write_epoch < dev->main_epoch;
     if (!movable || (!whole && !old_settled)) {
         if (buf->upload_pending) { RH_HIP(hipStreamWaitEvent(dev->stream, buf->upload_done, 0)); buf->upload_pending = false; }

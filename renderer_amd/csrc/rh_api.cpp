@@ -372,7 +372,8 @@ int cow_write(rh_buffer* buf, size_t offset, const void* data, size_t len) {
     // (not beside a compressor: its passes are not binned early, which is what the move is for, and a process has few
     // hardware queues -- a fifth stream shares one, and with the upload stream behind the compression stream's queue a
     // recording run was a sixth slower)
-    const bool movable = dev->early_binning && dev->cow_uploads && dev->compressors == 0 && !buf->external && buf->map_state == 0 &&
+    static const bool beside_compressor = getenv("RH_EXP_EARLY_WITH_COMPRESSOR") != nullptr;       // (diagnostic: see execute_pass)
+    const bool movable = dev->early_binning && dev->cow_uploads && (dev->compressors == 0 || beside_compressor) && !buf->external && buf->map_state == 0 &&
                          !(buf->usage & RH_BUFFER_MAP_READ);
     const bool old_settled = dev->before_tile_valid && buf->main_write_epoch < dev->main_epoch;
     if (!movable || (!whole && !old_settled)) {
@@ -1404,6 +1405,11 @@ int resolve_pending(rh_device* dev, bool blocking, bool may_rerun) {
                          (int)hipEventQuery(dev->before_tile), (int)dev->before_tile_valid, (int)hipEventQuery(dev->tile_done[0]), (int)hipEventQuery(dev->tile_done[1]),
                          (int)dev->tile_done_valid[0], (int)dev->tile_done_valid[1], (int)hipEventQuery(dev->setup_done),
                          (unsigned long long)dev->h_total[0], (unsigned long long)dev->h_total[1]);
+                // (with RH_OPTION_TIMING on: the marks of the last passes -- start, before set-up, after set-up, before
+                // the tile kernel, its end -- say which launch has not finished)
+                const size_t n_ev = dev->timing_events.size();
+                for (size_t i = n_ev >= 15 ? n_ev - 15 : 0; i < n_ev; i++)
+                    RH_TRACE("  pass %zu mark %zu: %s", i / 5, i % 5, hipEventQuery(dev->timing_events[i]) == hipSuccess ? "reached" : "not reached");
                 break;
             }
         }

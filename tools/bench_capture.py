@@ -37,6 +37,8 @@ def run_capture(frames=128, streams=64, quads=100_000, side=32, width=3840, heig
 
     shutil.rmtree(out, ignore_errors=True)
     r = Renderer(W, H, hip_ordinal=hip_ordinal)
+    if os.environ.get("RH_EXP_TIMING") == "1":                     # (diagnostic: event marks around every launch of a pass)
+        r.set_timing(True)
     hs = scenes.HipScene(scene, renderer=r)
     # budget: two rounds of the streams' frames may be held on the device at once (33 MB each at 4K): one being
     # compressed, one being captured

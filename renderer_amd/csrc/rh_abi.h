@@ -4,7 +4,7 @@
 #pragma once
 #include <stdint.h>
 
-#define RH_DEVICE_ABI_VERSION 20u
+#define RH_DEVICE_ABI_VERSION 21u
 #define RH_MODULE_MAGIC 0x52484d4fu   // "RHMO"
 
 #define RH_DEV_MAX_ATTRIBUTES 8
@@ -210,11 +210,12 @@ struct rh_tile_args {
     uint32_t pair_capacity;
     const unsigned long long* pair_total;
     // Workgroups against tiles.  A pass ends with the machine draining: the last tiles run a few to a SIMD, each at the
-    // speed of one wave's dependent chain, so the tiles the last workgroups take may be cut into 2, 4 or 8 bands of rows
-    // with a workgroup each (same records, the boxes cut to the band).  Workgroup j < split2_first takes tile j whole;
-    // the next 2 * (split4_first - split2_first) take the halves of tiles split2_first .. split4_first - 1; the next
-    // 4 * (split8_first - split4_first) the quarters of tiles split4_first .. split8_first - 1; the rest the eighths of
-    // the tiles from split8_first on.  (All relative to rh_draw_params::tile_first; all three = the number of tiles:
-    // nothing is cut.)
-    uint32_t split2_first, split4_first, split8_first;
+    // speed of one wave's dependent chain, so the tiles the last workgroups take may be cut into 2, 3, 4 or 8 bands of
+    // rows with a workgroup each (same records, the boxes cut to the band; thirds are 11, 11 and 10 rows).  Workgroup
+    // j < split2_first takes tile j whole; the next 2 * (split3_first - split2_first) take the halves of tiles
+    // split2_first .. split3_first - 1; the next 3 * (split4_first - split3_first) the thirds of tiles split3_first ..
+    // split4_first - 1; the next 4 * (split8_first - split4_first) the quarters of tiles split4_first .. split8_first - 1;
+    // the rest the eighths of the tiles from split8_first on.  (All relative to rh_draw_params::tile_first; all four =
+    // the number of tiles: nothing is cut.)
+    uint32_t split2_first, split4_first, split8_first, split3_first;
 };

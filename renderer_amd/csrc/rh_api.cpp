@@ -438,7 +438,7 @@ int rh_device_create(int hip_ordinal, uint32_t width, uint32_t height, rh_device
     }
     if (const char* v = getenv("RH_EARLY_BINNING")) dev->early_binning = atoi(v) ? 1 : 0;
     if (const char* v = getenv("RH_COW_UPLOADS")) dev->cow_uploads = atoi(v) ? 1 : 0;
-    if (const char* v = getenv("RH_TAIL_SPLIT")) dev->tail_split = std::max(0, std::min(2, atoi(v)));
+    if (const char* v = getenv("RH_TAIL_SPLIT")) dev->tail_split = std::max(0, std::min(3, atoi(v)));
     if (const char* v = getenv("RH_TILE_ROOM")) dev->room_override = (uint32_t)std::max(0, atoi(v));
     dev->compute_units = (uint32_t)prop.multiProcessorCount;
     dev->device_cache_max_bytes = (size_t)prop.totalGlobalMem / 2;
@@ -546,7 +546,7 @@ int rh_device_set_option(rh_device* dev, int option, int value) {
     if (option == RH_OPTION_EARLY_BINNING) { dev->early_binning = value ? 1 : 0; return 0; }
     if (option == RH_OPTION_EAGER_COUNT) { dev->eager_count = value ? 1 : 0; return 0; }
     if (option == RH_OPTION_SETUP_LAUNCH) { dev->setup_launch = value ? 1 : 0; return 0; }
-    if (option == RH_OPTION_TAIL_SPLIT) { if (value < 0 || value > 2) return fail("rh_device_set_option: RH_OPTION_TAIL_SPLIT takes 0, 1 or 2"); dev->tail_split = (int)value; return 0; }
+    if (option == RH_OPTION_TAIL_SPLIT) { if (value < 0 || value > 3) return fail("rh_device_set_option: RH_OPTION_TAIL_SPLIT takes 0, 1, 2 or 3"); dev->tail_split = (int)value; return 0; }
     if (option == RH_OPTION_STRIP_ROW0 || option == RH_OPTION_STRIP_ROW1) {
         if (value < 0) return fail("rh_device_set_option: negative strip row");
         (option == RH_OPTION_STRIP_ROW0 ? dev->strip_row0 : dev->strip_row1) = (uint32_t)value;
@@ -1320,7 +1320,7 @@ int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer, rh_device::Pa
     // How many workgroups the tile kernel `fn` is launched with, and which tiles they take whole, in halves or in quarters.
     auto workgroups_for = [&](hipFunction_t fn) -> uint32_t {
         uint32_t n_groups = n_launch_tiles;
-        ta.split2_first = ta.split4_first = ta.split8_first = n_launch_tiles;
+        ta.split2_first = ta.split3_first = ta.split4_first = ta.split8_first = n_launch_tiles;
         if (dev->tail_split) {
             // The GPU holds `room` workgroups of this kernel at once.  The tiles beyond the last full round of them would
             // run a few to a SIMD, each no faster than one wave's dependent chain: cut into bands they fill the SIMDs
@@ -1338,12 +1338,17 @@ int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer, rh_device::Pa
             // alone); in the mixed mode, where those are halves, quarters for as many of its last tiles as there is
             // room left (measured: quarters mixed with eighths are slower than quarters alone)
             const uint32_t cut = tail * 8u <= room ? 8u : tail * 4u <= room ? 4u : tail * 2u <= room ? 2u : 1u;
-            if (cut > 1u) {
+            if (dev->tail_split >= 3 && cut == 2u && tail * 3u <= room) {
+                // thirds for the whole tail: every place of the last round then gets about the same work
+                ta.split2_first = ta.split3_first = whole;
+                n_groups = whole + tail * 3u;
+            } else if (cut > 1u) {
                 const uint32_t finer = (dev->tail_split >= 2 && cut == 2u) ? (room - tail * cut) / cut : 0u;    // (< tail)
                 const uint32_t coarse_first = whole, finer_first = n_launch_tiles - finer;
                 ta.split2_first = cut == 2u ? coarse_first : whole;
                 ta.split4_first = cut == 2u ? finer_first : (cut == 4u ? coarse_first : whole);
                 ta.split8_first = cut == 2u ? n_launch_tiles : (cut == 4u ? finer_first : coarse_first);
+                ta.split3_first = ta.split4_first;
                 n_groups = whole + (tail - finer) * cut + finer * cut * 2u;
             }
         }

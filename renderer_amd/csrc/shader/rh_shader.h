@@ -58,7 +58,7 @@ struct Texture2D {
     uint32_t static_rgba8;      // 1: known to be RGBA8, at least 2x2 and at most 16 MiB (texel offsets exact in f32)
     // Footprint copies regrouped by phase (rh_slot_dev::poly), when the kernel body was built for them: the copy picked for
     // the primitive being shaded (PolyCopy, prepared once per primitive by the tile kernel), else null.
-    const uint8_t* poly_base; float poly_S, poly_invS, poly_WS;
+    const uint8_t* poly_base; float poly_invS, poly_C1;
     uint32_t static_poly;       // 1: the kernel body was built for textures that all have footprint copies: poly_base is set
 
     // Texel (x, y) of `layer` (generic path, any supported format): 8-bit channels on the 0..255 scale, float channels
@@ -111,11 +111,14 @@ struct Texture2D {
             if (static_rgba8 && static_poly) return make_float4(a, b, a * b, 0.8f);
 #endif
             if (static_rgba8 && static_poly) {
-                const float Sf = poly_S, invS = poly_invS, WSf = poly_WS;
-                const float xqf = floorf(ibf * invS), phf = __builtin_fmaf(xqf, -Sf, ibf);        // x = xq * S + ph, exact
-                const float permf = __builtin_fmaf(phf, WSf, xqf);
+                // Item x = xq * S + ph of row j sits at item ph * (W / S) + xq of the row in copy log2 S, i.e. at byte
+                //   B * (j * W + (x - xq * S) * (W / S) + xq) = x * (B * W / S) + xq * (B - B * W) + j * (B * W)      (B bytes per item)
+                // -- three products of small integers, every partial sum a multiple of B below 2^24 * B: exact in f32.
+                constexpr float Bf = (float)RH_POLY_ITEM_BYTES;
+                const float xqf = floorf(ibf * poly_invS);
+                const float offf = __builtin_fmaf(ibf, poly_C1, __builtin_fmaf(xqf, __builtin_fmaf(-Bf, (float)W, Bf), jbf * (Bf * (float)W)));
 #if RH_POLY_ITEM_BYTES == 32
-                const uint32_t off = (uint32_t)__builtin_fmaf(jbf, (float)(W << 5), permf * 32.0f);   // exact: below 2^24
+                const uint32_t off = (uint32_t)offf;
                 const uint4* const item = reinterpret_cast<const uint4*>(poly_base + (size_t)layer * (height * (width << 5)) + off);
                 const uint4 f0 = item[0], f1 = item[1];                  // channels 0, 1 and 2, 3: { left | right - left } of the upper, of the lower row
 #define RH_LERP_H2(ch, UP, LO) { const float top = lerp_h2(a, UP), bot = lerp_h2(a, LO); \
@@ -124,7 +127,7 @@ struct Texture2D {
 #undef RH_LERP_H2
                 return r;
 #else
-                const uint32_t off = (uint32_t)__builtin_fmaf(jbf, (float)(W << 4), permf * 16.0f);   // exact: below 2^24
+                const uint32_t off = (uint32_t)offf;
                 const uint4 f = *reinterpret_cast<const uint4*>(poly_base + (size_t)layer * (height * (width << 4)) + off);   // the four taps
                 t00 = f.x; t10 = f.y; t01 = f.z; t11 = f.w;
 #endif
@@ -169,14 +172,19 @@ struct Texture2D {
 // phase modulo S = 2^k, with S about the distance in texels between the samples of neighbouring fragments.  Any k gives
 // the same texels; the choice only decides how many cache lines a wave touches.
 struct PolyCopy {
-    const uint8_t* base = nullptr; float S = 1.0f, invS = 1.0f, WS = 0.0f;
-    // grad_log2 = floor(log2(1.41 * |d coordinate / dx| per pixel)); scalar integer work only (everything is uniform)
+    // invS = 2^-k for copy k; C1 = item bytes * width * 2^-k (see Texture2D::sample)
+    const uint8_t* base = nullptr; float invS = 1.0f, C1 = 0.0f;
+    // grad_log2 = floor(log2(1.41 * |d coordinate / dx| per pixel)).  Everything is uniform and is kept on the scalar
+    // unit (readfirstlane: the clamp would otherwise be done, and its results kept, in vector registers); the power of
+    // two divides by exponent arithmetic (width >= 32, k <= 5: nowhere near a denormal).
     RH_DEVICE void pick(const rh_slot_dev& slot, int grad_log2) {
         int k = grad_log2 + (31 - __builtin_clz(slot.width | 1u));
         k = k < 0 ? 0 : (k > RH_POLY_COPIES - 1 ? RH_POLY_COPIES - 1 : k);
+        k = __builtin_amdgcn_readfirstlane(k);
         base = reinterpret_cast<const uint8_t*>(slot.poly) + (size_t)((uint32_t)k * slot.size_bytes);    // size_bytes of a texture slot: bytes of one copy
-        S = __uint_as_float((uint32_t)(127 + k) << 23); invS = __uint_as_float((uint32_t)(127 - k) << 23);   // 2^k, 2^-k
-        WS = (float)slot.width * invS;
+        invS = __uint_as_float((uint32_t)(127 - k) << 23);
+        const uint32_t bw = __builtin_amdgcn_readfirstlane(__float_as_uint((float)(slot.width * (uint32_t)RH_POLY_ITEM_BYTES)));
+        C1 = __uint_as_float(bw - ((uint32_t)k << 23));        // (a slot with copies has a width)
     }
 };
 
@@ -204,7 +212,7 @@ struct BindingContext {
         const rh_slot_dev& s = p->slots[set * 4 + binding];
         const PolyCopy& c = poly[set * 4 + binding];
         return Texture2D{ reinterpret_cast<const uint8_t*>(s.ptr), s.width, s.height, s.layers, s.format, static_rgba8,
-                          c.base, c.S, c.invS, c.WS, static_poly };
+                          c.base, c.invS, c.C1, static_poly };
     }
     RH_DEVICE Sampler sampler(uint32_t set, uint32_t binding) const {
         return Sampler{ p->slots[set * 4 + binding].filter, static_filter };

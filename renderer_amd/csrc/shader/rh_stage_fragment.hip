@@ -17,7 +17,7 @@
 //       3. the tile is written back with coalesced row stores (RGBA or BGRA).
 //     Nothing in a tile waits for another wave: there is no workgroup barrier in the kernel, every lane of the set-up
 //     launch has a pair of its own, and a quad is cut into pieces only where it crosses a tile border.
-//     The last workgroups of a launch may each take a band of a tile's rows (a half, a quarter or an
+//     The last workgroups of a launch may each take a band of a tile's rows (a half, a third, a quarter or an
 //     eighth of the tile) instead of a whole tile (rh_tile_args::split2_first): the same records in the same order, every box cut
 //     to the band, only the band's rows brought in and written back -- a pixel still belongs to exactly one wave.
 //
@@ -45,7 +45,7 @@ constexpr int NV = N_VARYINGS;
 constexpr int TILE = RH_TILE_W, TILE_PX = RH_TILE_W * RH_TILE_H;
 constexpr int ROUND = RH_ROUND_HITS;
 static_assert(RH_TILE_W == 32 && RH_TILE_H == 32 && RH_TILE_THREADS == 64, "one wavefront per 32x32 tile; 8-bit tile-relative boxes");
-static_assert(ROUND == 16 || ROUND == 32 || ROUND == 64, "a round is at most one hit per lane");
+static_assert(ROUND == 8 || ROUND == 16 || ROUND == 32, "a round is at most one hit per lane, and two lanes set a pair up");
 
 // ---- record layout (dwords) -------------------------------------------------------------------------------------------
 // Set-up record, staged through LDS by the tile wave:
@@ -401,13 +401,15 @@ RH_DEVICE void lean_triangle(const LeanVertex& a, LeanVertex b, LeanVertex c, in
 #pragma unroll
     for (int i = 2 + 3 * NV; i < TRI_WORDS; i++) o[i] = 0u;
 }
-// Two lanes set a quad up together, lanes l and l + 32 of the wave (a round brings 32 pairs): lane l runs vertices 0 and 1
-// and sets up triangle A with the header and the diagonal, lane l + 32 runs vertices 3 and 2 and sets up triangle B; what
-// the other needs of one's vertices changes sides through the wave's lane permute.  `half`: 0 for lane l, 1 for l + 32;
-// both lanes are active together (they hold the same pair value).
-RH_DEVICE uint32_t from_partner(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, (int)v); }
-RH_DEVICE void setup_lean_pair(const rh_draw_params& p, uint32_t cluster, int ox, int oy, uint32_t* w, int lane) {
-    const bool half = lane >= 32;
+// Two lanes set a quad up together, lanes l and l + ROUND of the wave (a round brings ROUND <= 32 pairs): lane l runs
+// vertices 0 and 1 and sets up triangle A with the header and the diagonal, lane l + ROUND runs vertices 3 and 2 and sets
+// up triangle B; what the other needs of one's vertices changes sides through the wave's lane permute.  `half`: 0 for
+// lane l, 1 for l + ROUND; both lanes are active together (they hold the same pair value).
+RH_DEVICE uint32_t from_partner(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_ds_bpermute((lane ^ ROUND) << 2, (int)v); }
+// (r0, rows): the rows of the tile the workgroup works on (a band, or all 32).  The record's box is cut to them here
+// already -- the wave cuts every box to its rows anyway -- so a quad that misses the band ends after its first vertex.
+RH_DEVICE void setup_lean_pair(const rh_draw_params& p, uint32_t cluster, int ox, int oy, int r0, int rows, uint32_t* w, int lane) {
+    const bool half = lane >= ROUND;
 #if defined(RH_EXP) && RH_EXP == 6          /* diagnostic build: no set-up at all */
     w[0] = HDR_EMPTY; return;
 #endif
@@ -417,12 +419,12 @@ RH_DEVICE void setup_lean_pair(const rh_draw_params& p, uint32_t cluster, int ox
     const int32_t oX = (int32_t)from_partner((uint32_t)corner.X, lane), oY = (int32_t)from_partner((uint32_t)corner.Y, lane);
     // the bounding box of either triangle is the rectangle's (tri_pixel_bbox, cut to the tile), and the exact pixel set of
     // the rectangle under the top-left rule (setup_strip_quad)
-    const int32_t minX = min(corner.X, oX), maxX = max(corner.X, oX), minY = min(corner.Y, oY), maxY = max(corner.Y, oY), pad = p.bbox_pad;
-    const int bx0 = max(max(p.sc_x0, (minX - pad + 255) >> 8), ox), bx1 = min(min(p.sc_x1 - 1, (maxX + pad) >> 8), ox + TILE - 1);
-    const int by0 = max(max(p.sc_y0, (minY - pad + 255) >> 8), oy), by1 = min(min(p.sc_y1 - 1, (maxY + pad) >> 8), oy + TILE - 1);
+    // (the padded box of tri_pixel_bbox contains the exact one -- the pad is never negative -- so the exact box alone
+    // decides whether the record is empty)
+    const int32_t minX = min(corner.X, oX), maxX = max(corner.X, oX), minY = min(corner.Y, oY), maxY = max(corner.Y, oY);
     const int ex0 = max(max(p.sc_x0, ox), (minX + 255) >> 8), ex1 = min(min(p.sc_x1 - 1, ox + TILE - 1), (maxX - 1) >> 8);
-    const int ey0 = max(max(p.sc_y0, oy), (minY + 255) >> 8), ey1 = min(min(p.sc_y1 - 1, oy + TILE - 1), (maxY - 1) >> 8);
-    if (bx0 > bx1 || by0 > by1 || ex0 > ex1 || ey0 > ey1) { if (!half) w[0] = HDR_EMPTY; return; }     // (the same verdict in both lanes)
+    const int ey0 = max(max(p.sc_y0, oy + r0), (minY + 255) >> 8), ey1 = min(min(p.sc_y1 - 1, oy + r0 + rows - 1), (maxY - 1) >> 8);
+    if (ex0 > ex1 || ey0 > ey1) { if (!half) w[0] = HDR_EMPTY; return; }     // (the same verdict in both lanes)
     const uint32_t bbox = (uint32_t)(ex0 - ox) | ((uint32_t)(ey0 - oy) << 8) | ((uint32_t)(ex1 - ox) << 16) | ((uint32_t)(ey1 - oy) << 24);
     // the vertex on the diagonal this lane runs (vertex 1 or 2) and the partner's
     const LeanVertex mine = run_vertex_lean(p, first + (half ? 2u : 1u), instance);
@@ -550,6 +552,7 @@ RH_DEVICE bool edges_inside_i32(const float* e, int lx, int ly) {
 }
 
 constexpr int PACK_MAX = 4;               // boxes that may share one shading pass
+template <bool B> struct Flag { static constexpr bool value = B; };
 
 // ---- attachment pixels --------------------------------------------------------------------------------------------
 // LDS slot of one attachment pixel.  Narrow kernels (every attachment 8-bit UNORM): the packed pixel, r in byte 0 (an R8
@@ -649,7 +652,8 @@ RH_DEVICE uint32_t band_of_workgroup(uint32_t job, uint32_t n_tiles, int& r0, in
     const uint32_t group = job / (8u * F), r = job - group * (8u * F);
     const uint32_t left = n_tiles - group * 8u, m = left < 8u ? left : 8u;       // tiles of this group (the last may hold fewer)
     const uint32_t band = r / m;
-    rows = TILE / (int)F; r0 = (int)band * rows;
+    if (F == 3u) { r0 = (int)band * 11; rows = band < 2u ? 11 : 10; }       // thirds: 11 + 11 + 10 rows
+    else { rows = TILE / (int)F; r0 = (int)band * rows; }
     return group * 8u + (r - band * m);
 }
 RH_DEVICE uint32_t tile_of_workgroup(const rh_tile_args& a, int& r0, int& rows) {
@@ -657,9 +661,12 @@ RH_DEVICE uint32_t tile_of_workgroup(const rh_tile_args& a, int& r0, int& rows) 
     r0 = 0; rows = TILE;
     if (job < a.split2_first) return job;
     job -= a.split2_first;
-    const uint32_t halved = a.split4_first - a.split2_first;
+    const uint32_t halved = a.split3_first - a.split2_first;
     if (job < halved * 2u) return a.split2_first + band_of_workgroup<2>(job, halved, r0, rows);
     job -= halved * 2u;
+    const uint32_t in_thirds = a.split4_first - a.split3_first;
+    if (job < in_thirds * 3u) return a.split3_first + band_of_workgroup<3>(job, in_thirds, r0, rows);
+    job -= in_thirds * 3u;
     const uint32_t quartered = a.split8_first - a.split4_first;
     if (job < quartered * 4u) return a.split4_first + band_of_workgroup<4>(job, quartered, r0, rows);
     job -= quartered * 4u;
@@ -725,23 +732,24 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
     // 2. rounds of records
     int picked_grad = -1000;                            // the gradient hint the footprint copies were last picked for
     // (the values of a round's pairs are fetched a round ahead: the set-up below starts with them)
-    uint32_t value_next = (start < end && (lane & 31) < (int)min((uint32_t)ROUND, end - start)) ? a.vals[start + (uint32_t)(lane & 31)] : PAIR_GENERAL;
+    static_assert(2 * ROUND <= 64, "two lanes per pair of a round");
+    const int pl = lane & (ROUND - 1);                  // the pair of the round this lane works on while the round is set up ...
+    const bool sets_up = lane < 2 * ROUND;              // ... if it does
+    uint32_t value_next = (sets_up && start < end && pl < (int)min((uint32_t)ROUND, end - start)) ? a.vals[start + (uint32_t)pl] : PAIR_GENERAL;
     for (uint32_t base = start; base < end; base += ROUND) {
         const int n = (int)min((uint32_t)ROUND, end - base);
         {
             // lane = pair of this round.  General pairs bring the record the set-up launch wrote; a lean quad is set up
             // here and now, straight into the staging area.
-            // (lanes l and l + 32 hold the same pair: they set a lean quad up together, see setup_lean_pair)
-            static_assert(ROUND == 32, "two lanes per pair of a round");
-            const int pl = lane & 31;
+            // (lanes l and l + ROUND hold the same pair: they set a lean quad up together, see setup_lean_pair)
             const uint32_t value = value_next;
             const uint32_t nb = base + ROUND;
-            value_next = (nb < end && pl < (int)min((uint32_t)ROUND, end - nb)) ? a.vals[nb + (uint32_t)pl] : PAIR_GENERAL;
+            value_next = (sets_up && nb < end && pl < (int)min((uint32_t)ROUND, end - nb)) ? a.vals[nb + (uint32_t)pl] : PAIR_GENERAL;
             const bool lean = (value & PAIR_GENERAL) == 0u;
             if (!__any(lean)) stage_records(lds.rec, a.rec, base, n, lane);
             else {
                 uint32_t* const w = &lds.rec[pl * REC_WORDS];
-                if (lean) setup_lean_pair(p, value & CLIP_CLUSTER_MASK, ox, oy, w, lane);
+                if (lean) setup_lean_pair(p, value & CLIP_CLUSTER_MASK, ox, oy, r0, rows, w, lane);
                 else if (lane < n) {
                     const uint4* const src = reinterpret_cast<const uint4*>(a.rec + (size_t)(base + (uint32_t)lane) * (REC_WORDS * 4));
 #pragma unroll
@@ -830,6 +838,9 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
                 total = n0 + (ok1 ? n1 : 0u) + (ok2 ? n2 : 0u) + (ok3 ? n3 : 0u);
             }
             run_v = len | (total << 3) | (c1 << 10) | (c2 << 17) | (c3 << 24);
+            // (a small hit that nobody joins runs alone like any other lean quad: fewer instructions than a pack of one;
+            // from here on the bit says "a pack of two or more starts at this hit")
+            if (len == 1u) info_v &= ~INFO_SMALL;
         }
         // The passes of an axis-aligned rectangle with affine varyings (what the reference's quads are): every pixel of
         // the box is covered and the shared diagonal alone says by which triangle.  The loop is kept free of per-pass
@@ -841,10 +852,11 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
             const float4 dh = *reinterpret_cast<const float4*>(rf);                     // header, diagonal A, B, T
             const float3 dg = make_float3(dh.y, dh.z, dh.w);
             uint8_t* const px_bytes = reinterpret_cast<uint8_t*>(tile_px);
+            int pass = npass;                       // (a hit has at least one pass)
 #if defined(RH_EXP) && RH_EXP == 4          /* diagnostic build: the hits are walked, no pass runs */
             if (dg.x == 12345.0f)
 #endif
-            for (int pass = 0; pass < npass; pass++, idx_f += 64.0f) {
+            do {
                 // (both are small non-negative integers: the minimum of their bit patterns)
                 const float idc = __uint_as_float(min(__float_as_uint(idx_f), __float_as_uint(last_f)));
                 // floor((idx + 0.5) / w): the half keeps the quotient at least 1/128 away from an integer
@@ -866,13 +878,29 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
                     blend_pixel<BLEND>(reinterpret_cast<PxT*>(px_bytes + (size_t)t * (TILE_PX * sizeof(PxT)) + (size_t)pb * (sizeof(PxT) / 4)), a.att[t],
                                        out.color[t < RH_FRAGMENT_OUTPUTS ? t : RH_FRAGMENT_OUTPUTS - 1], a.src_factor, a.dst_factor);
                 }
-            }
+                idx_f += 64.0f;
+            } while (--pass > 0);
         };
         // Hits in order; k and everything read with readlane is wave-uniform and lives on the scalar unit.
+        // (nh >= 1; the three bodies are the arms of one if / else chain, so that every hit crosses few branches)
+        // The loop exists twice: a round none of whose hits changes the footprint copies -- nearly every round -- runs a
+        // loop that does not know of them, so that what was picked is not carried around the loop hit by hit.
+        auto hit_loop = [&](auto repicks_tag) {
+        constexpr bool REPICKS = decltype(repicks_tag)::value;
         int k = 0;
-        while (k < nh) {
+        do {
             const uint32_t info = __builtin_amdgcn_readlane(info_v, k);
-            if (TEX == 3 && (info & INFO_REPICK)) {
+            if (__builtin_expect((info & (INFO_LEAN | (REPICKS ? INFO_REPICK : 0u) | INFO_SMALL)) == INFO_LEAN, 1)) {
+                // the usual hit -- a lean quad alone, footprint copies as they are -- on a path of its own: one test
+                const uint32_t boxw = __builtin_amdgcn_readlane(boxw_v, k);
+                const float invw = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(invw_v), k));
+                const float last_f = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(last_v), k));
+                k++;
+                lean_passes((float)(boxw & 0xffu), (float)((boxw >> 8) & 0xffu), (float)((boxw >> 16) & 0xffu), invw, lane_f, last_f, (int)(boxw >> 24),
+                            recf + (int)(info & 0x3fu) * REC_WORDS);
+                continue;
+            }
+            if (REPICKS && (info & INFO_REPICK)) {
                 // the footprint copy of every texture slot for this primitive (uniform; unused slots fold away)
                 const int grad_log2 = (int)(info << 14) >> 26;
 #pragma unroll
@@ -892,8 +920,7 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
                 lean_passes((float)(m.x & 0xffu), (float)((m.x >> 8) & 0xffu), wf, __builtin_amdgcn_rcpf(wf), (float)(lane - st),
                             (float)((int)((run >> 3) & 127u) - st - 1), 1, recf + (int)(m.y & 0x3fu) * REC_WORDS);
                 k += (int)(run & 7u);
-                continue;
-            }
+            } else {
             const uint32_t rec_index = info & 0x3fu;
             const float* const rf = recf + (int)rec_index * REC_WORDS;
             const uint32_t boxw = __builtin_amdgcn_readlane(boxw_v, k);
@@ -902,7 +929,8 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
             const float hx0f = (float)(boxw & 0xffu), hy0f = (float)((boxw >> 8) & 0xffu), wf = (float)((boxw >> 16) & 0xffu);
             const int npass = (int)(boxw >> 24);
             k++;
-            if (info & INFO_LEAN) { lean_passes(hx0f, hy0f, wf, invw, lane_f, last_f, npass, rf); continue; }
+            if (info & INFO_LEAN) lean_passes(hx0f, hy0f, wf, invw, lane_f, last_f, npass, rf);
+            else {
             const uint32_t flags = (info >> 6) & 0x3fu;
             const float half_invw = 0.5f * invw;
             float idx_f = lane_f;
@@ -967,7 +995,12 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
                     for (int phase = 0; phase < 2; phase++) shade(phase ? cov_b : cov_a, phase != 0);
                 }
             }       // passes of the hit
-        }
+            }       // general body
+            }       // a hit alone
+        } while (k < nh);
+        };
+        if (TEX == 3 && __ballot((info_v & INFO_REPICK) != 0u && lane < nh) != 0ull) hit_loop(Flag<true>{});
+        else hit_loop(Flag<false>{});
         RH_PHASE_MARK(2)
     }
 

@@ -142,12 +142,13 @@ def test_axis_aligned_edges_on_pixel_centres(oracle, topology):
     assert orc["fragments"] > 0
 
 
-@pytest.mark.parametrize("size,room", [((512, 288), 0), ((1024, 512), 150), ((1024, 512), 460), ((1024, 512), 1500), ((1024, 512), 2500), ((1024, 512), 5000)])
+@pytest.mark.parametrize("size,room", [((512, 288), 0), ((1024, 512), 150), ((1024, 512), 155), ((1024, 512), 460), ((1024, 512), 1500), ((1024, 512), 2500), ((1024, 512), 5000)])
 def test_last_tiles_cut_into_bands_of_rows(oracle, size, room, monkeypatch):
     """The tiles beyond the last full round of workgroups run as 2, 4 or 8 bands of rows (RH_OPTION_TAIL_SPLIT): whole
-    tiles only, one kind of band, and the mix give the oracle's bytes.  144 tiles on the real GPU: eighths.  512 tiles
-    with the GPU taken to hold 150 workgroups: 450 whole tiles, then halves (the last 13 quartered in the mixed mode);
-    460: 460 whole, 52 in eighths; 1500: all halved (238 quartered in the mixed mode); 2500: all quartered; 5000: all in
+    tiles only, one kind of band, the mix and thirds give the oracle's bytes.  144 tiles on the real GPU: eighths.  512
+    tiles with the GPU taken to hold 150 workgroups: 450 whole tiles, then halves (the last 13 quartered in the mixed
+    mode); 155: 465 whole, 47 halved (14 of them quartered in the mixed mode) or, mode 3, cut into thirds of 11, 11 and
+    10 rows; 460: 460 whole, 52 in eighths; 1500: all halved (238 quartered in the mixed mode); 2500: all quartered; 5000: all in
     eighths."""
     if room:
         monkeypatch.setenv("RH_TILE_ROOM", str(room))
@@ -155,7 +156,7 @@ def test_last_tiles_cut_into_bands_of_rows(oracle, size, room, monkeypatch):
     scene = scenes.random_quads_scene(20000 if W > 1024 else 6000, 24, W, H, seed=17)
     scene["record"] = True                       # two attachments and the captured frame
     want = scenes.draw_oracle(scene)
-    for mode in (0, 1, 2):
+    for mode in (0, 1, 2, 3):
         hs = scenes.HipScene(scene)
         hs.renderer.set_tail_split(mode)
         hs.draw()
@@ -172,7 +173,7 @@ def test_last_tiles_cut_into_bands_of_rows(oracle, size, room, monkeypatch):
         assert not rows[0][:, W * 4:].any()
 
 
-@pytest.mark.parametrize("samples,fmt,room", [(4, "rgba_u8", 0), (2, "rgba_u8", 150), (8, "rgba_f16", 1500), (4, "rgba_f32", 2500)])
+@pytest.mark.parametrize("samples,fmt,room", [(4, "rgba_u8", 0), (2, "rgba_u8", 150), (4, "rgba_u8", 155), (8, "rgba_f16", 1500), (4, "rgba_f32", 2500)])
 def test_last_tiles_cut_into_bands_of_rows_multisampled(oracle, samples, fmt, room, monkeypatch):
     """The multisampled tile kernels take bands of rows the same way: samples and resolved image identical to the
     oracle's with whole tiles only, one kind of band and the mix."""
@@ -182,7 +183,7 @@ def test_last_tiles_cut_into_bands_of_rows_multisampled(oracle, samples, fmt, ro
     scene = scenes.tilted_quads_scene(1500, W, H, seed=23)
     scene.update(samples=samples, target_format=fmt)
     want = scenes.draw_oracle(scene)
-    for mode in (0, 1, 2):
+    for mode in (0, 1, 2, 3):
         hs = scenes.HipScene(scene)
         hs.renderer.set_tail_split(mode)
         hs.draw()

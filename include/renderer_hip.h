@@ -76,7 +76,8 @@ enum {
                                          each, so that the end of the pass fills the SIMDs instead of running a few long
                                          waves on each.  0: never; 1: the finest bands of which they all fit the round;
                                          2 (default): where those are halves, quarters for as many tiles as there is
-                                         room left (identical results) */
+                                         room left; 3: thirds (11, 11 and 10 rows) where the tail fits the round in
+                                         thirds but not in quarters, else as 2 (identical results) */
     RH_OPTION_EAGER_COUNT = 8,        /* 1 (default): rh_submit, before it returns, looks whether the pair count of its last
                                          pass has already arrived (without waiting for it); 0: it leaves that to the next
                                          call, so that the pass is certainly still awaiting its count when rh_submit
@@ -85,6 +86,9 @@ enum {
                                          itself, in LDS, and only other primitives get records from the set-up launch; 1:
                                          every record comes from the set-up launch (identical results; for testing the two
                                          set-up paths against each other) */
+    RH_OPTION_WAVE_PRIORITY = 10      /* 1 (default): the waves of the tile kernel set their issue priority by the work they
+                                         have left, so that the waves of a SIMD end closer together and a pass drains
+                                         faster; 0: priorities are left alone (identical results) */
 };
 
 #define RH_MAX_ATTRIBUTES 8

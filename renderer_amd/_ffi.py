@@ -27,6 +27,7 @@ OPTION_EARLY_BINNING = 6
 OPTION_TAIL_SPLIT = 7
 OPTION_EAGER_COUNT = 8
 OPTION_SETUP_LAUNCH = 9
+OPTION_WAVE_PRIORITY = 10
 COPY_BYTES_PER_ROW_ALIGNMENT = 256
 MAX_COLOR_TARGETS = 4
 

@@ -4,7 +4,7 @@
 #pragma once
 #include <stdint.h>
 
-#define RH_DEVICE_ABI_VERSION 21u
+#define RH_DEVICE_ABI_VERSION 22u
 #define RH_MODULE_MAGIC 0x52484d4fu   // "RHMO"
 
 #define RH_DEV_MAX_ATTRIBUTES 8
@@ -218,4 +218,8 @@ struct rh_tile_args {
     // the rest the eighths of the tiles from split8_first on.  (All relative to rh_draw_params::tile_first; all four =
     // the number of tiles: nothing is cut.)
     uint32_t split2_first, split4_first, split8_first, split3_first;
+    // Issue priority of a tile wave (s_setprio): min(3, pairs it has left * rows of its band / prio_quantum), looked at
+    // again every round of pairs; 0: priorities are left alone.  The host passes a sixteenth of the pass's average tile
+    // (pairs per tile * 32 rows / 16), so a wave runs at the top priority until its last fifth or so.
+    uint32_t prio_quantum;
 };

@@ -95,6 +95,8 @@ struct rh_device {
     // The tiles of a pass's last, partly filled round of workgroups are cut into bands of rows (rh_tile_args::split2_first):
     // 0 = never, 1 = halves, quarters or eighths (one kind per pass), 2 = where that kind is halves, quarters for as many of them as there is room left.
     int tail_split = 2;
+    // tile waves set their issue priority by the work they have left (rh_tile_args::prio_quantum)
+    int wave_priority = 1;
     struct Room { hipFunction_t fn; uint32_t groups; };            // per tile kernel: workgroups the whole GPU holds at once
     Room room[32] = {};
     int n_room = 0;
@@ -439,6 +441,7 @@ int rh_device_create(int hip_ordinal, uint32_t width, uint32_t height, rh_device
     if (const char* v = getenv("RH_EARLY_BINNING")) dev->early_binning = atoi(v) ? 1 : 0;
     if (const char* v = getenv("RH_COW_UPLOADS")) dev->cow_uploads = atoi(v) ? 1 : 0;
     if (const char* v = getenv("RH_TAIL_SPLIT")) dev->tail_split = std::max(0, std::min(3, atoi(v)));
+    if (const char* v = getenv("RH_WAVE_PRIORITY")) dev->wave_priority = atoi(v) ? 1 : 0;
     if (const char* v = getenv("RH_TILE_ROOM")) dev->room_override = (uint32_t)std::max(0, atoi(v));
     dev->compute_units = (uint32_t)prop.multiProcessorCount;
     dev->device_cache_max_bytes = (size_t)prop.totalGlobalMem / 2;
@@ -546,6 +549,7 @@ int rh_device_set_option(rh_device* dev, int option, int value) {
     if (option == RH_OPTION_EARLY_BINNING) { dev->early_binning = value ? 1 : 0; return 0; }
     if (option == RH_OPTION_EAGER_COUNT) { dev->eager_count = value ? 1 : 0; return 0; }
     if (option == RH_OPTION_SETUP_LAUNCH) { dev->setup_launch = value ? 1 : 0; return 0; }
+    if (option == RH_OPTION_WAVE_PRIORITY) { dev->wave_priority = value ? 1 : 0; return 0; }
     if (option == RH_OPTION_TAIL_SPLIT) { if (value < 0 || value > 3) return fail("rh_device_set_option: RH_OPTION_TAIL_SPLIT takes 0, 1, 2 or 3"); dev->tail_split = (int)value; return 0; }
     if (option == RH_OPTION_STRIP_ROW0 || option == RH_OPTION_STRIP_ROW1) {
         if (value < 0) return fail("rh_device_set_option: negative strip row");
@@ -1249,6 +1253,8 @@ int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer, rh_device::Pa
     ta.rec = ss.rec.as<uint8_t>(); ta.vals = sorted_vals; ta.ext = ss.ext.as<uint8_t>(); ta.ext_bytes = ext_bytes;
     ta.tile_start = tile_start; ta.tile_end = tile_end;
     ta.pair_total = pair_total; ta.pair_capacity = (uint32_t)total;
+    // (a sixteenth of the average tile's pairs x rows; `total` is the room given to the pairs when their number is not known yet)
+    ta.prio_quantum = dev->wave_priority && n_launch_tiles ? (uint32_t)std::max<unsigned long long>(1ull, (unsigned long long)total * 2ull / n_launch_tiles) : 0u;
     ta.n_att = (uint32_t)c.attachments.size();
     bool any_clear = false, capturing = false;
     for (size_t i = 0; i < c.attachments.size(); i++) {

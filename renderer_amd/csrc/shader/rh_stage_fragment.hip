@@ -93,6 +93,21 @@ extern "C" __device__ const rh_module_info_t rh_module_info = {
 #define RH_PHASE_MARK(K) { const unsigned long long now_ = __builtin_readcyclecounter(); ph_acc[K] += now_ - ph_t; ph_t = now_; }
 #define RH_PHASE_END if ((blockIdx.x % 1019u) == 7u && lane == 0) \
     printf("tile %u records %u: load %llu, stage %llu, shade %llu, store %llu\n", tile, end - start, ph_acc[0], ph_acc[1], ph_acc[2], ph_acc[3]);
+#elif defined(RH_WG_TIMES)
+// (-DRH_WG_TIMES, tools/wg_times.sh: every workgroup notes when it started and ended, on the 100 MHz clock all CUs share;
+// the last one to end prints every fourth note -- after the fact, so that printing does not disturb what is measured)
+__device__ unsigned long long rh_wg_t[3 * 32768];
+__device__ unsigned int rh_wg_done;
+#define RH_PHASE_BEGIN const unsigned long long wg_t0 = wall_clock64();
+#define RH_PHASE_MARK(K)
+#define RH_PHASE_END if (lane == 0 && gridDim.x <= 32768u) { \
+        rh_wg_t[3 * blockIdx.x] = wg_t0; rh_wg_t[3 * blockIdx.x + 1] = wall_clock64(); rh_wg_t[3 * blockIdx.x + 2] = (unsigned long long)rows | ((unsigned long long)(end - start) << 8); \
+        __threadfence(); \
+        if (atomicAdd(&rh_wg_done, 1u) == gridDim.x - 1u) { \
+            rh_wg_done = 0u; __threadfence(); \
+            printf("launch %u workgroups\n", gridDim.x); \
+            for (unsigned int i = 0; i < gridDim.x; i += 4u) printf("wg %u rows %u pairs %u t %llu %llu\n", i, (unsigned int)(rh_wg_t[3 * i + 2] & 255u), (unsigned int)(rh_wg_t[3 * i + 2] >> 8), rh_wg_t[3 * i], rh_wg_t[3 * i + 1]); \
+        } }
 #else
 #define RH_PHASE_BEGIN
 #define RH_PHASE_MARK(K)
@@ -738,6 +753,15 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
     uint32_t value_next = (sets_up && start < end && pl < (int)min((uint32_t)ROUND, end - start)) ? a.vals[start + (uint32_t)pl] : PAIR_GENERAL;
     for (uint32_t base = start; base < end; base += ROUND) {
         const int n = (int)min((uint32_t)ROUND, end - base);
+        if (a.prio_quantum) {
+            // Issue priority by the work the wave has left (pairs x rows, in quanta the host derives from the pass's
+            // average tile): the SIMD picks the wave of highest priority, the oldest among equals, so without this the
+            // waves of a SIMD end one after the other and the pass drains through SIMDs that are left with one starved
+            // wave; with it the waves with most left go first and those of a SIMD end closer together.
+            const uint32_t work = (end - base) * (uint32_t)rows, q = a.prio_quantum;
+            if (work >= 3u * q) __builtin_amdgcn_s_setprio(3); else if (work >= 2u * q) __builtin_amdgcn_s_setprio(2);
+            else if (work >= q) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+        }
         {
             // lane = pair of this round.  General pairs bring the record the set-up launch wrote; a lean quad is set up
             // here and now, straight into the staging area.

@@ -190,8 +190,14 @@ class Renderer:
     def set_tail_split(self, mode):
         """How the tiles of a pass's last, partly filled round of workgroups are cut into bands of rows: 0 never, 1 one
         kind of band per pass (halves, quarters or eighths), 2 (default) quarters beside the halves where there is room
-        left (identical results)."""
+        left, 3 thirds (11, 11 and 10 rows) where the tail fits the round in thirds but not in quarters (identical
+        results)."""
         _ffi.check(_ffi.lib().rh_device_set_option(self.device, _ffi.OPTION_TAIL_SPLIT, int(mode)))
+
+    def set_wave_priority(self, enabled):
+        """True (default): the tile kernel's waves set their issue priority by the work they have left; False: priorities
+        are left alone (identical results)."""
+        _ffi.check(_ffi.lib().rh_device_set_option(self.device, _ffi.OPTION_WAVE_PRIORITY, 1 if enabled else 0))
 
     def set_setup_launch(self, enabled):
         """True: every set-up record comes from the set-up launch; False (default): the tile kernel sets lean quads up

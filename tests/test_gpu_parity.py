@@ -193,6 +193,22 @@ def test_last_tiles_cut_into_bands_of_rows_multisampled(oracle, samples, fmt, ro
             assert_same(got[key], want[key], f"mode={mode} {key}")
 
 
+def test_wave_priority_changes_no_byte(oracle):
+    """The tile waves' issue priority (RH_OPTION_WAVE_PRIORITY) only changes which wave a SIMD serves first: the oracle's
+    bytes with it and without, whole tiles and bands."""
+    scene = scenes.random_quads_scene(8000, 16, 1024, 512, seed=29)
+    scene["record"] = True
+    want = scenes.draw_oracle(scene)
+    for enabled in (True, False):
+        hs = scenes.HipScene(scene)
+        hs.renderer.set_wave_priority(enabled)
+        hs.draw()
+        got = {"color": hs.read_color(), "recording": hs.read_recording()}
+        hs.close()
+        for key in got:
+            assert_same(got[key], want[key], f"priority={enabled} {key}")
+
+
 def test_general_and_specialised_kernel_bodies_agree(oracle):
     """The state-specialised kernel bodies and the general body give identical bytes."""
     scene = scenes.random_quads_scene(5000, 24, 512, 288, seed=5)

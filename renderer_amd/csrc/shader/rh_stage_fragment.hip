@@ -815,12 +815,11 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
         // What the passes of a hit need as wave-uniform numbers is worked out here for all the hits at once, each in the
         // lane of its hit, and fetched by the scalar side hit by hit (the SIMD issues one instruction of ANY kind per ~2.3
         // cycles, scalar ones included: what is done once per round for 32 hits is nearly free, what is done per hit is not):
-        //   boxw = x0 | y0 << 8 | width << 16, invw = 1 / width, last = pixels - 1
-        //   (the top byte of boxw: the hit's passes)
+        //   boxw = x0 | y0 << 8 | width << 16 | record of the round << 24, invw = 1 / width, last = pixels - 1
         uint32_t boxw_v; float invw_v, last_v;
         {
             const uint32_t bw = ((box_v >> 16) & 0xffu) - (box_v & 0xffu) + 1u;
-            boxw_v = (box_v & 0xffffu) | (bw << 16) | (((((info_v >> 18) & 0x7ffu) + 63u) >> 6) << 24);
+            boxw_v = (box_v & 0xffffu) | (bw << 16) | ((info_v & 0x3fu) << 24);
             invw_v = __builtin_amdgcn_rcpf((float)bw);
             last_v = (float)((info_v >> 18) & 0x7ffu) - 1.0f;
             if (TEX == 3) {
@@ -834,7 +833,7 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
         // A pack = up to PACK_MAX consecutive small hits whose boxes are pairwise disjoint and whose pixels fit
         // the 64 lanes of ONE pass (disjoint boxes cannot touch the same pixel, so their relative order is
         // immaterial).  Every lane works out the pack that would start at its hit:
-        //   run = length | pixels << 3 | lane at which member 1, 2, 3 starts << 10, 17, 24 (127 = no such member)
+        //   run = pixels | lane at which member 1, 2, 3 starts << 8, 16, 24 (127 = no such member)
         // (the footprint copies a pack reads are the ones picked for its first member or before: a hint, any copy holds the same texels)
         uint32_t run_v;
         {
@@ -861,7 +860,7 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
                 c1 = ok1 ? n0 : 127u; c2 = ok2 ? n0 + n1 : 127u; c3 = ok3 ? n0 + n1 + n2 : 127u;
                 total = n0 + (ok1 ? n1 : 0u) + (ok2 ? n2 : 0u) + (ok3 ? n3 : 0u);
             }
-            run_v = len | (total << 3) | (c1 << 10) | (c2 << 17) | (c3 << 24);
+            run_v = total | (c1 << 8) | (c2 << 16) | (c3 << 24);
             // (a small hit that nobody joins runs alone like any other lean quad: fewer instructions than a pack of one;
             // from here on the bit says "a pack of two or more starts at this hit")
             if (len == 1u) info_v &= ~INFO_SMALL;
@@ -876,21 +875,32 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
             const float4 dh = *reinterpret_cast<const float4*>(rf);                     // header, diagonal A, B, T
             const float3 dg = make_float3(dh.y, dh.z, dh.w);
             uint8_t* const px_bytes = reinterpret_cast<uint8_t*>(tile_px);
-            int pass = npass;                       // (a hit has at least one pass)
-#if defined(RH_EXP) && RH_EXP == 4          /* diagnostic build: the hits are walked, no pass runs */
-            if (dg.x == 12345.0f)
-#endif
-            do {
+            // The planes of the triangle a pixel falls into are read through a per-lane LDS address: triangle B's sit
+            // TRI_WORDS behind triangle A's, and B it is where the diagonal's edge function is negative.  (Sign bit times
+            // the distance plus the base, in two instructions; the compiler's own sequence takes three.)
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
+            typedef const f32x4 __attribute__((address_space(3))) lds_f32x4_t;
+            uint32_t planes_a = (uint32_t)(uintptr_t)(lds_f32x4_t*)(rf + HDR_WORDS);
+            asm("" : "+v"(planes_a));               // (in a vector register once per hit, not once per pass)
+            // One pass; LAST: the hit's last pass, whose lanes past the last pixel shade the last pixel again.
+            auto one_pass = [&](auto last_tag, const float idx_f) {
                 // (both are small non-negative integers: the minimum of their bit patterns)
-                const float idc = __uint_as_float(min(__float_as_uint(idx_f), __float_as_uint(last_f)));
+                const float idc = decltype(last_tag)::value ? __uint_as_float(min(__float_as_uint(idx_f), __float_as_uint(last_f))) : idx_f;
                 // floor((idx + 0.5) / w): the half keeps the quotient at least 1/128 away from an integer
                 const float row_f = floorf(__builtin_fmaf(idc, invw, half_invw));
                 const float col_f = __builtin_fmaf(-row_f, wf, idc);
                 const float lxf = hx0f + col_f, lyf = hy0f + row_f;          // tile-relative pixel, exact small integers
                 const uint32_t pb = (uint32_t)__builtin_fmaf(lyf, (float)(TILE * 4), lxf * 4.0f);
-                // triangle B where the diagonal's edge function is negative: its planes sit TRI_WORDS further on
-                const uint32_t in_b = __float_as_uint(__builtin_fmaf(dg.x, lxf, __builtin_fmaf(dg.y, lyf, dg.z))) >> 31;
-                const float* const tp = rf + HDR_WORDS + in_b * (uint32_t)TRI_WORDS;
+                const float e = __builtin_fmaf(dg.x, lxf, __builtin_fmaf(dg.y, lyf, dg.z));
+                uint32_t at;
+                if (TRI_WORDS * 4 <= 64) asm("v_lshrrev_b32 %0, 31, %1\n\tv_mad_u32_u24 %0, %0, %3, %2" : "=&v"(at) : "v"(e), "v"(planes_a), "n"(TRI_WORDS * 4));
+                else at = planes_a + (__float_as_uint(e) >> 31) * (uint32_t)(TRI_WORDS * 4);
+                float tp[TRI_WORDS];                  // (16-byte reads; what is not used is not read)
+#pragma unroll
+                for (int i = 0; i < TRI_WORDS / 4; i++) {
+                    const f32x4 q = ((lds_f32x4_t*)(uintptr_t)at)[i];
+                    tp[4 * i] = q.x; tp[4 * i + 1] = q.y; tp[4 * i + 2] = q.z; tp[4 * i + 3] = q.w;
+                }
                 const float dx = __builtin_fmaf(lxf, 256.0f, -tp[OFF_XR]), dy = __builtin_fmaf(lyf, 256.0f, -tp[OFF_YR]);   // exact
                 Varyings var; float* vf = reinterpret_cast<float*>(&var);
 #pragma unroll
@@ -902,8 +912,14 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
                     blend_pixel<BLEND>(reinterpret_cast<PxT*>(px_bytes + (size_t)t * (TILE_PX * sizeof(PxT)) + (size_t)pb * (sizeof(PxT) / 4)), a.att[t],
                                        out.color[t < RH_FRAGMENT_OUTPUTS ? t : RH_FRAGMENT_OUTPUTS - 1], a.src_factor, a.dst_factor);
                 }
-                idx_f += 64.0f;
-            } while (--pass > 0);
+            };
+#if defined(RH_EXP) && RH_EXP == 4          /* diagnostic build: the hits are walked, no pass runs */
+            if (dg.x == 12345.0f)
+#endif
+            {
+                for (int pass = npass; pass > 1; pass--, idx_f += 64.0f) one_pass(Flag<false>{}, idx_f);      // (a hit has at least one pass)
+                one_pass(Flag<true>{}, idx_f);
+            }
         };
         // Hits in order; k and everything read with readlane is wave-uniform and lives on the scalar unit.
         // (nh >= 1; the three bodies are the arms of one if / else chain, so that every hit crosses few branches)
@@ -920,7 +936,7 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
                 const float invw = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(invw_v), k));
                 const float last_f = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(last_v), k));
                 k++;
-                lean_passes((float)(boxw & 0xffu), (float)((boxw >> 8) & 0xffu), (float)((boxw >> 16) & 0xffu), invw, lane_f, last_f, (int)(boxw >> 24),
+                lean_passes((float)(boxw & 0xffu), (float)((boxw >> 8) & 0xffu), (float)((boxw >> 16) & 0xffu), invw, lane_f, last_f, (int)((((info >> 18) & 0x7ffu) + 63u) >> 6),
                             recf + (int)(info & 0x3fu) * REC_WORDS);
                 continue;
             }
@@ -931,19 +947,24 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
                 for (int i = 0; i < RH_DEV_MAX_SLOTS; i++) fctx.poly[i].pick(p.slots[i], grad_log2);
             }
             if (info & INFO_SMALL) {
-                // a pack: every lane takes the box and the record of the member its pixel belongs to
+                // a pack: every lane takes the box and the record of the member its pixel belongs to.  Where the members
+                // start is wave-uniform, so "lane >= start" is a mask the scalar unit makes with a shift, and the member
+                // of a lane (times eight: where its start sits in `run`) takes three selects by those masks.
                 const uint32_t run = __builtin_amdgcn_readlane(run_v, k);
-                const int c1 = (int)((run >> 10) & 127u), c2 = (int)((run >> 17) & 127u), c3 = (int)(run >> 24);
-                const bool g1 = lane >= c1, g2 = lane >= c2, g3 = lane >= c3;
-                const int slot = (g1 ? 1 : 0) + (g2 ? 1 : 0) + (g3 ? 1 : 0);
-                const int st = g3 ? c3 : (g2 ? c2 : (g1 ? c1 : 0));
-                const int src = (k + slot) << 2;
-                const uint2 m = make_uint2((uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)boxw_v), (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)info_v));
-                const float wf = (float)((m.x >> 16) & 0xffu);
+                const uint32_t c1 = (run >> 8) & 127u, c2 = (run >> 16) & 127u, c3 = run >> 24;
+                const unsigned long long m1 = c1 < 64u ? ~0ull << c1 : 0ull, m2 = c2 < 64u ? ~0ull << c2 : 0ull, m3 = c3 < 64u ? ~0ull << c3 : 0ull;
+                uint32_t slot8;
+                asm("v_cndmask_b32_e64 %0, 0, 8, %1" : "=v"(slot8) : "s"(m1));
+                asm("v_cndmask_b32_e64 %0, %1, 16, %2" : "=v"(slot8) : "v"(slot8), "s"(m2));
+                asm("v_cndmask_b32_e64 %0, %1, 24, %2" : "=v"(slot8) : "v"(slot8), "s"(m3));
+                const uint32_t st = __builtin_amdgcn_ubfe(run & 0xffffff00u, slot8, 7u);      // (member 0 starts at lane 0)
+                const int src = (k << 2) + (int)(slot8 >> 1);
+                const uint32_t mb = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)boxw_v);
+                const float minvw = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)__float_as_uint(invw_v)));
                 // (the lanes past the pack's pixels shade its last pixel again)
-                lean_passes((float)(m.x & 0xffu), (float)((m.x >> 8) & 0xffu), wf, __builtin_amdgcn_rcpf(wf), (float)(lane - st),
-                            (float)((int)((run >> 3) & 127u) - st - 1), 1, recf + (int)(m.y & 0x3fu) * REC_WORDS);
-                k += (int)(run & 7u);
+                lean_passes((float)(mb & 0xffu), (float)((mb >> 8) & 0xffu), (float)((mb >> 16) & 0xffu), minvw, (float)(int)((uint32_t)lane - st),
+                            (float)(int)((run & 127u) - 1u - st), 1, recf + (int)(mb >> 24) * REC_WORDS);
+                k += 1 + (int)(((~c1 >> 6) & 1u) + ((~c2 >> 6) & 1u) + ((~c3 >> 6) & 1u));         // (a start is below 64, or 127)
             } else {
             const uint32_t rec_index = info & 0x3fu;
             const float* const rf = recf + (int)rec_index * REC_WORDS;
@@ -951,7 +972,7 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
             const float invw = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(invw_v), k));
             const float last_f = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(last_v), k));
             const float hx0f = (float)(boxw & 0xffu), hy0f = (float)((boxw >> 8) & 0xffu), wf = (float)((boxw >> 16) & 0xffu);
-            const int npass = (int)(boxw >> 24);
+            const int npass = (int)((((info >> 18) & 0x7ffu) + 63u) >> 6);
             k++;
             if (info & INFO_LEAN) lean_passes(hx0f, hy0f, wf, invw, lane_f, last_f, npass, rf);
             else {

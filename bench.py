@@ -368,6 +368,7 @@ def main():
     renderer.synchronize()
     renderer.set_timing(True)
     renderer.drain_timings()
+    early_before = renderer.last_pass_stats()["early"]
 
     barrier()
     t0 = time.perf_counter()
@@ -393,7 +394,10 @@ def main():
     # Outside the timed region: the same frames with every launch on the one stream, so that the tile kernel's duration
     # is also known with nothing beside it (in the timed region the binning of the next frame shares the GPU with it).
     alone = None
-    overlapped = os.environ.get("RH_EARLY_BINNING", "1") != "0"
+    # (whether the timed passes were binned beside the tile kernel of the pass before: the library does that by itself
+    # only for passes with millions of pairs, RH_EARLY_BINNING=2 asks for it always, 0 never)
+    overlapped = stats["early"] - early_before > 0
+    early_mode = int(os.environ.get("RH_EARLY_BINNING", "1"))
     if rank == 0 and n_gpus == 1 and overlapped and not args.no_alone:
         renderer.set_early_binning(False)
         for _ in range(max(2, args.warmup)):
@@ -408,7 +412,7 @@ def main():
         alone_s = time.perf_counter() - t1
         alone_t = renderer.drain_timings()
         renderer.set_timing(False)
-        renderer.set_early_binning(True)
+        renderer.set_early_binning(early_mode)
         np_ = max(1, alone_t["passes"])
         alone = {"ms_per_step": alone_s / args.steps * 1e3, "kernel_ms": alone_t["tile_ms"] / np_,
                  "binning_ms": alone_t["bin_ms"] / np_, "setup_ms": alone_t["setup_ms"] / np_}
@@ -544,9 +548,10 @@ def main():
                          "algorithmic_bytes_per_launch": b_alg, "compulsory_bytes_per_launch": b_min,
                          "kernel_ms": tile_ms, "binning_ms": bin_ms, "setup_ms": setup_ms,
                          "fragments_per_s": n_frag / (tile_ms * 1e-3) if tile_ms > 0 else 0.0,
-                         # binning and set-up of frame n+1 run on a stream of their own beside the tile kernel of frame n
-                         # (unless RH_EARLY_BINNING=0): binning_ms is then their wall time spread under that kernel, not
-                         # time added to the frame, and kernel_ms is the tile kernel with that work sharing the GPU
+                         # true: binning and set-up of frame n+1 ran on a stream of their own beside the tile kernel of
+                         # frame n (passes with millions of pairs, or RH_EARLY_BINNING=2): binning_ms is then their wall
+                         # time spread under that kernel, not time added to the frame, and kernel_ms is the tile kernel
+                         # with that work sharing the GPU
                          "overlapped": overlapped,
                          # "hbm" is how the path is priced (bytes the reference's semantics move per fragment); the tile
                          # lives in LDS, so what the kernel actually runs into is the SIMDs' instruction issue rate

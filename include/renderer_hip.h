@@ -70,7 +70,9 @@ enum {
     RH_OPTION_EARLY_BINNING = 6,      /* 1 (default): binning and set-up of a pass that is queued whole run on a stream of
                                          their own, beside the tile kernel of the pass before (they read only what the
                                          vertex stage reads, and wait for everything queued before the pass that could
-                                         change it); 0: everything on one stream (identical results) */
+                                         change it); 1 does so for passes with room for four million (tile, pair) pairs
+                                         or more, whose binning chain is long enough for that to pay, 2 for every pass
+                                         it is valid for; 0: everything on one stream (identical results) */
     RH_OPTION_TAIL_SPLIT = 7,         /* the tiles beyond the last full round of workgroups the GPU holds at once are cut
                                          into bands of rows (halves, quarters or eighths of a tile) with a workgroup
                                          each, so that the end of the pass fills the SIMDs instead of running a few long

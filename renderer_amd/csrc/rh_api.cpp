@@ -89,7 +89,8 @@ struct rh_device {
     hipStream_t bin_stream = nullptr;           // created when the first pass takes it (a process has few hardware queues)
     int compressors = 0;                        // rh_compressor objects alive on this device (each brings two streams of its own)
     int bin_priority = 0;
-    int early_binning = 1;
+    int early_binning = 1;           // 0 never, 1 where it pays (passes with room for early_min_pairs pairs or more), 2 wherever it is valid
+    uint64_t early_min_pairs = 4000000;
     int eager_count = 1;                        // RH_OPTION_EAGER_COUNT
     int setup_launch = 0;                       // RH_OPTION_SETUP_LAUNCH
     // The tiles of a pass's last, partly filled round of workgroups are cut into bands of rows (rh_tile_args::split2_first):
@@ -438,7 +439,8 @@ int rh_device_create(int hip_ordinal, uint32_t width, uint32_t height, rh_device
         hipEventCreateWithFlags(&dev->setup_done, hipEventDisableTiming) != hipSuccess) {
         rh_device_destroy(dev); return fail("rh_device_create: creating the binning stream failed");
     }
-    if (const char* v = getenv("RH_EARLY_BINNING")) dev->early_binning = atoi(v) ? 1 : 0;
+    if (const char* v = getenv("RH_EARLY_BINNING")) dev->early_binning = std::max(0, std::min(2, atoi(v)));
+    if (const char* v = getenv("RH_EARLY_MIN_PAIRS")) dev->early_min_pairs = (uint64_t)std::max(0ll, atoll(v));
     if (const char* v = getenv("RH_COW_UPLOADS")) dev->cow_uploads = atoi(v) ? 1 : 0;
     if (const char* v = getenv("RH_TAIL_SPLIT")) dev->tail_split = std::max(0, std::min(3, atoi(v)));
     if (const char* v = getenv("RH_WAVE_PRIORITY")) dev->wave_priority = atoi(v) ? 1 : 0;
@@ -546,7 +548,7 @@ int rh_device_set_option(rh_device* dev, int option, int value) {
     if (option == RH_OPTION_GENERAL_KERNELS) { dev->general_kernels = value ? 1 : 0; return 0; }
     if (option == RH_OPTION_BINNING_TICKETS) { dev->binning_tickets = value ? 1 : 0; return 0; }
     if (option == RH_OPTION_TIMING) { dev->timing = value ? 1 : 0; return 0; }
-    if (option == RH_OPTION_EARLY_BINNING) { dev->early_binning = value ? 1 : 0; return 0; }
+    if (option == RH_OPTION_EARLY_BINNING) { if (value < 0 || value > 2) return fail("rh_device_set_option: RH_OPTION_EARLY_BINNING takes 0, 1 or 2"); dev->early_binning = (int)value; return 0; }
     if (option == RH_OPTION_EAGER_COUNT) { dev->eager_count = value ? 1 : 0; return 0; }
     if (option == RH_OPTION_SETUP_LAUNCH) { dev->setup_launch = value ? 1 : 0; return 0; }
     if (option == RH_OPTION_WAVE_PRIORITY) { dev->wave_priority = value ? 1 : 0; return 0; }
@@ -1137,7 +1139,11 @@ int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer, rh_device::Pa
     // (and no compressor on the device: with its two streams beside the three of a pass binned early, passes were seen
     // to stop for good at the first one binned early, under some assignments of the streams to hardware queues and not
     // under others; a recording run renders on the main stream alone, as it always has for a scene that moves)
-    const bool early = deferred && alternating && dev->early_binning && !vertex_reads_texture && buffers_settled && dev->before_tile_valid &&
+    // (and, in the default mode, only a pass with a long binning chain: beside a tile kernel the chain gets the places
+    // that kernel's workgroups leave, slows it down and still ends behind it -- measured at 4K, that costs a frame with
+    // 2 M pairs 3 % and gains one with 3.6 M or more 1 .. 4 %)
+    const bool early_pays = dev->early_binning >= 2 || dev->pair_guess >= dev->early_min_pairs;
+    const bool early = deferred && alternating && dev->early_binning && early_pays && !vertex_reads_texture && buffers_settled && dev->before_tile_valid &&
                        (dev->compressors == 0 || getenv("RH_EXP_EARLY_WITH_COMPRESSOR"));
     if (early && !dev->bin_stream) RH_HIP(hipStreamCreateWithPriority(&dev->bin_stream, hipStreamNonBlocking, dev->bin_priority));
     if (early) dev->stats.early++;

@@ -182,10 +182,11 @@ class Renderer:
         """Forces the form of the binning chain that launches too large for the device use (identical results; for testing)."""
         _ffi.check(_ffi.lib().rh_device_set_option(self.device, _ffi.OPTION_BINNING_TICKETS, 1 if enabled else 0))
 
-    def set_early_binning(self, enabled):
-        """Binning and set-up of a pass on a stream of their own, beside the tile kernel of the pass before (default on;
-        identical results either way)."""
-        _ffi.check(_ffi.lib().rh_device_set_option(self.device, _ffi.OPTION_EARLY_BINNING, 1 if enabled else 0))
+    def set_early_binning(self, mode):
+        """Binning and set-up of a pass on a stream of their own, beside the tile kernel of the pass before: False / 0
+        never, True / 1 (default) for passes with a long binning chain (room for four million pairs or more), 2 for
+        every pass it is valid for (identical results whichever)."""
+        _ffi.check(_ffi.lib().rh_device_set_option(self.device, _ffi.OPTION_EARLY_BINNING, int(mode)))
 
     def set_tail_split(self, mode):
         """How the tiles of a pass's last, partly filled round of workgroups are cut into bands of rows: 0 never, 1 one

@@ -17,6 +17,12 @@ except ImportError:
     pass
 
 
+# The tests' scenes are small: in the default mode none of their passes would be binned early (that is for passes with
+# millions of pairs), so the suite asks for early binning wherever it is valid and keeps covering that path; tests of
+# the one-stream path switch it off themselves.
+os.environ.setdefault("RH_EARLY_BINNING", "2")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

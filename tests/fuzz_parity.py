@@ -111,6 +111,8 @@ def run_one(seed):
     # how the device cuts the last tiles of a pass into bands of rows (read when the device is made): never, one kind,
     # mixed; with the GPU taken to hold few workgroups, so that these small targets see whole tiles, halves and quarters
     os.environ["RH_TAIL_SPLIT"] = str(int(rng.integers(0, 4)))
+    os.environ["RH_EARLY_BINNING"] = str(int(rng.choice([0, 2, 2])))
+    os.environ["RH_WAVE_PRIORITY"] = str(int(rng.integers(0, 2)))
     os.environ["RH_TILE_ROOM"] = str(int(rng.choice([0, 16, 50, 120, 300])))
     try:
         hip = scenes.draw_hip(scene, clip_to_viewport=clip, initial=initial, twice=seed % 2 == 0)

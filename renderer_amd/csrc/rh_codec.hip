@@ -26,6 +26,7 @@
 // acceleration 1, byU32 table, 64-bit hash5; LZ4_saveDict after every update; LZ4_renormDictT).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "rh_codec.h"
 
 namespace {
@@ -861,10 +862,13 @@ last_literals:
 // One workgroup (one wave) per job.  A job is a sequence of writes to one stream; every write is one
 // LZ4F_compressUpdate: full 64 KiB blocks, then the remainder, then the dictionary save.  Every source is readable up
 // to READ_SLACK bytes behind its end.
-extern "C" __global__ __launch_bounds__(64) void rh_lz4f_compress(const rh_lz4_job* jobs, rh_lz4_stream_state* states) {
+extern "C" __global__ __launch_bounds__(64) void rh_lz4f_compress(const rh_lz4_job* jobs, rh_lz4_stream_state* states, uint32_t top_priority) {
     extern __shared__ uint8_t lds_raw[];
     Lds& L = *reinterpret_cast<Lds*>(lds_raw);
     const int lane = (int)threadIdx.x;
+    // A stream is one long chain of dependent steps: whenever its wave can issue, it should -- before the waves of the
+    // rendering kernels that share its SIMD, which have others to stand in for them.
+    if (top_priority) __builtin_amdgcn_s_setprio(3);
     // (a reference, not a copy: a local copy with its run-time indexed arrays would live in per-lane memory, and
     // everything derived from it -- block sizes, positions, every branch of the match loop -- would be treated as
     // varying across the lanes instead of running on the scalar unit)
@@ -1178,7 +1182,8 @@ int lz4f_compress_launch(const rh_lz4_job* d_jobs, uint32_t n_jobs, rh_lz4_strea
     // launch is one round of packets
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rh_lz4f_compress), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lds));
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(rh_lz4f_compress, dim3(n_jobs), dim3(64), sizeof(Lds), s, d_jobs, d_states);
+    static const uint32_t top_priority = (getenv("RH_LZ4_PRIORITY") && !atoi(getenv("RH_LZ4_PRIORITY"))) ? 0u : 1u;
+    hipLaunchKernelGGL(rh_lz4f_compress, dim3(n_jobs), dim3(64), sizeof(Lds), s, d_jobs, d_states, top_priority);
     return (int)hipGetLastError();
 }
 

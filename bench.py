@@ -366,7 +366,9 @@ def main():
     for _ in range(args.warmup):
         step()
     renderer.synchronize()
-    renderer.set_timing(True)
+    # (marks around the tile kernel only, the kernel the roofline prices: every mark is a bubble of some 7 us in the
+    # stream, and five per frame cost the frame 3 %; what binning and set-up take comes from an untimed leg below)
+    renderer.set_timing(2)
     renderer.drain_timings()
     early_before = renderer.last_pass_stats()["early"]
 
@@ -398,8 +400,10 @@ def main():
     # only for passes with millions of pairs, RH_EARLY_BINNING=2 asks for it always, 0 never)
     overlapped = stats["early"] - early_before > 0
     early_mode = int(os.environ.get("RH_EARLY_BINNING", "1"))
-    if rank == 0 and n_gpus == 1 and overlapped and not args.no_alone:
-        renderer.set_early_binning(False)
+    phases = None
+    if rank == 0 and n_gpus == 1 and not args.no_alone:
+        if overlapped:
+            renderer.set_early_binning(False)
         for _ in range(max(2, args.warmup)):
             step()
         renderer.synchronize()
@@ -414,8 +418,10 @@ def main():
         renderer.set_timing(False)
         renderer.set_early_binning(early_mode)
         np_ = max(1, alone_t["passes"])
-        alone = {"ms_per_step": alone_s / args.steps * 1e3, "kernel_ms": alone_t["tile_ms"] / np_,
-                 "binning_ms": alone_t["bin_ms"] / np_, "setup_ms": alone_t["setup_ms"] / np_}
+        phases = {"ms_per_step": alone_s / args.steps * 1e3, "kernel_ms": alone_t["tile_ms"] / np_,
+                  "binning_ms": alone_t["bin_ms"] / np_, "setup_ms": alone_t["setup_ms"] / np_}
+        if overlapped:
+            alone = phases
 
     # release the quads scene before the recording leg
     hs.close()
@@ -526,8 +532,9 @@ def main():
         b_alg = args.quads * scene["instances"].shape[1] * 4 + n_frag * 2 * 4 * 1 + tex_bytes
         b_min = args.quads * scene["instances"].shape[1] * 4 + args.width * args.height * 4 + tex_bytes
         tile_ms = timings["tile_ms"] / max(1, timings["passes"])
-        bin_ms = timings["bin_ms"] / max(1, timings["passes"])
-        setup_ms = timings["setup_ms"] / max(1, timings["passes"])
+        # (from the untimed leg with marks around every phase; beside a tile kernel -- `overlapped` -- they are longer)
+        bin_ms = phases["binning_ms"] if phases else None
+        setup_ms = phases["setup_ms"] if phases else None
         achieved = b_alg / (tile_ms * 1e-3) / 1e9 if tile_ms > 0 else 0.0
         c2_profiled = (args.workload == "c2" and args.quads == 10_000_000 and (args.width, args.height) == (3840, 2160))
         traffic = pmc_traffic_bytes("c1") if default_workload else (pmc_traffic_bytes("c2") if c2_profiled else None)
@@ -547,6 +554,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": b_alg, "compulsory_bytes_per_launch": b_min,
                          "kernel_ms": tile_ms, "binning_ms": bin_ms, "setup_ms": setup_ms,
+                         "phases_from": "an untimed leg of this run, every launch on one stream, HIP events around every phase of a pass (the timed region has them around the tile kernel only)",
                          "fragments_per_s": n_frag / (tile_ms * 1e-3) if tile_ms > 0 else 0.0,
                          # true: binning and set-up of frame n+1 ran on a stream of their own beside the tile kernel of
                          # frame n (passes with millions of pairs, or RH_EARLY_BINNING=2): binning_ms is then their wall

@@ -56,7 +56,9 @@ enum {
     RH_OPTION_CLIP_TO_VIEWPORT = 0,   /* 1 (default): fragments outside the viewport rectangle are clipped, as strict
                                          clip-volume clipping gives; 0: only the attachment bounds restrict them */
     RH_OPTION_TIMING = 1,             /* 1: record HIP events around the binning phase and the tile kernel of every
-                                         render pass (read with rh_device_drain_timings); default 0 */
+                                         render pass (read with rh_device_drain_timings); 2: around the tile kernel
+                                         only (bin_ms and setup_ms then read 0; every mark is a bubble of some 7 us in
+                                         the stream); default 0 */
     RH_OPTION_STRIP_ROW0 = 2,         /* sort-first split of a large target over several devices: render passes touch */
     RH_OPTION_STRIP_ROW1 = 3,         /* only pixel rows [ROW0, ROW1) (multiples of 32, or the target height); clears
                                          included.  ROW1 = 0 (default) disables the restriction. */

@@ -512,7 +512,7 @@ void device_release(rh_device* dev) {
     for (hipEvent_t e : { dev->tile_done[0], dev->tile_done[1], dev->before_tile, dev->setup_done }) if (e) (void)hipEventDestroy(e);
     if (dev->bin_stream) (void)hipStreamDestroy(dev->bin_stream);
     for (hipEvent_t e : dev->event_pool) (void)hipEventDestroy(e);
-    for (hipEvent_t e : dev->timing_events) (void)hipEventDestroy(e);
+    for (hipEvent_t e : dev->timing_events) if (e) (void)hipEventDestroy(e);
     if (dev->copy_stream) (void)hipStreamSynchronize(dev->copy_stream);
     for (rh_device::StagedUpload& u : dev->staged) {
         if (u.h) (void)hipHostFree(u.h);
@@ -547,7 +547,12 @@ int rh_device_set_option(rh_device* dev, int option, int value) {
     if (option == RH_OPTION_CLIP_TO_VIEWPORT) { dev->clip_to_viewport = value ? 1 : 0; return 0; }
     if (option == RH_OPTION_GENERAL_KERNELS) { dev->general_kernels = value ? 1 : 0; return 0; }
     if (option == RH_OPTION_BINNING_TICKETS) { dev->binning_tickets = value ? 1 : 0; return 0; }
-    if (option == RH_OPTION_TIMING) { dev->timing = value ? 1 : 0; return 0; }
+    if (option == RH_OPTION_TIMING) {
+        if (value < 0 || value > 2) return fail("rh_device_set_option: RH_OPTION_TIMING takes 0, 1 or 2");
+        // (the marks of a pass are counted in fives: a change of mode starts from a clean slate)
+        if ((int)value != dev->timing) { for (hipEvent_t e : dev->timing_events) if (e) dev->event_pool.push_back(e); dev->timing_events.clear(); }
+        dev->timing = (int)value; return 0;
+    }
     if (option == RH_OPTION_EARLY_BINNING) { if (value < 0 || value > 2) return fail("rh_device_set_option: RH_OPTION_EARLY_BINNING takes 0, 1 or 2"); dev->early_binning = (int)value; return 0; }
     if (option == RH_OPTION_EAGER_COUNT) { dev->eager_count = value ? 1 : 0; return 0; }
     if (option == RH_OPTION_SETUP_LAUNCH) { dev->setup_launch = value ? 1 : 0; return 0; }
@@ -1004,6 +1009,9 @@ namespace {
 
 int timing_mark(rh_device* dev, hipStream_t on = nullptr) {
     if (!dev->timing) return 0;
+    // (a pass makes five marks, in order; mode 2 keeps the two around the tile kernel only -- every mark is a bubble of
+    // some 7 us in the stream)
+    if (dev->timing == 2 && dev->timing_events.size() % 5 < 3) { dev->timing_events.push_back(nullptr); return 0; }
     hipEvent_t e = nullptr;
     if (!dev->event_pool.empty()) { e = dev->event_pool.back(); dev->event_pool.pop_back(); }
     else RH_HIP(hipEventCreate(&e));
@@ -1214,7 +1222,7 @@ int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer, rh_device::Pa
             // a triangle crosses a clip plane: the pass starts again with the kernels that clip
             if (no_alloc) return fail("rh_submit_static: the pass has triangles that cross a clip plane; the kernels that clip them need private memory, which the runtime allocates");
             pl->clips = true;
-            if (dev->timing && !dev->timing_events.empty()) { dev->event_pool.push_back(dev->timing_events.back()); dev->timing_events.pop_back(); }
+            if (dev->timing && !dev->timing_events.empty()) { if (dev->timing_events.back()) dev->event_pool.push_back(dev->timing_events.back()); dev->timing_events.pop_back(); }
             return execute_pass(dev, c, false, ss_in, no_alloc, fused);
         }
         if (pl->clips) note_clipping(pl, (uint32_t)dev->h_total[2] != 0u);
@@ -1426,7 +1434,7 @@ int resolve_pending(rh_device* dev, bool blocking, bool may_rerun) {
                 // the tile kernel, its end -- say which launch has not finished)
                 const size_t n_ev = dev->timing_events.size();
                 for (size_t i = n_ev >= 15 ? n_ev - 15 : 0; i < n_ev; i++)
-                    RH_TRACE("  pass %zu mark %zu: %s", i / 5, i % 5, hipEventQuery(dev->timing_events[i]) == hipSuccess ? "reached" : "not reached");
+                    RH_TRACE("  pass %zu mark %zu: %s", i / 5, i % 5, !dev->timing_events[i] ? "not recorded" : hipEventQuery(dev->timing_events[i]) == hipSuccess ? "reached" : "not reached");
                 break;
             }
         }
@@ -1445,7 +1453,7 @@ int resolve_pending(rh_device* dev, bool blocking, bool may_rerun) {
     else if (total >= RH_WANTS_CLIP && !c.pipeline->clips) {
         // a triangle crosses a clip plane (nothing was written): the pass runs again, now and from now on with the kernels that clip
         c.pipeline->clips = true;
-        for (int k = 0; k < 5 && dev->timing && !dev->timing_events.empty(); k++) { dev->event_pool.push_back(dev->timing_events.back()); dev->timing_events.pop_back(); }
+        for (int k = 0; k < 5 && dev->timing && !dev->timing_events.empty(); k++) { if (dev->timing_events.back()) dev->event_pool.push_back(dev->timing_events.back()); dev->timing_events.pop_back(); }
         dev->stats.reruns++;
         rc = execute_pass(dev, c, false, dev->grown, false, fused);
     }
@@ -1456,7 +1464,7 @@ int resolve_pending(rh_device* dev, bool blocking, bool may_rerun) {
         if (total <= capacity) dev->pair_guess = std::max<uint64_t>(dev->pair_guess, std::min<uint64_t>(total + total / 4 + 4096, 0x7ffffffeull));
         else {
             // the attempt that wrote nothing is not a pass of its own: its timing marks go back to the pool
-            for (int k = 0; k < 5 && dev->timing && !dev->timing_events.empty(); k++) { dev->event_pool.push_back(dev->timing_events.back()); dev->timing_events.pop_back(); }
+            for (int k = 0; k < 5 && dev->timing && !dev->timing_events.empty(); k++) { if (dev->timing_events.back()) dev->event_pool.push_back(dev->timing_events.back()); dev->timing_events.pop_back(); }
             dev->stats.reruns++;
             rc = execute_pass(dev, c, false, dev->grown, false, fused);
         }
@@ -1542,12 +1550,14 @@ int rh_device_drain_timings(rh_device* dev, rh_timings* out) {
         hipEvent_t e0 = dev->timing_events[5 * i], e1 = dev->timing_events[5 * i + 1], e2 = dev->timing_events[5 * i + 2], e3 = dev->timing_events[5 * i + 3], e4 = dev->timing_events[5 * i + 4];
         RH_HIP(hipEventSynchronize(e4));
         float a = 0.0f, b = 0.0f, c = 0.0f;
-        RH_HIP(hipEventElapsedTime(&a, e0, e1));
-        RH_HIP(hipEventElapsedTime(&b, e1, e2));
+        if (e0 && e1 && e2) {
+            RH_HIP(hipEventElapsedTime(&a, e0, e1));
+            RH_HIP(hipEventElapsedTime(&b, e1, e2));
+        }
         RH_HIP(hipEventElapsedTime(&c, e3, e4));
         out->passes++; out->bin_ms += a; out->setup_ms += b; out->tile_ms += c;
     }
-    for (hipEvent_t e : dev->timing_events) dev->event_pool.push_back(e);
+    for (hipEvent_t e : dev->timing_events) if (e) dev->event_pool.push_back(e);
     dev->timing_events.clear();
     return 0;
 }

@@ -205,8 +205,9 @@ class Renderer:
         itself (identical results)."""
         _ffi.check(_ffi.lib().rh_device_set_option(self.device, _ffi.OPTION_SETUP_LAUNCH, 1 if enabled else 0))
 
-    def set_timing(self, enabled):
-        _ffi.check(_ffi.lib().rh_device_set_option(self.device, _ffi.OPTION_TIMING, 1 if enabled else 0))
+    def set_timing(self, mode):
+        """HIP-event marks around the phases of every pass (True / 1), around the tile kernel only (2), or none."""
+        _ffi.check(_ffi.lib().rh_device_set_option(self.device, _ffi.OPTION_TIMING, int(mode)))
 
     def drain_timings(self):
         t = _ffi.Timings()

@@ -16,6 +16,6 @@ done
 for round in $(seq ${ROUNDS:-2}); do
   for spec in "$@"; do
     name=${spec%%:*}; setting=; case $name in *@*) setting=${name#*@}; name=${name%%@*};; esac
-    env $setting RH_FRAG_CO_OVERRIDE=/tmp/$name.frag.co timeout -k 10 120 python bench.py --capture-frames 0 --no-cpu-baseline --no-alone --steps 20 --warmup 5 ${BENCH_ARGS} | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('%-14s %-18s' % ('$name', '$setting'), 'ms_per_step', round(d['ms_per_step'],4), 'tile_ms', round(d['roofline']['kernel_ms'],4), 'bin_ms', round(d['roofline']['binning_ms'],4), 'setup_ms', round(d['roofline']['setup_ms'],4))" || exit 1
+    env $setting RH_FRAG_CO_OVERRIDE=/tmp/$name.frag.co timeout -k 10 120 python bench.py --capture-frames 0 --no-cpu-baseline --no-alone --steps 20 --warmup 5 ${BENCH_ARGS} | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('%-14s %-18s' % ('$name', '$setting'), 'ms_per_step', round(d['ms_per_step'],4), 'tile_ms', round(d['roofline']['kernel_ms'],4), 'bin_ms', round(d['roofline']['binning_ms'] or 0,4), 'setup_ms', round(d['roofline']['setup_ms'] or 0,4))" || exit 1
   done
 done

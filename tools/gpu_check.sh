@@ -9,5 +9,5 @@ rc=$?; tail -3 gpurun_out/$TAG/tests.log
 timeout -k 10 300 python bench.py --capture-frames 0 --no-cpu-baseline > gpurun_out/$TAG/bench.json 2> gpurun_out/$TAG/bench.err || exit 1
 python - <<PY
 import json; d=json.load(open("gpurun_out/$TAG/bench.json")); r=d["roofline"]
-print("ms_per_step %.4f tile_ms %.4f setup_ms %.4f bin_ms %.4f frac %.4f value %.1fM" % (d["ms_per_step"], r["kernel_ms"], r["setup_ms"], r["binning_ms"], r["frac"], d["value"]/1e6))
+print("ms_per_step %.4f tile_ms %.4f setup_ms %.4f bin_ms %.4f frac %.4f value %.1fM" % (d["ms_per_step"], r["kernel_ms"], r["setup_ms"] or 0, r["binning_ms"] or 0, r["frac"], d["value"]/1e6))
 PY

@@ -5,6 +5,7 @@ missing or a call fails, an exception is raised (the reference panics on the cor
 """
 import ctypes as C
 import os
+import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "librenderer_hip.so")
@@ -156,6 +157,9 @@ SIGNATURES = {
 }
 
 _lib = None
+# Whether PyTorch was already imported when the library was loaded: only then do the two share one HIP runtime, and
+# only then can torch use memory the renderer allocated (partition.texture_as_tensor checks this).
+torch_came_first = None
 
 
 def lib():
@@ -170,6 +174,8 @@ def lib():
         # so that both share the one runtime; RH_HIP_RUNTIME=torch asks for that explicitly.
         if os.environ.get("RH_HIP_RUNTIME") == "torch":
             import torch  # noqa: F401
+        global torch_came_first
+        torch_came_first = "torch" in sys.modules
         L = C.CDLL(LIB_PATH)
         for name, (restype, argtypes) in SIGNATURES.items():
             fn = getattr(L, name)

@@ -127,7 +127,12 @@ def texture_as_tensor(texture, device):
     import torch
     from . import _ffi
     w, h, _ = texture.size
-    ptr = _ffi.lib().rh_texture_device_ptr(texture.handle)
+    lib = _ffi.lib()
+    if not _ffi.torch_came_first:
+        # two HIP runtimes in the process: torch's cannot see the renderer's allocations (it would fault, or find no GPU)
+        raise _ffi.RendererError("texture_as_tensor: librenderer_hip.so was loaded before PyTorch was imported, so the two use "
+                                 "separate HIP runtimes and cannot share device memory; import torch first, or set RH_HIP_RUNTIME=torch")
+    ptr = lib.rh_texture_device_ptr(texture.handle)
     return torch.as_tensor(_DeviceArray(ptr, (h, w, 4)), device=device)
 
 

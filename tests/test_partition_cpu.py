@@ -102,3 +102,23 @@ def test_gathers_world_size_2_gloo(tmp_path):
     port = _free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert sorted(os.listdir(tmp_path)) == ["ok0", "ok1"]
+
+
+def test_texture_as_tensor_refuses_two_hip_runtimes():
+    """A process that loaded librenderer_hip.so before importing PyTorch holds two HIP runtimes: torch cannot use the
+    renderer's device memory then, and the zero-copy view says so instead of faulting."""
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "from renderer_amd import _ffi, partition\n"
+        "_ffi.lib()\n"
+        "assert _ffi.torch_came_first is False\n"
+        "class T: size = (4, 4, 1); handle = None\n"
+        "try:\n"
+        "    partition.texture_as_tensor(T(), 'cpu')\n"
+        "except _ffi.RendererError as e:\n"
+        "    assert 'import torch first' in str(e); print('refused')\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "refused" in out.stdout, out.stderr[-2000:]

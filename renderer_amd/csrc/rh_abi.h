@@ -4,7 +4,7 @@
 #pragma once
 #include <stdint.h>
 
-#define RH_DEVICE_ABI_VERSION 22u
+#define RH_DEVICE_ABI_VERSION 23u
 #define RH_MODULE_MAGIC 0x52484d4fu   // "RHMO"
 
 #define RH_DEV_MAX_ATTRIBUTES 8
@@ -33,7 +33,7 @@ struct rh_module_info_t {
     uint32_t vertex_tag;     // hash of the vertex function's source name: ties a fragment object to its vertex object
     uint32_t rec_bytes;      // fragment objects: bytes of one set-up record (depends on the number of varyings)
     uint32_t ext_bytes;      // fragment objects: bytes of one extended record of a single-sampled pass
-    uint32_t poly_item_bytes;   // fragment objects: the form of footprint copies its bilinear body reads (rh_slot_dev::poly): 16 or 32
+    uint32_t poly_item_bytes;   // fragment objects: the form of footprint copies its bilinear body reads (rh_slot_dev::poly): 16, 32 or 48 (both)
 };
 
 struct rh_slot_dev {
@@ -45,7 +45,8 @@ struct rh_slot_dev {
                              // textures with `poly`: bytes of one footprint copy
     // Textures: null, or RH_POLY_COPIES copies of the texture made for bilinear sampling.  An item of a copy is the
     // whole 2x2 footprint of a texel: t(x, y), t(x+1, y), t(x, y+1), t(x+1, y+1) (clamped to the layer), so a fragment
-    // fetches its four taps at ONE address.  Two forms (rh_module_info_t::poly_item_bytes):
+    // fetches its four taps at ONE address.  Two forms (rh_module_info_t::poly_item_bytes; 48 there = both, RH_POLY_COPIES
+    // copies of the 32-byte form followed by as many of the 16-byte form in one block, `size_bytes` = one 32-byte copy):
     //   16 bytes: the four texels as they are;
     //   32 bytes: per channel c two dwords of f16 pairs, { t(x,y).c | (t(x+1,y).c - t(x,y).c) << 16 } and the same for
     //     the row below: 8-bit values and their differences are exact in f16, and an f32 fma that reads f16 operands
@@ -222,4 +223,7 @@ struct rh_tile_args {
     // again every round of pairs; 0: priorities are left alone.  The host passes a sixteenth of the pass's average tile
     // (pairs per tile * 32 rows / 16), so a wave runs at the top priority until its last fifth or so.
     uint32_t prio_quantum;
+    // Bodies that read footprint copies of both forms choose the form per primitive (PolyCopy::wide_for in rh_shader.h)
+    // by the width of the pass's first texture that has copies: floor(log2(width)), and whether it is a power of two.
+    uint32_t poly_log2w, poly_pow2;
 };

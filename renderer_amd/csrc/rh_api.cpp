@@ -1301,8 +1301,9 @@ int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer, rh_device::Pa
         // (rh_slot_dev::poly): made here, on the pass's stream, when the texels may have changed since they were made.
         // (Item offsets are computed in f32, exact below 2^24 bytes: 2^20 texels of 16-byte items, 2^19 of 32-byte ones.)
         const uint32_t item_bytes = pl->fs->info.poly_item_bytes;
-        const size_t poly_max_bytes = item_bytes == 32u ? ((size_t)2 << 20) : ((size_t)4 << 20);
-        bool all_poly = blend_class && tex_class == 1 && !dev->general_kernels && pl->samples == 1 && total > 0 && (item_bytes == 16u || item_bytes == 32u);
+        // (48: both forms, the 32-byte copies first and the 16-byte ones behind them in one block; the kernel picks per primitive)
+        const size_t poly_max_bytes = item_bytes >= 32u ? ((size_t)2 << 20) : ((size_t)4 << 20);
+        bool all_poly = blend_class && tex_class == 1 && !dev->general_kernels && pl->samples == 1 && total > 0 && (item_bytes == 16u || item_bytes == 32u || item_bytes == 48u);
         for (const SlotRef& sl : pl->slots)
             if (sl.kind == RH_SLOT_TEXTURE && (sl.tex->width % 32u != 0 || sl.tex->bytes > poly_max_bytes ||
                                                (no_alloc && !(sl.tex->poly && sl.tex->poly_item_bytes == item_bytes)))) all_poly = false;
@@ -1319,12 +1320,15 @@ int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer, rh_device::Pa
                     t->poly_item_bytes = item_bytes; t->poly_valid = false;
                 }
                 if (!t->poly_valid || t->poly_always) {
-                    rhk::polyphase_build(t->dptr, t->poly, t->width, t->height, t->layers, item_bytes, sm);
+                    rhk::polyphase_build(t->dptr, t->poly, t->width, t->height, t->layers, item_bytes == 48u ? 32u : item_bytes, sm);
+                    if (item_bytes == 48u)
+                        rhk::polyphase_build(t->dptr, (uint8_t*)t->poly + t->bytes / 4 * 32u * RH_POLY_COPIES, t->width, t->height, t->layers, 16u, sm);
                     RH_HIP(hipGetLastError());
                     t->poly_valid = true;
                 }
+                if (!ta.poly_log2w) { ta.poly_log2w = bits_for(t->width + 1) - 1; ta.poly_pow2 = (t->width & (t->width - 1)) == 0 ? 1u : 0u; }
                 ta.p.slots[i].poly = t->poly;
-                ta.p.slots[i].size_bytes = (uint32_t)(t->bytes / 4 * item_bytes);
+                ta.p.slots[i].size_bytes = (uint32_t)(t->bytes / 4 * (item_bytes == 48u ? 32u : item_bytes));
             }
             tex_class = 3;
         }

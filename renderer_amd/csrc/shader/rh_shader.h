@@ -34,9 +34,10 @@ typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));   // 
 RH_DEVICE v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 
 // The form of footprint copies the bilinear body reads (rh_slot_dev::poly): 32 = f16 pairs read by v_fma_mix_f32, 16 = the
-// texels as bytes.  Identical results; the code object tells the host which one to build (rh_module_info_t).
+// texels as bytes, 48 = both, picked per primitive (PolyCopy::pick).  Identical results; the code object tells the host
+// which to build (rh_module_info_t).
 #ifndef RH_POLY_ITEM_BYTES
-#define RH_POLY_ITEM_BYTES 32
+#define RH_POLY_ITEM_BYTES 48
 #endif
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 // fma(a, hi half, lo half) of a dword holding two f16: one v_fma_mix_f32
@@ -58,7 +59,7 @@ struct Texture2D {
     uint32_t static_rgba8;      // 1: known to be RGBA8, at least 2x2 and at most 16 MiB (texel offsets exact in f32)
     // Footprint copies regrouped by phase (rh_slot_dev::poly), when the kernel body was built for them: the copy picked for
     // the primitive being shaded (PolyCopy, prepared once per primitive by the tile kernel), else null.
-    const uint8_t* poly_base; float poly_invS, poly_C1;
+    const uint8_t* poly_base; float poly_invS, poly_C1, poly_C2, poly_C3; bool poly_wide;
     uint32_t static_poly;       // 1: the kernel body was built for textures that all have footprint copies: poly_base is set
 
     // Texel (x, y) of `layer` (generic path, any supported format): 8-bit channels on the 0..255 scale, float channels
@@ -114,23 +115,22 @@ struct Texture2D {
                 // Item x = xq * S + ph of row j sits at item ph * (W / S) + xq of the row in copy log2 S, i.e. at byte
                 //   B * (j * W + (x - xq * S) * (W / S) + xq) = x * (B * W / S) + xq * (B - B * W) + j * (B * W)      (B bytes per item)
                 // -- three products of small integers, every partial sum a multiple of B below 2^24 * B: exact in f32.
-                constexpr float Bf = (float)RH_POLY_ITEM_BYTES;
+                // (poly_C1 = B W / S, poly_C2 = B W, poly_C3 = B - B W: uniform, from PolyCopy::pick)
                 const float xqf = floorf(ibf * poly_invS);
-                const float offf = __builtin_fmaf(ibf, poly_C1, __builtin_fmaf(xqf, __builtin_fmaf(-Bf, (float)W, Bf), jbf * (Bf * (float)W)));
-#if RH_POLY_ITEM_BYTES == 32
-                const uint32_t off = (uint32_t)offf;
-                const uint4* const item = reinterpret_cast<const uint4*>(poly_base + (size_t)layer * (height * (width << 5)) + off);
-                const uint4 f0 = item[0], f1 = item[1];                  // channels 0, 1 and 2, 3: { left | right - left } of the upper, of the lower row
+                const uint32_t off = (uint32_t)__builtin_fmaf(ibf, poly_C1, __builtin_fmaf(xqf, poly_C3, jbf * poly_C2));
+                if (poly_wide) {
+                    // 32-byte items: channels 0, 1 and 2, 3 as { left | right - left } f16 pairs of the upper, of the lower row
+                    const uint4* const item = reinterpret_cast<const uint4*>(poly_base + (size_t)layer * (height * (width << 5)) + off);
+                    const uint4 f0 = item[0], f1 = item[1];
 #define RH_LERP_H2(ch, UP, LO) { const float top = lerp_h2(a, UP), bot = lerp_h2(a, LO); \
                                  r.ch = __builtin_fmaf(b, bot, __builtin_fmaf(-b, top, top)) * scale; }
-                RH_LERP_H2(x, f0.x, f0.y) RH_LERP_H2(y, f0.z, f0.w) RH_LERP_H2(z, f1.x, f1.y) RH_LERP_H2(w, f1.z, f1.w)
+                    RH_LERP_H2(x, f0.x, f0.y) RH_LERP_H2(y, f0.z, f0.w) RH_LERP_H2(z, f1.x, f1.y) RH_LERP_H2(w, f1.z, f1.w)
 #undef RH_LERP_H2
-                return r;
-#else
-                const uint32_t off = (uint32_t)offf;
-                const uint4 f = *reinterpret_cast<const uint4*>(poly_base + (size_t)layer * (height * (width << 4)) + off);   // the four taps
+                    return r;
+                }
+                // 16-byte items: the four taps as they are
+                const uint4 f = *reinterpret_cast<const uint4*>(poly_base + (size_t)layer * (height * (width << 4)) + off);
                 t00 = f.x; t10 = f.y; t01 = f.z; t11 = f.w;
-#endif
 #if defined(RH_EXP) && RH_EXP == 2      /* diagnostic build: the read, but no filter */
                 return make_float4(__uint_as_float(t00 ^ t10) * a, __uint_as_float(t01 ^ t11) * b, 0.5f, 0.8f);
 #endif
@@ -172,25 +172,48 @@ struct Texture2D {
 // phase modulo S = 2^k, with S about the distance in texels between the samples of neighbouring fragments.  Any k gives
 // the same texels; the choice only decides how many cache lines a wave touches.
 struct PolyCopy {
-    // invS = 2^-k for copy k; C1 = item bytes * width * 2^-k (see Texture2D::sample)
-    const uint8_t* base = nullptr; float invS = 1.0f, C1 = 0.0f;
-    // grad_log2 = floor(log2(1.41 * |d coordinate / dx| per pixel)).  Everything is uniform and is kept on the scalar
-    // unit (readfirstlane: the clamp would otherwise be done, and its results kept, in vector registers); the power of
-    // two divides by exponent arithmetic (width >= 32, k <= 5: nowhere near a denormal).
-    RH_DEVICE void pick(const rh_slot_dev& slot, int grad_log2) {
+    // invS = 2^-k for copy k; with B the bytes of an item: C1 = B * width * 2^-k, C2 = B * width, C3 = B - B * width (see
+    // Texture2D::sample); wide: the copy holds the 32-byte items
+    const uint8_t* base = nullptr; float invS = 1.0f, C1 = 0.0f, C2 = 0.0f, C3 = 0.0f; bool wide = RH_POLY_ITEM_BYTES != 16;
+    // grad_log2 = floor(log2(1.41 * |d coordinate / dx| per pixel)).  Everything is uniform and is kept on the scalar unit (readfirstlane: the clamp would otherwise be
+    // done, and its results kept, in vector registers); the power of two divides by exponent arithmetic (width >= 32,
+    // k <= 5: nowhere near a denormal).
+    // Which items: the 32-byte ones cost two loads per fragment and pay where the lanes of a wave read neighbouring
+    // items -- a magnified or barely minified texture (copy 0), or one minified by a power of two, whose copy puts the
+    // texels that far apart side by side.  At any other ratio neighbouring fragments' items are scattered whatever the
+    // copy, every load is a cache line of its own, and the 16-byte items' one load is what counts (a 256-texel texture
+    // over 24-px quads: twice as fast).
+    // (`wide_items`: the caller's choice for the primitive, wide_for() below, one for all its texture slots)
+    RH_DEVICE void pick(const rh_slot_dev& slot, int grad_log2, bool wide_items) {
         int k = grad_log2 + (31 - __builtin_clz(slot.width | 1u));
         k = k < 0 ? 0 : (k > RH_POLY_COPIES - 1 ? RH_POLY_COPIES - 1 : k);
         k = __builtin_amdgcn_readfirstlane(k);
-        base = reinterpret_cast<const uint8_t*>(slot.poly) + (size_t)((uint32_t)k * slot.size_bytes);    // size_bytes of a texture slot: bytes of one copy
+        const bool both = RH_POLY_ITEM_BYTES == 48;
+        wide = both ? wide_items : RH_POLY_ITEM_BYTES == 32;
+        // slot.size_bytes: bytes of one copy (of the 32-byte form when both are there: those come first, the 16-byte ones behind them)
+        const uint32_t narrow_size = both ? slot.size_bytes >> 1 : slot.size_bytes;
+        const size_t at = wide ? (size_t)((uint32_t)k * slot.size_bytes)
+                               : (size_t)(both ? (uint32_t)RH_POLY_COPIES * slot.size_bytes : 0u) + (size_t)((uint32_t)k * narrow_size);
+        base = reinterpret_cast<const uint8_t*>(slot.poly) + at;
         invS = __uint_as_float((uint32_t)(127 - k) << 23);
-        const uint32_t bw = __builtin_amdgcn_readfirstlane(__float_as_uint((float)(slot.width * (uint32_t)RH_POLY_ITEM_BYTES)));
-        C1 = __uint_as_float(bw - ((uint32_t)k << 23));        // (a slot with copies has a width)
+        const uint32_t B = wide ? 32u : 16u;
+        const float bw = (float)(slot.width * B);
+        const uint32_t bw_bits = __builtin_amdgcn_readfirstlane(__float_as_uint(bw));
+        C1 = __uint_as_float(bw_bits - ((uint32_t)k << 23));        // (a slot with copies has a width)
+        C2 = __uint_as_float(bw_bits);
+        C3 = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint((float)B - bw)));
+    }
+    // The choice for a primitive whose gradient hint is (grad_log2, near), going by a texture 2^log2_width texels wide.
+    static RH_DEVICE bool wide_for(int grad_log2, bool near, uint32_t log2_width, bool width_is_pow2) {
+        if (RH_POLY_ITEM_BYTES != 48) return RH_POLY_ITEM_BYTES == 32;
+        return grad_log2 + (int)log2_width <= 0 || (near && width_is_pow2);
     }
 };
 
 struct BindingContext {
     const rh_draw_params* p;
     uint32_t static_rgba8 = 0, static_filter = 0, static_poly = 0;
+    uint32_t static_wide = 0;            // (static_poly) 1: every slot's copies are the 32-byte ones, 2: the 16-byte ones, 0: PolyCopy::wide says
     PolyCopy poly[RH_DEV_MAX_SLOTS];     // (static_poly) per texture slot; slots a shader does not sample cost nothing
     // A read-only storage buffer as an array of T.  An element that does not lie inside the bound buffer reads as
     // zeros (what wgpu's robust buffer access guarantees at worst), so a draw with more instances than the buffer
@@ -212,7 +235,7 @@ struct BindingContext {
         const rh_slot_dev& s = p->slots[set * 4 + binding];
         const PolyCopy& c = poly[set * 4 + binding];
         return Texture2D{ reinterpret_cast<const uint8_t*>(s.ptr), s.width, s.height, s.layers, s.format, static_rgba8,
-                          c.base, c.invS, c.C1, static_poly };
+                          c.base, c.invS, c.C1, c.C2, c.C3, static_wide ? static_wide == 1u : c.wide, static_poly };
     }
     RH_DEVICE Sampler sampler(uint32_t set, uint32_t binding) const {
         return Sampler{ p->slots[set * 4 + binding].filter, static_filter };

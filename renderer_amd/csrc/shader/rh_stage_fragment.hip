@@ -50,8 +50,9 @@ static_assert(ROUND == 8 || ROUND == 16 || ROUND == 32, "a round is at most one 
 // ---- record layout (dwords) -------------------------------------------------------------------------------------------
 // Set-up record, staged through LDS by the tile wave:
 //   [0] header: box x0 | y0 << 5 | x1 << 10 | y1 << 15 (tile-relative, inclusive, 0..31 each; x0 > x1: contributes
-//       nothing) | flags << 20 | g << 26, g = floor(log2(1.41 * largest |d varying / dx| per pixel)) over the cluster's
-//       planes clamped to -32..31: how far apart neighbouring fragments sample a texture, in units of its size
+//       nothing) | flags << 20 | hint << 26.  hint = near | g << 1 with g = floor(log2(1.41 * largest |d varying / dx| per
+//       pixel)) over the cluster's planes clamped to -16..15: how far apart neighbouring fragments sample a texture, in
+//       units of its size; near: that distance is within half a per cent of a power of two
 //   [1..3] shared diagonal of a rectangle (edge 1 of triangle A): A, B, T
 //   then per triangle TRI_WORDS: XR, YR (reference vertex in 24.8 fixed point relative to the tile origin, as f32, exact),
 //   v0[NV], dvdx[NV], dvdy[NV] (gradients per 1/256 pixel)
@@ -70,14 +71,19 @@ static_assert(REC_WORDS % 4 == 0 && EXT_WORDS % 4 == 0, "records move as 16-byte
 
 constexpr uint32_t BBOX_EMPTY = 0x000000ffu;    // x0 = 255 > x1 = 0 (the kernels work with boxes as x0 | y0 << 8 | x1 << 16 | y1 << 24)
 constexpr uint32_t HDR_EMPTY = 31u;             // header of a record that contributes nothing: x0 = 31 > x1 = 0, no flags
-RH_DEVICE uint32_t hdr_pack(uint32_t box, uint32_t flags, int g) {
+// `gmax`: the largest |d varying / dx| of the cluster, per 1/256 pixel.
+RH_DEVICE uint32_t hdr_pack(uint32_t box, uint32_t flags, float gmax) {
     if (box == BBOX_EMPTY) return HDR_EMPTY;
-    g = g < -32 ? -32 : (g > 31 ? 31 : g);
-    return (box & 31u) | (((box >> 8) & 31u) << 5) | (((box >> 16) & 31u) << 10) | (((box >> 24) & 31u) << 15) | (flags << 20) | ((uint32_t)g << 26);
+    int g = (int)((__float_as_uint(gmax * (256.0f * 1.41421356f)) >> 23) & 0xffu) - 127;
+    g = g < -16 ? -16 : (g > 15 ? 15 : g);
+    // (a power of two times 1 +- 0.005: the fraction bits of the distance per pixel are nearly all zeros or nearly all ones)
+    const uint32_t frac = __float_as_uint(gmax * 256.0f) & 0x7fffffu;
+    const uint32_t near = (frac < 41943u || frac > 8304721u) ? 1u : 0u;
+    return (box & 31u) | (((box >> 8) & 31u) << 5) | (((box >> 16) & 31u) << 10) | (((box >> 24) & 31u) << 15) | (flags << 20) | (near << 26) | ((uint32_t)g << 27);
 }
 RH_DEVICE uint32_t hdr_box(uint32_t h) { return (h & 31u) | (((h >> 5) & 31u) << 8) | (((h >> 10) & 31u) << 16) | (((h >> 15) & 31u) << 24); }
 RH_DEVICE uint32_t hdr_flags(uint32_t h) { return (h >> 20) & 63u; }
-RH_DEVICE int hdr_grad(uint32_t h) { return (int)h >> 26; }
+RH_DEVICE int hdr_hint(uint32_t h) { return (int)h >> 26; }          // the six bits as one signed number (compared, and taken apart by PolyCopy::pick)
 constexpr uint32_t FLAG_PERSP_A = 1u, FLAG_PERSP_B = 2u, FLAG_HAS_A = 4u, FLAG_HAS_B = 8u, FLAG_BIG = 16u, FLAG_RECT = 32u;
 } // namespace rh
 
@@ -286,7 +292,7 @@ RH_DEVICE void write_records(const PairSetup& s, int ox, int oy, uint32_t* w, ui
         const TriSetup& tg = has_a ? s.ta : s.tb;
 #pragma unroll
         for (int v = 0; v < NV; v++) g = fmaxf(g, fabsf(tg.dvdx[v]));
-        w[0] = hdr_pack(bbox, flags, (int)((__float_as_uint(g * (256.0f * 1.41421356f)) >> 23) & 0xffu) - 127);
+        w[0] = hdr_pack(bbox, flags, g);
     }
     w[1] = edge_word(s.ta, 1, false); w[2] = edge_word(s.ta, 4, false); w[3] = edge_word(s.ta, 7, false);      // the shared diagonal (used when RECT: never BIG)
     const TriSetup* const ts[2] = { &s.ta, &s.tb };
@@ -464,7 +470,7 @@ RH_DEVICE void setup_lean_pair(const rh_draw_params& p, uint32_t cluster, int ox
     uint32_t t[TRI_WORDS], dg[3];
     float g;
     lean_triangle(ta, tb, tc, ox, oy, t, !half, dg, g);
-    if (!half) q[0] = make_uint4(hdr_pack(bbox, FLAG_HAS_A | FLAG_HAS_B | FLAG_RECT, (int)((__float_as_uint(g * (256.0f * 1.41421356f)) >> 23) & 0xffu) - 127), dg[0], dg[1], dg[2]);
+    if (!half) q[0] = make_uint4(hdr_pack(bbox, FLAG_HAS_A | FLAG_HAS_B | FLAG_RECT, g), dg[0], dg[1], dg[2]);
     uint4* const qt = q + HDR_WORDS / 4 + (half ? TRI_WORDS / 4 : 0);
 #pragma unroll
     for (int i = 0; i < TRI_WORDS / 4; i++) qt[i] = make_uint4(t[4 * i], t[4 * i + 1], t[4 * i + 2], t[4 * i + 3]);
@@ -568,6 +574,7 @@ RH_DEVICE bool edges_inside_i32(const float* e, int lx, int ly) {
 
 constexpr int PACK_MAX = 4;               // boxes that may share one shading pass
 template <bool B> struct Flag { static constexpr bool value = B; };
+template <int N> struct Int { static constexpr int value = N; };
 
 // ---- attachment pixels --------------------------------------------------------------------------------------------
 // LDS slot of one attachment pixel.  Narrow kernels (every attachment 8-bit UNORM): the packed pixel, r in byte 0 (an R8
@@ -746,6 +753,10 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
 
     // 2. rounds of records
     int picked_grad = -1000;                            // the gradient hint the footprint copies were last picked for
+    // Which form of footprint items the primitive at hand reads (PolyCopy::wide_for): one choice for all its texture
+    // slots, going by the width of the first of them (the host says which); the pass loops exist once for either form.
+    bool wide_items = true;
+    const uint32_t poly_log2w = a.poly_log2w; const bool poly_pow2 = a.poly_pow2 != 0u;      // (the width of the pass's first texture with copies)
     // (the values of a round's pairs are fetched a round ahead: the set-up below starts with them)
     static_assert(2 * ROUND <= 64, "two lanes per pair of a round");
     const int pl = lane & (ROUND - 1);                  // the pair of the round this lane works on while the round is set up ...
@@ -808,7 +819,16 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
         {
             const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
             const int dest = hit ? below : nh + lane - below;
-            const uint32_t info = (uint32_t)lane | (fl << 6) | ((hdr >> 26) << 12) | ((uint32_t)npx << 18) | (lean_hit ? INFO_LEAN : 0u) | (small ? INFO_SMALL : 0u);
+            // (the hint, with what makes no difference to the copies taken out: beyond the last copy and below the first
+            // one every distance reads the same copy, in the 32-byte form -- so a scene of tiny quads of many sizes, or
+            // of magnified ones, does not pick anew hit after hit)
+            uint32_t hint6 = hdr >> 26;
+            if (TEX == 3) {
+                const int k = ((int)hdr >> 27) + (int)poly_log2w;
+                if (k >= RH_POLY_COPIES - 1) hint6 = (((uint32_t)(RH_POLY_COPIES - 1 - (int)poly_log2w) << 1) | 1u) & 63u;
+                else if (k <= 0) hint6 = ((uint32_t)(-(int)poly_log2w) << 1) & 63u;
+            }
+            const uint32_t info = (uint32_t)lane | (fl << 6) | (hint6 << 12) | ((uint32_t)npx << 18) | (lean_hit ? INFO_LEAN : 0u) | (small ? INFO_SMALL : 0u);
             box_v = (uint32_t)__builtin_amdgcn_ds_permute(dest << 2, (int)bb);
             info_v = (uint32_t)__builtin_amdgcn_ds_permute(dest << 2, (int)(hit ? info : 0u));
         }
@@ -870,7 +890,10 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
         // tests and of lane masks: a lane past the last pixel shades the last pixel once more -- same inputs, same result,
         // the same bytes written to the same place.  The arguments are wave-uniform for a hit that runs alone, per lane
         // for a pack.
-        auto lean_passes = [&](const float hx0f, const float hy0f, const float wf, const float invw, float idx_f, const float last_f, const int npass, const float* const rf) {
+        auto lean_passes = [&](auto wide_tag, const float hx0f, const float hy0f, const float wf, const float invw, float idx_f, const float last_f, const int npass, const float* const rf) {
+            // (this copy of the loop reads one form of items: known to the compiler through the context's static_wide)
+            FragmentContext fc = fctx;
+            if (TEX == 3) fc.static_wide = decltype(wide_tag)::value ? 1u : 2u;
             const float half_invw = 0.5f * invw;
             const float4 dh = *reinterpret_cast<const float4*>(rf);                     // header, diagonal A, B, T
             const float3 dg = make_float3(dh.y, dh.z, dh.w);
@@ -906,7 +929,7 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
 #pragma unroll
                 for (int v = 0; v < NV; v++) vf[v] = __builtin_fmaf(tp[OFF_DVDY + v], dy, __builtin_fmaf(tp[OFF_DVDX + v], dx, tp[OFF_V0 + v]));
                 Outputs out;
-                fragment_main(fctx, var, out);
+                fragment_main(fc, var, out);
 #pragma unroll
                 for (int t = 0; t < NA; t++) {
                     blend_pixel<BLEND>(reinterpret_cast<PxT*>(px_bytes + (size_t)t * (TILE_PX * sizeof(PxT)) + (size_t)pb * (sizeof(PxT) / 4)), a.att[t],
@@ -925,8 +948,27 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
         // (nh >= 1; the three bodies are the arms of one if / else chain, so that every hit crosses few branches)
         // The loop exists twice: a round none of whose hits changes the footprint copies -- nearly every round -- runs a
         // loop that does not know of them, so that what was picked is not carried around the loop hit by hit.
-        auto hit_loop = [&](auto repicks_tag) {
+        // the footprint copy of every texture slot for the primitive of a hit (uniform; unused slots fold away)
+        auto repick = [&](const uint32_t info) {
+            const int hint = (int)(info << 14) >> 26;
+            wide_items = PolyCopy::wide_for(hint >> 1, (hint & 1) != 0, poly_log2w, poly_pow2);
+#pragma unroll
+            for (int i = 0; i < RH_DEV_MAX_SLOTS; i++) fctx.poly[i].pick(p.slots[i], hint >> 1, wide_items);
+        };
+        // ... and, where nothing is picked anew, once for either form of footprint items, so that the loop and the passes
+        // it runs know the form at compile time (ITEMS: 1 the 32-byte items, 2 the 16-byte ones, 0 looked up as they go).
+        auto hit_loop = [&](auto repicks_tag, auto wide_tag) {
         constexpr bool REPICKS = decltype(repicks_tag)::value;
+        constexpr int ITEMS = decltype(wide_tag)::value;
+        auto run_lean = [&](const float x0, const float y0, const float w, const float invw, const float idx, const float last, const int np, const float* const rfp) {
+            if (ITEMS == 1) lean_passes(Flag<true>{}, x0, y0, w, invw, idx, last, np, rfp);
+            else if (ITEMS == 2) lean_passes(Flag<false>{}, x0, y0, w, invw, idx, last, np, rfp);
+            else if (wide_items) lean_passes(Flag<true>{}, x0, y0, w, invw, idx, last, np, rfp);
+            else lean_passes(Flag<false>{}, x0, y0, w, invw, idx, last, np, rfp);
+        };
+        FragmentContext fg = fctx;                      // the general body's: the form known where the loop knows it
+        if (TEX == 3 && ITEMS != 0) fg.static_wide = (uint32_t)ITEMS;
+        FragmentContext& fgen = ITEMS != 0 ? fg : fctx;  // (the loop that picks anew reads what it picked)
         int k = 0;
         do {
             const uint32_t info = __builtin_amdgcn_readlane(info_v, k);
@@ -936,16 +978,13 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
                 const float invw = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(invw_v), k));
                 const float last_f = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(last_v), k));
                 k++;
-                lean_passes((float)(boxw & 0xffu), (float)((boxw >> 8) & 0xffu), (float)((boxw >> 16) & 0xffu), invw, lane_f, last_f, (int)((((info >> 18) & 0x7ffu) + 63u) >> 6),
-                            recf + (int)(info & 0x3fu) * REC_WORDS);
+                const float bx = (float)(boxw & 0xffu), by = (float)((boxw >> 8) & 0xffu), bwf = (float)((boxw >> 16) & 0xffu);
+                const int np = (int)((((info >> 18) & 0x7ffu) + 63u) >> 6);
+                const float* const rfk = recf + (int)(info & 0x3fu) * REC_WORDS;
+                run_lean(bx, by, bwf, invw, lane_f, last_f, np, rfk);
                 continue;
             }
-            if (REPICKS && (info & INFO_REPICK)) {
-                // the footprint copy of every texture slot for this primitive (uniform; unused slots fold away)
-                const int grad_log2 = (int)(info << 14) >> 26;
-#pragma unroll
-                for (int i = 0; i < RH_DEV_MAX_SLOTS; i++) fctx.poly[i].pick(p.slots[i], grad_log2);
-            }
+            if (REPICKS && (info & INFO_REPICK)) repick(info);
             if (info & INFO_SMALL) {
                 // a pack: every lane takes the box and the record of the member its pixel belongs to.  Where the members
                 // start is wave-uniform, so "lane >= start" is a mask the scalar unit makes with a shift, and the member
@@ -962,8 +1001,10 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
                 const uint32_t mb = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)boxw_v);
                 const float minvw = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)__float_as_uint(invw_v)));
                 // (the lanes past the pack's pixels shade its last pixel again)
-                lean_passes((float)(mb & 0xffu), (float)((mb >> 8) & 0xffu), (float)((mb >> 16) & 0xffu), minvw, (float)(int)((uint32_t)lane - st),
-                            (float)(int)((run & 127u) - 1u - st), 1, recf + (int)(mb >> 24) * REC_WORDS);
+                const float mx = (float)(mb & 0xffu), my = (float)((mb >> 8) & 0xffu), mw = (float)((mb >> 16) & 0xffu);
+                const float midx = (float)(int)((uint32_t)lane - st), mlast = (float)(int)((run & 127u) - 1u - st);
+                const float* const mrf = recf + (int)(mb >> 24) * REC_WORDS;
+                run_lean(mx, my, mw, minvw, midx, mlast, 1, mrf);
                 k += 1 + (int)(((~c1 >> 6) & 1u) + ((~c2 >> 6) & 1u) + ((~c3 >> 6) & 1u));         // (a start is below 64, or 127)
             } else {
             const uint32_t rec_index = info & 0x3fu;
@@ -974,7 +1015,7 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
             const float hx0f = (float)(boxw & 0xffu), hy0f = (float)((boxw >> 8) & 0xffu), wf = (float)((boxw >> 16) & 0xffu);
             const int npass = (int)((((info >> 18) & 0x7ffu) + 63u) >> 6);
             k++;
-            if (info & INFO_LEAN) lean_passes(hx0f, hy0f, wf, invw, lane_f, last_f, npass, rf);
+            if (info & INFO_LEAN) run_lean(hx0f, hy0f, wf, invw, lane_f, last_f, npass, rf);
             else {
             const uint32_t flags = (info >> 6) & 0x3fu;
             const float half_invw = 0.5f * invw;
@@ -1025,7 +1066,7 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
                     }
                     if (cov) {
                         Outputs out;
-                        fragment_main(fctx, var, out);
+                        fragment_main(fgen, var, out);
 #pragma unroll
                         for (int t = 0; t < NA; t++) {
                             blend_pixel<BLEND>(tile_px + t * TILE_PX + pidx, a.att[t],
@@ -1044,8 +1085,13 @@ RH_DEVICE void tile_kernel(const rh_tile_args& a, TileLds<NA, WIDE>& lds) {
             }       // a hit alone
         } while (k < nh);
         };
-        if (TEX == 3 && __ballot((info_v & INFO_REPICK) != 0u && lane < nh) != 0ull) hit_loop(Flag<true>{});
-        else hit_loop(Flag<false>{});
+        // (a change at the round's first hit only -- the first round of a tile, as a rule -- is made here, ahead of the loop)
+        unsigned long long changes = TEX == 3 ? __ballot((info_v & INFO_REPICK) != 0u && lane < nh) : 0ull;
+        if (changes & 1ull) { repick(__builtin_amdgcn_readlane(info_v, 0)); changes &= ~1ull; if (lane == 0) info_v &= ~INFO_REPICK; }
+        if (changes) hit_loop(Flag<true>{}, Int<0>{});
+        else if (TEX != 3) hit_loop(Flag<false>{}, Int<0>{});
+        else if (wide_items) hit_loop(Flag<false>{}, Int<1>{});
+        else hit_loop(Flag<false>{}, Int<2>{});
         RH_PHASE_MARK(2)
     }
 

@@ -193,6 +193,25 @@ def test_last_tiles_cut_into_bands_of_rows_multisampled(oracle, samples, fmt, ro
             assert_same(got[key], want[key], f"mode={mode} {key}")
 
 
+@pytest.mark.parametrize("name,scene_fn", [
+    ("12 px (21:1, not a power of two: 16-byte items)", lambda: scenes.random_quads_scene(20000, 12, 1280, 720, seed=61)),
+    ("24 px (10.7:1: 16-byte items)", lambda: scenes.random_quads_scene(6000, 24, 1280, 720, seed=62)),
+    ("16 px (16:1: 32-byte items)", lambda: scenes.random_quads_scene(12000, 16, 1280, 720, seed=63)),
+    ("sides 3..70 px mixed (the form changes from hit to hit inside a round)", lambda: scenes.tiny_quads_scene(9000, 1280, 720, seed=64, lo=3, hi=70)),
+    ("sides 2..8 px, packs (64:1 and beyond)", lambda: scenes.tiny_quads_scene(60000, 1280, 720, seed=65)),
+])
+def test_both_forms_of_footprint_items_match_the_oracle(oracle, name, scene_fn):
+    """The bilinear body reads a texture through 32-byte footprint items (f16 pairs) where neighbouring fragments read
+    neighbouring items -- magnified, or minified by a power of two -- and through 16-byte ones (the texels as bytes)
+    elsewhere, chosen per primitive from the gradient hint in its record; the two give the same bits.  Both blends."""
+    for blend in ("premultiplied", "additive"):
+        scene = scene_fn(); scene["blend"] = blend
+        want = scenes.draw_oracle(scene)
+        got = scenes.draw_hip(scene, twice=True)
+        assert_same(got["color"], want["color"], f"{name} / {blend}")
+        assert want["fragments"] > 0
+
+
 def test_wave_priority_changes_no_byte(oracle):
     """The tile waves' issue priority (RH_OPTION_WAVE_PRIORITY) only changes which wave a SIMD serves first: the oracle's
     bytes with it and without, whole tiles and bands."""

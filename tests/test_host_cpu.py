@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/renderer_hip.h but not exported"
     # the ctypes binding covers exactly the declared surface
     assert sorted(_ffi.SIGNATURES) == declared
-    assert lib.rh_abi_version() == 22
+    assert lib.rh_abi_version() == 23
 
 
 def test_shader_code_objects_are_gfx950_elf():

@@ -199,6 +199,10 @@ def test_last_tiles_cut_into_bands_of_rows_multisampled(oracle, samples, fmt, ro
     ("16 px (16:1: 32-byte items)", lambda: scenes.random_quads_scene(12000, 16, 1280, 720, seed=63)),
     ("sides 3..70 px mixed (the form changes from hit to hit inside a round)", lambda: scenes.tiny_quads_scene(9000, 1280, 720, seed=64, lo=3, hi=70)),
     ("sides 2..8 px, packs (64:1 and beyond)", lambda: scenes.tiny_quads_scene(60000, 1280, 720, seed=65)),
+    ("a texture 96 texels wide (not a power of two: the hint's power-of-two bit says nothing about it)",
+     lambda: dict(scenes.random_quads_scene(8000, 16, 1280, 720, seed=66), texture=np.ascontiguousarray(scenes.load_letter_f()[40:104, 80:176]))),
+    ("a texture 2048 texels wide, magnified and minified", lambda: dict(scenes.tiny_quads_scene(4000, 1280, 720, seed=67, lo=3, hi=90),
+                                                                       texture=np.ascontiguousarray(np.tile(scenes.load_letter_f(), (1, 8, 1))[:128]))),
 ])
 def test_both_forms_of_footprint_items_match_the_oracle(oracle, name, scene_fn):
     """The bilinear body reads a texture through 32-byte footprint items (f16 pairs) where neighbouring fragments read

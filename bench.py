@@ -562,8 +562,8 @@ def main():
                          # with that work sharing the GPU
                          "overlapped": overlapped,
                          # "hbm" is how the path is priced (bytes the reference's semantics move per fragment); the tile
-                         # lives in LDS, so what the kernel actually runs into is the SIMDs' instruction issue rate
-                         "limited_by": "VALU instruction issue (LDS-resident tile: HBM traffic is a tenth of the algorithmic bytes)"},
+                         # lives in LDS, so what the kernel actually runs into is on the CU, not in memory
+                         "limited_by": "instruction issue and, by now as much, the chain of LDS and texture round trips a wave makes per 64-pixel pass (LDS-resident tile: HBM traffic is a tenth of the algorithmic bytes)"},
         }
         if alone is not None and alone["kernel_ms"] > 0:
             # the same kernel over the same frames with nothing beside it (untimed leg above): the kernel's own figure

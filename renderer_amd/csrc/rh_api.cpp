@@ -1148,8 +1148,8 @@ int execute_pass(rh_device* dev, const PassCmd& c, bool may_defer, rh_device::Pa
     // to stop for good at the first one binned early, under some assignments of the streams to hardware queues and not
     // under others; a recording run renders on the main stream alone, as it always has for a scene that moves)
     // (and, in the default mode, only a pass with a long binning chain: beside a tile kernel the chain gets the places
-    // that kernel's workgroups leave, slows it down and still ends behind it -- measured at 4K, that costs a frame with
-    // 2 M pairs 3 % and gains one with 3.6 M or more 1 .. 4 %)
+    // that kernel's workgroups leave, slows it down and still ends behind it -- measured at 4K, a frame with 2 M pairs
+    // gains or loses 2 .. 3 % by it depending on what else is in the streams, one with 3.6 M or more gains 1 .. 4 %)
     const bool early_pays = dev->early_binning >= 2 || dev->pair_guess >= dev->early_min_pairs;
     const bool early = deferred && alternating && dev->early_binning && early_pays && !vertex_reads_texture && buffers_settled && dev->before_tile_valid &&
                        (dev->compressors == 0 || getenv("RH_EXP_EARLY_WITH_COMPRESSOR"));
